@@ -1,0 +1,260 @@
+/*
+ * vinet_hip.h -- C ABI of libvinet_hip.so: the MI355X (gfx950) kernels behind
+ * the ViNet / AViNet saliency hot path.
+ *
+ * The reference (samyak0210/ViNet) has no FFI seam of its own: its hot path is
+ * `nn.Module`s calling aten.  The seam this library fills is therefore "the
+ * aten ops that model_utils.py / model.py / loss.py execute", one entry point
+ * per kernel family x direction.  Each declaration cites the reference call
+ * site(s) (file:line under /root/reference) whose device work it replaces.
+ *
+ * Conventions
+ *  - plain C, POD structs, no torch types.  All pointers are DEVICE pointers
+ *    unless named `host_*`.
+ *  - the caller owns every buffer (inputs, outputs, workspaces).  The library
+ *    allocates nothing, creates no streams and never synchronises: work is
+ *    enqueued on the `hipStream_t` passed in (as `void*`), on the device that
+ *    is current for the calling thread.
+ *  - re-entrant; safe to call from several host threads (one per device /
+ *    autograd worker threads).
+ *  - return value: 0 = ok; negative = invalid argument (see
+ *    vinet_last_error()); positive = hipError_t from the launch.
+ *  - activations are CHANNELS-LAST 5-D views `[B][T][H][W][C]` (the torch
+ *    `channels_last_3d` memory format of a logical NCDHW tensor), described by
+ *    VinetTensor: W-stride `ld` elements (>= C, so a view may be a channel
+ *    slice of a wider concat buffer), H-stride `W*ld`, T-stride `H*W*ld`,
+ *    batch stride `sB` (so a view may also be a T slice of a longer buffer).
+ *  - dtype: VINET_F32 (parity path) or VINET_BF16 (throughput path); all
+ *    accumulation, BN statistics and loss arithmetic are fp32/fp64.
+ */
+#ifndef VINET_HIP_H
+#define VINET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VINET_ABI_VERSION 1
+
+enum { VINET_F32 = 0, VINET_BF16 = 1 };
+enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
+enum { VINET_CONV_GENERIC = 0, VINET_CONV_STEM = 1 };
+
+typedef struct VinetTensor {
+  void* ptr;      /* element [0,0,0,0,0] of the view */
+  int32_t B, T, H, W, C;
+  int32_t ld;     /* elements between consecutive W positions */
+  int64_t sB;     /* elements between consecutive batch items */
+} VinetTensor;
+
+/* A per-channel affine (+ReLU) applied to a tensor WHILE IT IS LOADED: the
+ * consumer-side form of BatchNorm3d(+ReLU) in training mode, where the
+ * producer conv stores its raw output and the statistics only exist after the
+ * whole tensor has been written (model_utils.py:132-133,145-146,149-150).
+ * scale == NULL means identity. */
+typedef struct VinetAffine {
+  const float* scale;
+  const float* shift;
+  int32_t relu;
+} VinetAffine;
+
+/* ------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA.
+ * Replaces nn.Conv3d forward and its two backward halves wherever the
+ * reference calls them: model_utils.py:131,144,148 (BasicConv3d / SepConv3d),
+ * model.py:256,261,266,271,275,280,282 (decoder), and, with T as the 1-D axis,
+ * nn.Conv2d (k,1) of SoundNet model.py:750-791.
+ *
+ *   y[b, (to,ho,wo) -> storage pos, n] (+)= act( out_scale[n] * sum_{tap,c}
+ *        pre(x[b, to*sT+dt_tap, ho*sH+dh_tap, wo*sW+dw_tap, c]) * w[slice_tap][n][c] + out_shift[n] )
+ *
+ *  - `taps`: ntaps x int32[4] = (dt, dh, dw, weight slice); padding is folded
+ *    into the offsets (dt = kt - padT ...), out-of-range reads are zero.  A
+ *    transposed convolution (dgrad of a strided conv) is expressed by the
+ *    caller as one launch per stride phase with that phase's tap subset.
+ *  - `w`: packed [nslices][N][Kp], Kp = Cin rounded up to 32, same dtype as x
+ *    (see vinet_pack_weights).
+ *  - output storage position = (to*omT+ooT, ho*omH+ooH, wo*omW+ooW) inside
+ *    `y`, so producers write straight into concat buffers / phase-strided
+ *    gradients (torch.cat at model_utils.py:187, model.py:290,296,302 is never
+ *    materialised as a copy).
+ *  - `stats` (optional): per-M-tile partial sums of the pre-activation values,
+ *    layout [tilesM][2][N] fp32 (sum, sum of squares), tilesM =
+ *    ceil(M / vinet_conv3d_tile_m(desc)); reduced by vinet_bn_finalize.
+ *  - mode VINET_CONV_STEM: x has C == 4 (3 + zero pad), taps index kernel
+ *    rows only and each K chunk of 32 is 8 consecutive W positions x 4
+ *    channels (the 1x7x7 stride-2 stem, model.py:693 / model_utils.py:144).
+ * ---------------------------------------------------------------------- */
+typedef struct VinetConvDesc {
+  int32_t dtype;        /* of x and w */
+  int32_t out_dtype;    /* of y */
+  int32_t mode;         /* VINET_CONV_GENERIC / VINET_CONV_STEM */
+  VinetTensor x;        /* C = Cin (multiple of 16 bytes worth of elements) */
+  VinetTensor y;        /* output storage, C = N */
+  int32_t oT, oH, oW;   /* iteration space; M = B*oT*oH*oW */
+  int32_t sT, sH, sW;
+  int32_t omT, omH, omW, ooT, ooH, ooW;
+  int32_t ntaps;
+  const int32_t* taps;
+  const void* w;
+  int32_t Kp;
+  VinetAffine pre;      /* applied to x on load */
+  const float* out_scale;
+  const float* out_shift;
+  int32_t act;
+  int32_t accumulate;   /* y += ... */
+  float* stats;
+  int32_t n_valid;      /* 0 = y.C; else only channels < n_valid have weights /
+                           affine (the rest of a channel-padded y gets act(0)) */
+} VinetConvDesc;
+
+int vinet_conv3d(const VinetConvDesc* desc, void* stream);
+/* BM of the tile configuration vinet_conv3d will pick for this problem. */
+int vinet_conv3d_tile_m(const VinetConvDesc* desc);
+
+/* Weight gradient: dw[slice_tap][n][c] (+)= sum_m dy[m][n] * pre(x[m shifted by tap])[c]
+ * (the wgrad half of convolution_backward, train.py:216).  `dw` is fp32
+ * [nslices][N][Kp] and MUST be zero on entry (split-K partial products are
+ * accumulated with fp32 atomics); vinet_unpack_wgrad converts it to the
+ * torch [N][Cin][kT][kH][kW] layout. */
+typedef struct VinetWgradDesc {
+  int32_t dtype;
+  int32_t mode;
+  VinetTensor x;
+  VinetTensor dy;       /* [B][oT][oH][oW][N] */
+  int32_t sT, sH, sW;
+  int32_t ntaps;
+  const int32_t* taps;
+  float* dw;
+  int32_t Kp;
+  VinetAffine pre;
+} VinetWgradDesc;
+
+int vinet_conv3d_wgrad(const VinetWgradDesc* desc, void* stream);
+
+/* fp32 torch-layout master weights [N][Cin][ntaps] -> packed compute weights.
+ *  transpose == 0: out[t][n][c]       (Kp = pad32(Cin))   forward / wgrad layout
+ *  transpose == 1: out[t][c][n]       (Kp = pad32(N))     dgrad layout
+ *  stem      == 1: out[kh][n][kw*4+c] (Kp = 32; ntaps = 7*7, Cin = 3)
+ * Replaces the implicit weight reads of every nn.Conv3d above. */
+int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_t ntaps, int32_t transpose, int32_t stem,
+                       int32_t dtype, void* out, void* stream);
+/* packed fp32 dw -> torch layout; grad (+)= dw. */
+int vinet_unpack_wgrad(const float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem, int32_t accumulate,
+                       float* grad, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Layout / dtype conversion at the module boundary.
+ * NCDHW-logical fp32 tensor with arbitrary element strides (train.py:205
+ * hands over a permuted view) -> channels-last, channel-padded `dst`
+ * (dst.C >= C, pad channels zeroed); and back.
+ * ---------------------------------------------------------------------- */
+int vinet_import_ncdhw(const float* src, int64_t sb, int64_t sc, int64_t st, int64_t sh, int64_t sw, int32_t C,
+                       const VinetTensor* dst, int32_t dst_dtype, void* stream);
+/* dst[b,c,t,h,w] (fp32, strides given) = pre(src); accumulate adds. */
+int vinet_export_ncdhw(const VinetTensor* src, int32_t src_dtype, VinetAffine pre, float* dst, int64_t sb, int64_t sc,
+                       int64_t st, int64_t sh, int64_t sw, int32_t accumulate, void* stream);
+/* channels-last -> channels-last copy with optional affine+relu (materialises
+ * a pending BN, writes a skip connection into a T-concat buffer, converts
+ * dtype).  dst (+)= pre(src). */
+int vinet_copy_affine(const VinetTensor* src, int32_t src_dtype, VinetAffine pre, const VinetTensor* dst,
+                      int32_t dst_dtype, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm3d / BatchNorm2d (model_utils.py:132,145,149; model.py:752-786).
+ * ---------------------------------------------------------------------- */
+/* Training: reduce conv-epilogue partials [rows][2][C] -> batch mean / biased
+ * var; write mean, invstd, and the consumer-side affine scale = gamma*invstd,
+ * shift = beta - mean*scale; update running stats with `momentum` (unbiased
+ * variance), as aten native_batch_norm does. */
+int vinet_bn_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                      float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* Eval: scale = gamma / sqrt(running_var + eps), shift = beta + (conv_bias - running_mean)*scale. */
+int vinet_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                  const float* conv_bias /* optional */, float eps, int32_t C, float* scale, float* shift,
+                  float* invstd /* optional */, void* stream);
+/* Generic per-channel statistics of a tensor (used when the producer is not a
+ * conv epilogue): partials [rows][2][C]; returns rows via vinet_stats_rows. */
+int vinet_channel_stats(const VinetTensor* x, int32_t dtype, float* partials, void* stream);
+int vinet_stats_rows(const VinetTensor* x);
+/* Backward of y = relu?(scale*x_raw + shift) followed by BN-train statistics:
+ *  pass 1: partials[rows][2][C] of (sum dz*mask, sum dz*mask*xhat)
+ *  pass 2: dx_raw = scale*(dz*mask - c1 - xhat*c2)   (c1 = c2 = 0 in eval mode)
+ * native_batch_norm_backward + threshold_backward (train.py:216). */
+int vinet_bn_bwd_reduce(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,
+                        const float* mean, const float* invstd, float* partials, void* stream);
+int vinet_bn_bwd_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* scale,
+                          int32_t train, float* dgamma_acc, float* dbeta_acc, const float* invstd, float* c1, float* c2,
+                          void* stream);
+int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,
+                       const float* mean, const float* invstd, const float* c1, const float* c2,
+                       const VinetTensor* dx, void* stream);
+/* dy = dz * act'(z) for z = relu(.) or sigmoid(.) outputs (threshold_backward /
+ * sigmoid_backward of the decoder, model.py:257-283).  z may be fp32. */
+int vinet_act_bwd(const VinetTensor* dz, int32_t dz_dtype, const VinetTensor* z, int32_t z_dtype, int32_t act,
+                  const VinetTensor* dy, int32_t dy_dtype, void* stream);
+/* per-channel sum over all voxels (conv bias gradients):
+ * out[j] (+)= sum over voxels and over channels c with c % Cout == j.
+ * workspace: fp32 [vinet_stats_rows(x)][2][x.C]. */
+int vinet_channel_sum(const VinetTensor* x, int32_t dtype, float* workspace, int32_t Cout, float* out,
+                      int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * MaxPool3d (model.py:696,700,705,713,714, model_utils.py:178, model.py:229;
+ * MaxPool2d (k,1) of SoundNet model.py:753,759,774 with T as the pooled axis).
+ * -inf padding, first maximum in (t,h,w) scan order wins ties.  `argmax`
+ * (optional, uint8 [B][oT][oH][oW][C] dense) holds the window-relative tap
+ * index for the backward gather.
+ * ---------------------------------------------------------------------- */
+typedef struct VinetPoolDesc {
+  int32_t dtype;
+  int32_t kT, kH, kW, sT, sH, sW, pT, pH, pW;
+} VinetPoolDesc;
+int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, VinetAffine pre, const VinetTensor* y,
+                    uint8_t* argmax, void* stream);
+int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy, const uint8_t* argmax, const VinetTensor* dx,
+                        int32_t accumulate, void* stream);
+
+/* nn.Upsample(scale_factor=(1,2,2), mode='trilinear', align_corners=False)
+ * (model.py:254,258,263,268,273,278) and its backward. */
+int vinet_upsample2x(const VinetTensor* x, const VinetTensor* y, int32_t dtype, void* stream);
+int vinet_upsample2x_bwd(const VinetTensor* dy, const VinetTensor* dx, int32_t dtype, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Losses (loss.py:13-99): per-sample reductions in fp64, maps fp32 (or fp64
+ * ground truth).  `which`: 0 kldiv, 1 cc, 2 similarity.
+ *  fwd: per_sample[b] and the batch mean in *loss (fp32, device);
+ *       `saved` (fp64 [B][8]) keeps the per-sample reductions for backward.
+ *  bwd: ds[b,i] (+)= gscale * dloss/ds.
+ * ---------------------------------------------------------------------- */
+int vinet_loss_fwd(int32_t which, const float* s, const void* gt, int32_t gt_is_f64, int32_t B, int32_t n,
+                   double* saved, float* loss, void* stream);
+int vinet_loss_bwd(int32_t which, const float* s, const void* gt, int32_t gt_is_f64, int32_t B, int32_t n,
+                   const double* saved, const float* gscale, float coeff, int32_t accumulate, float* ds, void* stream);
+
+/* torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) over one flat fp32 buffer
+ * (train.py:188,217). bias corrections are passed by the host. */
+int vinet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float bias_c1, float bias_c2, float grad_scale, void* stream);
+
+/* nn.Bilinear(42, 3, 336) fusion (model.py:230,236):
+ *  out[b, o, c] = sum_ij x1[b, i, c] * w[o][i][j] * x2[b, j, c] + bias[o]
+ * with x1 = [B][I][C], x2 = [B][J][C], out = [B][O][C] channels-last. */
+int vinet_bilinear_fwd(const void* x1, const void* x2, int32_t dtype, const float* w, const float* bias, int32_t B,
+                       int32_t C, int32_t I, int32_t J, int32_t O, void* out, void* stream);
+int vinet_bilinear_bwd(const void* x1, const void* x2, const void* dout, int32_t dtype, const float* w, int32_t B,
+                       int32_t C, int32_t I, int32_t J, int32_t O, void* dx1, void* dx2, float* dw, float* dbias,
+                       void* stream);
+
+/* misc */
+int vinet_fill_f32(float* p, int64_t n, float value, void* stream);
+int vinet_abi_version(void);
+const char* vinet_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VINET_HIP_H */

@@ -1,0 +1,77 @@
+"""Build libvinet_hip.so (gfx950) in-tree with hipcc.
+
+    python -m vinet_amd.build [--force]
+
+One translation unit per kernel family, compiled in parallel, linked into
+``vinet_amd/libvinet_hip.so``.  The .so is git-ignored but travels to the GPU
+box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "obj")
+LIB = os.path.join(HERE, "libvinet_hip.so")
+SOURCES = ["conv_api.hip", "conv_bf16.hip", "conv_f32.hip", "conv_wgrad.hip", "elementwise.hip", "loss_adam.hip"]
+HEADERS = ["common.h", "conv_igemm.h", os.path.join(ROOT, "include", "vinet_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+         "-Wno-unused-result", "-ffp-contract=off"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + hdrs):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return s, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        if verbose:
+            print("[vinet_amd.build] compiling %d file(s) for gfx950 ..." % len(jobs), flush=True)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            for s, rc, out in ex.map(compile_one, jobs):
+                if rc != 0:
+                    raise RuntimeError("hipcc failed on %s:\n%s" % (s, out))
+                if verbose and out.strip():
+                    print(out)
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        if verbose:
+            print("[vinet_amd.build] linked", LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,128 @@
+// Shared device/host helpers for libvinet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "vinet_hip.h"
+
+typedef uint16_t bf16_t;  // storage type; arithmetic is always fp32
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(4))) float f32x4_v;
+typedef __attribute__((ext_vector_type(4))) short s16x4_v;
+
+#define VN_DEV __device__ __forceinline__
+
+VN_DEV float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+VN_DEV bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved (same as aten)
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+VN_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int EG = 4;  // elements per 16-byte group
+  static constexpr int DT = VINET_F32;
+};
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int EG = 8;
+  static constexpr int DT = VINET_BF16;
+};
+
+// 16 bytes of T <-> fp32 lanes
+template <typename T> VN_DEV void unpack16(const uint4& u, float* f);
+template <> VN_DEV void unpack16<float>(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+}
+template <> VN_DEV void unpack16<bf16_t>(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T> VN_DEV uint4 pack16(const float* f);
+template <> VN_DEV uint4 pack16<float>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> VN_DEV uint4 pack16<bf16_t>(const float* f) {
+  return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+template <typename T> VN_DEV float load1(const T* p);
+template <> VN_DEV float load1<float>(const float* p) { return *p; }
+template <> VN_DEV float load1<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> VN_DEV void store1(T* p, float v);
+template <> VN_DEV void store1<float>(float* p, float v) { *p = v; }
+template <> VN_DEV void store1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// Device-side tensor view (mirror of VinetTensor with typed helpers).
+struct TView {
+  char* p;
+  int B, T, H, W, C, ld;
+  long sB;
+};
+static inline TView make_view(const VinetTensor& t) {
+  TView v;
+  v.p = (char*)t.ptr; v.B = t.B; v.T = t.T; v.H = t.H; v.W = t.W; v.C = t.C; v.ld = t.ld; v.sB = t.sB;
+  return v;
+}
+// element offset of voxel (b,t,h,w), channel 0
+VN_DEV long vox_off(const TView& v, int b, int t, int h, int w) {
+  return (long)b * v.sB + ((long)(t * v.H + h) * v.W + w) * (long)v.ld;
+}
+
+struct Affine {
+  const float* scale;
+  const float* shift;
+  int relu;
+};
+static inline Affine make_affine(const VinetAffine& a) {
+  Affine r; r.scale = a.scale; r.shift = a.shift; r.relu = a.relu; return r;
+}
+
+// XCD-aware bijective block remap: consecutive logical ids land on the same
+// XCD (blockIdx b runs on XCD b % 8), so neighbouring tiles share an L2.
+VN_DEV int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+VN_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+VN_DEV double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- host side -----------------------------------------------------------
+void vinet_set_error(const char* fmt, ...);
+#define VN_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      vinet_set_error(__VA_ARGS__);        \
+      return -1;                           \
+    }                                      \
+  } while (0)
+
+static inline int vn_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    vinet_set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+static inline int vn_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+static inline bool vn_tensor_ok(const VinetTensor& t, int eg) {
+  return t.ptr && t.B > 0 && t.T > 0 && t.H > 0 && t.W > 0 && t.C > 0 && t.ld >= t.C && (t.ld % eg) == 0 &&
+         (t.C % eg) == 0 && (((uintptr_t)t.ptr) & 15) == 0 && (t.sB % eg) == 0;
+}

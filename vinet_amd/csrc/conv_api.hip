@@ -1,0 +1,105 @@
+// Host side of the convolution entry points + library-wide error state.
+#include <stdarg.h>
+
+#include "conv_igemm.h"
+
+static thread_local char g_err[512] = "";
+
+void vinet_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* vinet_last_error(void) { return g_err; }
+extern "C" int vinet_abi_version(void) { return VINET_ABI_VERSION; }
+
+// Largest BN whose padded width is within 25% of the best achievable padding;
+// then shrink BM while the grid would leave most of the 256 CUs idle.
+ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N) {
+  if (mode == VINET_CONV_STEM) return dtype == VINET_BF16 ? ConvTile{4, 4, 4, 1} : ConvTile{2, 4, 4, 1};
+  static const int nts[6] = {8, 6, 4, 3, 2, 1};
+  int best_pad = 1 << 30;
+  for (int i = 0; i < 6; ++i) {
+    const int bn = nts[i] * 16;
+    const int pad = ((N + bn - 1) / bn) * bn;
+    if (pad < best_pad) best_pad = pad;
+  }
+  int nt = 1;
+  for (int i = 0; i < 6; ++i) {
+    const int bn = nts[i] * 16;
+    const int pad = ((N + bn - 1) / bn) * bn;
+    if (pad * 4 <= best_pad * 5) { nt = nts[i]; break; }
+  }
+  if (dtype == VINET_F32) return ConvTile{2, nt, 4, 1};  // BM = 128
+  ConvTile t{4, nt, 4, 1};                               // BM = 256
+  if (nt == 8 || nt == 4) {
+    const int bn = nt * 16;
+    const long tilesN = (N + bn - 1) / bn;
+    const long blocks256 = ((M + 255) / 256) * tilesN;
+    if (blocks256 < 512) {
+      const long blocks128 = ((M + 127) / 128) * tilesN;
+      if (blocks128 >= 512 || bn == 64) t = (bn == 128) ? ConvTile{4, 4, 2, 2} : ConvTile{4, 2, 2, 2};  // BM 128
+      if (blocks128 < 512) t = (bn == 128) ? ConvTile{2, 4, 2, 2} : ConvTile{2, 2, 2, 2};               // BM 64
+    }
+  }
+  return t;
+}
+
+static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
+  VN_CHECK_ARG(d != nullptr, "conv: null descriptor");
+  VN_CHECK_ARG(d->dtype == VINET_F32 || d->dtype == VINET_BF16, "conv: bad dtype %d", d->dtype);
+  VN_CHECK_ARG(d->out_dtype == VINET_F32 || d->out_dtype == VINET_BF16, "conv: bad out_dtype %d", d->out_dtype);
+  VN_CHECK_ARG(d->mode == VINET_CONV_GENERIC || d->mode == VINET_CONV_STEM, "conv: bad mode %d", d->mode);
+  const int eg = d->dtype == VINET_F32 ? 4 : 8;
+  VN_CHECK_ARG(vn_tensor_ok(d->x, d->mode == VINET_CONV_STEM ? 4 : eg),
+               "conv: bad x view (C=%d ld=%d must be multiples of %d, 16-byte aligned)", d->x.C, d->x.ld, eg);
+  VN_CHECK_ARG(d->y.ptr && d->y.C > 0 && d->y.ld >= d->y.C, "conv: bad y view");
+  VN_CHECK_ARG(d->x.B == d->y.B, "conv: batch mismatch %d vs %d", d->x.B, d->y.B);
+  VN_CHECK_ARG(d->ntaps > 0 && d->taps && d->w, "conv: taps/weights missing");
+  VN_CHECK_ARG(d->Kp > 0 && d->Kp % 32 == 0, "conv: Kp=%d must be a multiple of 32", d->Kp);
+  if (d->mode == VINET_CONV_STEM) VN_CHECK_ARG(d->x.C == 4 && d->Kp == 32, "conv stem: x.C must be 4 and Kp 32");
+  else VN_CHECK_ARG(d->Kp >= d->x.C, "conv: Kp=%d < Cin=%d", d->Kp, d->x.C);
+  VN_CHECK_ARG(d->oT > 0 && d->oH > 0 && d->oW > 0, "conv: empty iteration space");
+  VN_CHECK_ARG(d->sT > 0 && d->sH > 0 && d->sW > 0 && d->omT > 0 && d->omH > 0 && d->omW > 0, "conv: bad strides");
+  VN_CHECK_ARG((d->oT - 1) * d->omT + d->ooT < d->y.T && (d->oH - 1) * d->omH + d->ooH < d->y.H &&
+                   (d->oW - 1) * d->omW + d->ooW < d->y.W && d->ooT >= 0 && d->ooH >= 0 && d->ooW >= 0,
+               "conv: output placement outside y");
+  const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  VN_CHECK_ARG(M < (1L << 31), "conv: M too large");
+
+  a.x = (const char*)d->x.ptr; a.y = (char*)d->y.ptr; a.w = (const char*)d->w; a.taps = (const int4*)d->taps;
+  a.in_scale = d->pre.scale; a.in_shift = d->pre.shift; a.in_relu = d->pre.relu;
+  a.out_scale = d->out_scale; a.out_shift = d->out_shift; a.stats = d->stats;
+  a.Ti = d->x.T; a.Hi = d->x.H; a.Wi = d->x.W; a.Cin = d->x.C; a.ldx = d->x.ld; a.sBx = d->x.sB;
+  a.To = d->oT; a.Ho = d->oH; a.Wo = d->oW;
+  a.sT = d->sT; a.sH = d->sH; a.sW = d->sW;
+  a.yT = d->y.T; a.yH = d->y.H; a.yW = d->y.W; a.N = d->y.C; a.ldy = d->y.ld; a.sBy = d->y.sB;
+  a.omT = d->omT; a.omH = d->omH; a.omW = d->omW; a.ooT = d->ooT; a.ooH = d->ooH; a.ooW = d->ooW;
+  a.ntaps = d->ntaps; a.Kp = d->Kp; a.M = (int)M;
+  a.Nw = d->n_valid > 0 ? d->n_valid : d->y.C;
+  VN_CHECK_ARG(a.Nw <= d->y.C, "conv: n_valid > y.C");
+  a.act = d->act; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == VINET_F32;
+  const int oeb = a.out_f32 ? 4 : 2;
+  a.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && (a.sBy % 4 == 0) && ((((uintptr_t)d->y.ptr) % (4 * oeb)) == 0);
+  t = vinet_pick_conv_tile(d->dtype, d->mode, M, a.N);
+  a.tilesM = vn_div_up(M, t.BM());
+  a.tilesN = vn_div_up(a.N, t.BN());
+  return 0;
+}
+
+extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
+  if (!d) return -1;
+  const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C).BM();
+}
+
+extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
+  ConvArgs a;
+  ConvTile t;
+  int rc = fill_args(d, a, t);
+  if (rc) return rc;
+  if (d->dtype == VINET_BF16) return vinet_launch_conv_bf16(t, d->mode, a, (hipStream_t)stream);
+  return vinet_launch_conv_f32(t, d->mode, a, (hipStream_t)stream);
+}

@@ -1,0 +1,381 @@
+// Implicit-GEMM 3-D convolution on MFMA for gfx950 (channels-last activations).
+//
+//   M = B*oT*oH*oW output voxels, N = output channels, K = ntaps * Kp
+//   workgroup = 256 threads = 4 waves, tile BM x BN, K step 32
+//   A (activations): gathered per tap with bounds checks, optional consumer-side
+//      BN+ReLU applied in registers, staged global -> VGPR -> LDS (double buffer)
+//   B (weights): packed [slice][N][Kp], staged the same way
+//   bf16: v_mfma_f32_16x16x32_bf16, fragments by ds_read_b128 from a padded
+//      (80-byte row) LDS image;  fp32: v_mfma_f32_16x16x4_f32 (exact fp32).
+//   epilogue: per-channel affine, BN partial statistics (sum, sum^2) per M tile,
+//      ReLU / sigmoid, LDS-transposed so each lane stores 4 consecutive
+//      channels, optional accumulate, arbitrary output placement.
+//
+// The same kernel serves forward convs, every dgrad (the caller passes the
+// transposed weight pack and per-phase tap tables) and SoundNet's 1-D convs.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+  const char* x;
+  char* y;
+  const char* w;
+  const int4* taps;
+  const float* in_scale;
+  const float* in_shift;
+  const float* out_scale;
+  const float* out_shift;
+  float* stats;
+  int Ti, Hi, Wi, Cin, ldx;
+  long sBx;
+  int To, Ho, Wo;
+  int sT, sH, sW;
+  int yT, yH, yW, N, ldy;
+  long sBy;
+  int omT, omH, omW, ooT, ooH, ooW;
+  int ntaps, Kp, M, tilesM, tilesN, Nw;
+  int in_relu, act, accumulate, out_f32, vec_ok;
+};
+
+template <typename T, int MT, int NT, int WARPS_M, int WARPS_N>
+struct ConvCfg {
+  static constexpr int BM = 16 * MT * WARPS_M;
+  static constexpr int BN = 16 * NT * WARPS_N;
+  static constexpr int BK = 32;
+  static constexpr int EG = ElemTraits<T>::EG;
+  static constexpr int G = BK / EG;                     // 16-byte groups per K row
+  static constexpr int RS = BK * (int)sizeof(T) + 16;   // padded LDS row stride (bytes)
+  static constexpr int A_BYTES = BM * RS;
+  static constexpr int B_BYTES = BN * RS;
+  static constexpr int WNC = NT * 16;                   // columns per wave
+  static constexpr int EROW = WNC + 4;                  // epilogue LDS row stride (floats)
+  static constexpr int KLOOP_BYTES = 2 * (A_BYTES + B_BYTES);
+  static constexpr int EPI_BYTES = 4 * 16 * EROW * 4 + WARPS_M * BN * 2 * 4;
+  static constexpr int SMEM = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
+};
+
+template <typename T> struct MmaAcc { f32x4_v v; };
+
+template <typename T, int MT, int NT, int WARPS_M, int WARPS_N, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  using Cfg = ConvCfg<T, MT, NT, WARPS_M, WARPS_N>;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, EG = Cfg::EG, G = Cfg::G, RS = Cfg::RS;
+  constexpr int A_LOADS = (BM * G) / 256;
+  constexpr int B_ITEMS = BN * G;
+  constexpr int B_LOADS = (B_ITEMS + 255) / 256;
+  static_assert((BM * G) % 256 == 0, "A tile must divide evenly over 256 threads");
+  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = wg % a.tilesN, tile_m = wg / a.tilesN;
+  const int g = tid % G;
+
+  // ---- per-thread A rows (fixed across the K loop) -------------------------
+  long a_base[A_LOADS];
+  int a_t[A_LOADS], a_h[A_LOADS], a_w[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int row = (i * 256 + tid) / G;
+    const int m = tile_m * BM + row;
+    if (m < a.M) {
+      const int wo = m % a.Wo;
+      const int t1 = m / a.Wo;
+      const int ho = t1 % a.Ho;
+      const int t2 = t1 / a.Ho;
+      const int to = t2 % a.To;
+      const int b = t2 / a.To;
+      a_base[i] = (long)b * a.sBx;
+      a_t[i] = to * a.sT; a_h[i] = ho * a.sH; a_w[i] = wo * a.sW;
+    } else {
+      a_base[i] = 0; a_t[i] = -(1 << 28); a_h[i] = 0; a_w[i] = 0;
+    }
+  }
+
+  const int cpt = a.Kp / BK;          // K chunks per tap
+  const int nchunks = a.ntaps * cpt;
+  const bool has_pre = a.in_scale != nullptr;
+
+  uint4 ra[A_LOADS], rb[B_LOADS];
+
+  auto load_tiles = [&](int it) {
+    const int tap = it / cpt;
+    const int c0 = (it - tap * cpt) * BK;
+    const int4 tp = a.taps[tap];
+    if constexpr (MODE == VINET_CONV_GENERIC) {
+      const int c = c0 + g * EG;
+      const bool cin_ok = c < a.Cin;
+      float sc[EG], sh[EG];
+      if (has_pre && cin_ok) {
+#pragma unroll
+        for (int e = 0; e < EG; ++e) { sc[e] = a.in_scale[c + e]; sh[e] = a.in_shift[c + e]; }
+      }
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const int ti = a_t[i] + tp.x, hi = a_h[i] + tp.y, wi = a_w[i] + tp.z;
+        const bool ok = cin_ok && (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi &&
+                        (unsigned)wi < (unsigned)a.Wi;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) {
+          const long off = a_base[i] + ((long)(ti * a.Hi + hi) * a.Wi + wi) * (long)a.ldx + c;
+          v = *(const uint4*)(a.x + off * (long)sizeof(T));
+          if (has_pre) {
+            float f[EG];
+            unpack16<T>(v, f);
+#pragma unroll
+            for (int e = 0; e < EG; ++e) {
+              f[e] = fmaf(f[e], sc[e], sh[e]);
+              if (a.in_relu) f[e] = fmaxf(f[e], 0.f);
+            }
+            v = pack16<T>(f);
+          }
+        }
+        ra[i] = v;
+      }
+    } else {
+      // stem: K chunk = 8 consecutive W positions x 4 channels; x has C == 4
+      constexpr int PP = EG / 4;  // 4-channel pixels per 16-byte group
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const int ti = a_t[i] + tp.x, hi = a_h[i] + tp.y;
+        const bool row_ok = (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi;
+        const long rowoff = a_base[i] + ((long)(ti * a.Hi + hi) * a.Wi) * (long)a.ldx;
+        uint32_t words[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+          const int wi = a_w[i] + tp.z + g * PP + p;
+          if (row_ok && (unsigned)wi < (unsigned)a.Wi) {
+            const char* src = a.x + (rowoff + (long)wi * a.ldx) * (long)sizeof(T);
+            if constexpr (sizeof(T) == 2) {
+              const uint2 q = *(const uint2*)src;
+              words[2 * p] = q.x; words[2 * p + 1] = q.y;
+            } else {
+              const uint4 q = *(const uint4*)src;
+              words[0] = q.x; words[1] = q.y; words[2] = q.z; words[3] = q.w;
+            }
+          }
+        }
+        ra[i] = make_uint4(words[0], words[1], words[2], words[3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+      const int idx = j * 256 + tid;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx < B_ITEMS) {
+        const int n = idx / G, gg = idx % G;
+        const int nn = tile_n * BN + n;
+        if (nn < a.Nw) {
+          const long off = ((long)tp.w * a.Nw + nn) * (long)a.Kp + c0 + gg * EG;
+          v = *(const uint4*)(a.w + off * (long)sizeof(T));
+        }
+      }
+      rb[j] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    char* As = smem + buf * Cfg::A_BYTES;
+    char* Bs = smem + 2 * Cfg::A_BYTES + buf * Cfg::B_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int row = (i * 256 + tid) / G;
+      *(uint4*)(As + row * RS + g * 16) = ra[i];
+    }
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+      const int idx = j * 256 + tid;
+      if (idx < B_ITEMS) *(uint4*)(Bs + (idx / G) * RS + (idx % G) * 16) = rb[j];
+    }
+  };
+
+  f32x4_v acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const char* As = smem + buf * Cfg::A_BYTES + (wm * MT * 16 + (lane & 15)) * RS;
+    const char* Bs = smem + 2 * Cfg::A_BYTES + buf * Cfg::B_BYTES + (wn * NT * 16 + (lane & 15)) * RS;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8_v af[MT], bfr[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8_v*)(As + i * 16 * RS + (lane >> 4) * 16);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8_v*)(Bs + j * 16 * RS + (lane >> 4) * 16);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float af[MT], bfr[NT];
+        const int kb = (kk * 4 + (lane >> 4)) * 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *(const float*)(As + i * 16 * RS + kb);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfr[j] = *(const float*)(Bs + j * 16 * RS + kb);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- main loop: one barrier per K chunk, loads of chunk i+1 in flight
+  //      while the MFMAs of chunk i run -------------------------------------
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int it = 0; it < nchunks; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nchunks) load_tiles(it + 1);
+    compute(buf);
+    if (it + 1 < nchunks) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------
+  constexpr int WNC = Cfg::WNC, EROW = Cfg::EROW;
+  float* Ew = (float*)smem + wave * (16 * EROW);
+  float* red = (float*)smem + 4 * 16 * EROW;
+  const int m_wave = tile_m * BM + wm * MT * 16;
+  const int n_wave = tile_n * BN + wn * WNC;
+
+  {
+    float s_sum[NT], s_sq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n_wave + j * 16 + (lane & 15);
+      const bool nok = n < a.Nw;
+      const float sc = (a.out_scale && nok) ? a.out_scale[n] : 1.f;
+      const float sh = (a.out_shift && nok) ? a.out_shift[n] : 0.f;
+      float ss = 0.f, qq = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m_wave + i * 16 + (lane >> 4) * 4 + r;
+          float v = fmaf(acc[i][j][r], sc, sh);
+          if (a.stats && nok && m < a.M) { ss += v; qq += v * v; }
+          if (a.act == VINET_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == VINET_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+          acc[i][j][r] = v;
+        }
+      s_sum[j] = ss; s_sq[j] = qq;
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float ss = s_sum[j], qq = s_sq[j];
+        ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+        qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
+        if (lane < 16) {
+          const int col = wn * WNC + j * 16 + lane;
+          red[(wm * BN + col) * 2 + 0] = ss;
+          red[(wm * BN + col) * 2 + 1] = qq;
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ew[((lane >> 4) * 4 + r) * EROW + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    for (int e = lane; e < 16 * (WNC / 4); e += 64) {
+      const int rr = e / (WNC / 4), cc = (e % (WNC / 4)) * 4;
+      const int m = m_wave + i * 16 + rr;
+      const int n = n_wave + cc;
+      if (m < a.M && n < a.N) {
+        const float4 v = *(const float4*)&Ew[rr * EROW + cc];
+        const int wo = m % a.Wo;
+        const int t1 = m / a.Wo;
+        const int ho = t1 % a.Ho;
+        const int t2 = t1 / a.Ho;
+        const int to = t2 % a.To;
+        const int b = t2 / a.To;
+        const long off = (long)b * a.sBy +
+                         ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) *
+                             (long)a.ldy + n;
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (a.vec_ok) {
+          if (a.out_f32) {
+            float* dst = (float*)a.y + off;
+            if (a.accumulate) { const float4 q = *(const float4*)dst; o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
+            *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+            bf16_t* dst = (bf16_t*)a.y + off;
+            if (a.accumulate) {
+              const uint2 q = *(const uint2*)dst;
+              o[0] += __uint_as_float(q.x << 16); o[1] += __uint_as_float(q.x & 0xffff0000u);
+              o[2] += __uint_as_float(q.y << 16); o[3] += __uint_as_float(q.y & 0xffff0000u);
+            }
+            *(uint2*)dst = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+          }
+        } else {
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            if (n + e2 < a.N) {
+              if (a.out_f32) {
+                float* dst = (float*)a.y + off + e2;
+                *dst = a.accumulate ? *dst + o[e2] : o[e2];
+              } else {
+                bf16_t* dst = (bf16_t*)a.y + off + e2;
+                *dst = f2bf(a.accumulate ? bf2f(*dst) + o[e2] : o[e2]);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (a.stats && tid < BN) {
+    const int n = tile_n * BN + tid;
+    if (n < a.N) {
+      float ss = 0.f, qq = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < WARPS_M; ++w2) { ss += red[(w2 * BN + tid) * 2]; qq += red[(w2 * BN + tid) * 2 + 1]; }
+      a.stats[((long)tile_m * 2 + 0) * a.N + n] = ss;
+      a.stats[((long)tile_m * 2 + 1) * a.N + n] = qq;
+    }
+  }
+}
+
+// ---- host-side dispatch helpers ---------------------------------------------
+struct ConvTile { int MT, NT, WM, WN; int BM() const { return 16 * MT * WM; } int BN() const { return 16 * NT * WN; } };
+
+// Tile choice is a pure function of (dtype, mode, M, N) so callers can size the
+// statistics workspace (vinet_conv3d_tile_m).
+ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N);
+int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
+int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
+
+template <typename T, int MT, int NT, int WM, int WN, int MODE>
+static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
+  using Cfg = ConvCfg<T, MT, NT, WM, WN>;
+  auto kern = conv_igemm_kernel<T, MT, NT, WM, WN, MODE>;
+  static bool attr_done[64] = {false};  // per device; benign race (same value written)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv): %s", hipGetErrorString(e)); return (int)e; }
+    attr_done[dev & 63] = true;
+  }
+  const int grid = a.tilesM * a.tilesN;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::SMEM, s, a);
+  return vn_launch_status("conv_igemm");
+}

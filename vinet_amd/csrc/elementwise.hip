@@ -1,0 +1,695 @@
+// HBM-bound kernels of the ViNet path: layout/dtype conversion, weight packing,
+// BatchNorm (statistics, fold, backward), activation backward, MaxPool3d,
+// 2x bilinear upsample.  All work on channels-last views and move 4 channels
+// (8 bytes bf16 / 16 bytes fp32) per lane with channels fastest across lanes,
+// so every wave touches whole contiguous rows.
+#include "common.h"
+
+// ---- 4-channel ("quad") typed access -----------------------------------------
+template <typename T> VN_DEV float4 ldq(const T* p);
+template <> VN_DEV float4 ldq<float>(const float* p) { return *(const float4*)p; }
+template <> VN_DEV float4 ldq<bf16_t>(const bf16_t* p) {
+  const uint2 q = *(const uint2*)p;
+  return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                     __uint_as_float(q.y & 0xffff0000u));
+}
+template <typename T> VN_DEV void stq(T* p, float4 v);
+template <> VN_DEV void stq<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> VN_DEV void stq<bf16_t>(bf16_t* p, float4 v) { *(uint2*)p = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w)); }
+
+VN_DEV float4 affine4(float4 v, const Affine& a, int c) {
+  if (a.scale) {
+    const float4 s = *(const float4*)(a.scale + c);
+    const float4 h = *(const float4*)(a.shift + c);
+    v.x = fmaf(v.x, s.x, h.x); v.y = fmaf(v.y, s.y, h.y); v.z = fmaf(v.z, s.z, h.z); v.w = fmaf(v.w, s.w, h.w);
+  }
+  if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  return v;
+}
+
+VN_DEV void decode_vox(const TView& v, long vox, int& b, int& t, int& h, int& w) {
+  w = (int)(vox % v.W); vox /= v.W;
+  h = (int)(vox % v.H); vox /= v.H;
+  t = (int)(vox % v.T); b = (int)(vox / v.T);
+}
+static inline long view_voxels(const VinetTensor& t) { return (long)t.B * t.T * t.H * t.W; }
+static inline bool quad_ok(const VinetTensor& t, int esz) {
+  return t.ptr && t.C > 0 && (t.C % 4) == 0 && (t.ld % 4) == 0 && t.ld >= t.C && (t.sB % 4) == 0 &&
+         (((uintptr_t)t.ptr) % (4 * esz)) == 0;
+}
+static inline int esize(int dtype) { return dtype == VINET_F32 ? 4 : 2; }
+static inline bool same_dims(const VinetTensor& a, const VinetTensor& b) {
+  return a.B == b.B && a.T == b.T && a.H == b.H && a.W == b.W && a.C == b.C;
+}
+static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : g); }
+
+#define DISPATCH_T(dt, T, ...)                         \
+  if ((dt) == VINET_F32) { using T = float; __VA_ARGS__ } \
+  else { using T = bf16_t; __VA_ARGS__ }
+
+// ============================================================================
+// weight packing
+// ============================================================================
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, int N, int Cin, int ntaps, int transpose, int stem,
+                                    int rows, int Kp, int nslices, T* __restrict__ out) {
+  const long total = (long)nslices * rows * Kp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    const int r = (int)((i / Kp) % rows);
+    const int s = (int)(i / ((long)Kp * rows));
+    float v = 0.f;
+    if (stem) {  // out[kh][n][kw*4+c], w[n][c][kh*7+kw]
+      const int kw = k >> 2, c = k & 3;
+      if (kw < 7 && c < Cin) v = w[((long)r * Cin + c) * ntaps + s * 7 + kw];
+    } else if (!transpose) {  // out[t][n][c]
+      if (k < Cin) v = w[((long)r * Cin + k) * ntaps + s];
+    } else {  // out[t][c][n]
+      if (k < N) v = w[((long)k * Cin + r) * ntaps + s];
+    }
+    store1<T>(out + i, v);
+  }
+}
+
+extern "C" int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_t ntaps, int32_t transpose,
+                                  int32_t stem, int32_t dtype, void* out, void* stream) {
+  VN_CHECK_ARG(w && out && N > 0 && Cin > 0 && ntaps > 0, "pack_weights: bad arguments");
+  int rows, Kp, nslices;
+  if (stem) {
+    VN_CHECK_ARG(ntaps == 49 && Cin <= 4 && !transpose, "pack_weights stem: need 1x7x7, Cin<=4");
+    rows = N; Kp = 32; nslices = 7;
+  } else if (!transpose) { rows = N; Kp = (Cin + 31) / 32 * 32; nslices = ntaps; }
+  else { rows = Cin; Kp = (N + 31) / 32 * 32; nslices = ntaps; }
+  const long total = (long)nslices * rows * Kp;
+  int grid = ew_grid(total); if (grid > 8192) grid = 8192;
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, N,
+                                          Cin, ntaps, transpose, stem, rows, Kp, nslices, (T*)out);)
+  return vn_launch_status("pack_weights");
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dw, int N, int Cin, int ntaps, int stem, int Kp,
+                                    int accumulate, float* __restrict__ grad) {
+  const long total = (long)N * Cin * ntaps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % ntaps);
+    const int c = (int)((i / ntaps) % Cin);
+    const int n = (int)(i / ((long)ntaps * Cin));
+    float v;
+    if (stem) { const int kh = t / 7, kw = t % 7; v = dw[((long)kh * N + n) * 32 + kw * 4 + c]; }
+    else v = dw[((long)t * N + n) * Kp + c];
+    grad[i] = accumulate ? grad[i] + v : v;
+  }
+}
+
+extern "C" int vinet_unpack_wgrad(const float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem,
+                                  int32_t accumulate, float* grad, void* stream) {
+  VN_CHECK_ARG(dw && grad && N > 0 && Cin > 0 && ntaps > 0, "unpack_wgrad: bad arguments");
+  const int Kp = stem ? 32 : (Cin + 31) / 32 * 32;
+  const long total = (long)N * Cin * ntaps;
+  int grid = ew_grid(total); if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dw, N, Cin, ntaps, stem, Kp,
+                     accumulate, grad);
+  return vn_launch_status("unpack_wgrad");
+}
+
+// ============================================================================
+// NCDHW <-> channels-last
+// ============================================================================
+template <typename T>
+__global__ void import_ncdhw_kernel(const float* __restrict__ src, long sb, long sc, long st, long sh, long sw, int C,
+                                    TView dst, long nvox) {
+  const int Q = dst.C / 4;
+  const long total = nvox * Q;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long vox = i % nvox;       // voxels fastest: coalesced planar reads
+  const int q = (int)(i / nvox);
+  int b, t, h, w;
+  decode_vox(dst, vox, b, t, h, w);
+  const float* s = src + b * sb + t * st + h * sh + w * sw;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const int c = q * 4 + e; v[e] = c < C ? s[c * sc] : 0.f; }
+  stq<T>((T*)dst.p + vox_off(dst, b, t, h, w) + q * 4, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+extern "C" int vinet_import_ncdhw(const float* src, int64_t sb, int64_t sc, int64_t st, int64_t sh, int64_t sw,
+                                  int32_t C, const VinetTensor* dst, int32_t dst_dtype, void* stream) {
+  VN_CHECK_ARG(src && dst && quad_ok(*dst, esize(dst_dtype)) && C > 0 && C <= dst->C, "import_ncdhw: bad arguments");
+  const long nvox = view_voxels(*dst);
+  const long total = nvox * (dst->C / 4);
+  DISPATCH_T(dst_dtype, T, hipLaunchKernelGGL(import_ncdhw_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+                                              (hipStream_t)stream, src, sb, sc, st, sh, sw, C, make_view(*dst), nvox);)
+  return vn_launch_status("import_ncdhw");
+}
+
+template <typename T>
+__global__ void export_ncdhw_kernel(TView src, Affine pre, float* __restrict__ dst, long sb, long sc, long st, long sh,
+                                    long sw, int accumulate, long nvox) {
+  const int Q = src.C / 4;
+  const long total = nvox * Q;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long vox = i % nvox;
+  const int q = (int)(i / nvox);
+  int b, t, h, w;
+  decode_vox(src, vox, b, t, h, w);
+  float4 v = ldq<T>((const T*)src.p + vox_off(src, b, t, h, w) + q * 4);
+  v = affine4(v, pre, q * 4);
+  float* d = dst + b * sb + t * st + h * sh + w * sw + (long)(q * 4) * sc;
+  const float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e * sc] = accumulate ? d[e * sc] + o[e] : o[e];
+}
+
+extern "C" int vinet_export_ncdhw(const VinetTensor* src, int32_t src_dtype, VinetAffine pre, float* dst, int64_t sb,
+                                  int64_t sc, int64_t st, int64_t sh, int64_t sw, int32_t accumulate, void* stream) {
+  VN_CHECK_ARG(src && dst && quad_ok(*src, esize(src_dtype)), "export_ncdhw: bad arguments");
+  const long nvox = view_voxels(*src);
+  const long total = nvox * (src->C / 4);
+  DISPATCH_T(src_dtype, T, hipLaunchKernelGGL(export_ncdhw_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+                                              (hipStream_t)stream, make_view(*src), make_affine(pre), dst, sb, sc, st,
+                                              sh, sw, accumulate, nvox);)
+  return vn_launch_status("export_ncdhw");
+}
+
+template <typename TI, typename TO>
+__global__ void copy_affine_kernel(TView src, Affine pre, TView dst, int accumulate, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Q = src.C / 4;
+  const int q = (int)(i % Q);
+  const long vox = i / Q;
+  int b, t, h, w;
+  decode_vox(src, vox, b, t, h, w);
+  float4 v = ldq<TI>((const TI*)src.p + vox_off(src, b, t, h, w) + q * 4);
+  v = affine4(v, pre, q * 4);
+  TO* d = (TO*)dst.p + vox_off(dst, b, t, h, w) + q * 4;
+  if (accumulate) { const float4 o = ldq<TO>(d); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+  stq<TO>(d, v);
+}
+
+extern "C" int vinet_copy_affine(const VinetTensor* src, int32_t src_dtype, VinetAffine pre, const VinetTensor* dst,
+                                 int32_t dst_dtype, int32_t accumulate, void* stream) {
+  VN_CHECK_ARG(src && dst && quad_ok(*src, esize(src_dtype)) && quad_ok(*dst, esize(dst_dtype)) && same_dims(*src, *dst),
+               "copy_affine: bad views");
+  const long total = view_voxels(*src) * (src->C / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const TView sv = make_view(*src), dv = make_view(*dst);
+  const Affine a = make_affine(pre);
+  const dim3 g(ew_grid(total)), blk(256);
+  if (src_dtype == VINET_F32 && dst_dtype == VINET_F32) hipLaunchKernelGGL((copy_affine_kernel<float, float>), g, blk, 0, s, sv, a, dv, accumulate, total);
+  else if (src_dtype == VINET_F32) hipLaunchKernelGGL((copy_affine_kernel<float, bf16_t>), g, blk, 0, s, sv, a, dv, accumulate, total);
+  else if (dst_dtype == VINET_F32) hipLaunchKernelGGL((copy_affine_kernel<bf16_t, float>), g, blk, 0, s, sv, a, dv, accumulate, total);
+  else hipLaunchKernelGGL((copy_affine_kernel<bf16_t, bf16_t>), g, blk, 0, s, sv, a, dv, accumulate, total);
+  return vn_launch_status("copy_affine");
+}
+
+// ============================================================================
+// BatchNorm
+// ============================================================================
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int rows, int C, double count,
+                                   const float* gamma, const float* beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* mean_o, float* invstd_o,
+                                   float* scale_o, float* shift_o) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+    s += (double)partials[((long)r * 2 + 0) * C + c];
+    q += (double)partials[((long)r * 2 + 1) * C + c];
+  }
+  __shared__ double red[2][4];
+  s = wave_sum_d(s); q = wave_sum_d(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = (float)(g * invstd);
+    if (mean_o) mean_o[c] = (float)mean;
+    if (invstd_o) invstd_o[c] = (float)invstd;
+    scale_o[c] = sc;
+    shift_o[c] = b - (float)mean * sc;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+extern "C" int vinet_bn_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                 float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  VN_CHECK_ARG(partials && rows > 0 && C > 0 && count > 0 && scale && shift, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, rows, C, count, gamma,
+                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  return vn_launch_status("bn_finalize");
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                               const float* conv_bias, float eps, int C, float* scale, float* shift, float* invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(rv[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * is;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) + ((conv_bias ? conv_bias[c] : 0.f) - rm[c]) * sc;
+  if (invstd) invstd[c] = is;
+}
+
+extern "C" int vinet_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                             const float* running_var, const float* conv_bias, float eps, int32_t C, float* scale,
+                             float* shift, float* invstd, void* stream) {
+  VN_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, conv_bias, eps, C, scale, shift, invstd);
+  return vn_launch_status("bn_fold");
+}
+
+// Per-channel reductions over voxels.  Thread (q, r): channel quad q, voxel lane
+// r; a block covers `vb` consecutive voxels and writes one partial row.
+// MODE 0: (sum x, sum x^2) of x;  MODE 1: (sum dz*mask, sum dz*mask*xhat).
+static inline int stats_rows_for(long nvox) {
+  long rows = (nvox + 63) / 64;
+  if (rows > 1024) rows = 1024;
+  if (rows < 1) rows = 1;
+  return (int)rows;
+}
+extern "C" int vinet_stats_rows(const VinetTensor* x) { return x ? stats_rows_for(view_voxels(*x)) : -1; }
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void channel_reduce_kernel(TView x, TView dz, Affine fwd, const float* mean,
+                                                             const float* invstd, long nvox, long vb,
+                                                             float* __restrict__ partials) {
+  const int Q = x.C / 4;
+  const int Qb = Q < 256 ? Q : 256;
+  const int R = 256 / Qb;
+  const int r = threadIdx.x / Qb;
+  const int q0 = threadIdx.x % Qb;
+  __shared__ float red[256 * 8];
+  const long v0 = (long)blockIdx.x * vb;
+  long v1 = v0 + vb; if (v1 > nvox) v1 = nvox;
+  for (int q = q0; q < Q; q += Qb) {
+    float s[4] = {0, 0, 0, 0}, p[4] = {0, 0, 0, 0};
+    if (r < R) {
+      float4 mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
+      if (MODE == 1) { mu = *(const float4*)(mean + q * 4); is = *(const float4*)(invstd + q * 4); }
+      for (long v = v0 + r; v < v1; v += R) {
+        int b, t, h, w;
+        decode_vox(x, v, b, t, h, w);
+        const float4 xv = ldq<T>((const T*)x.p + vox_off(x, b, t, h, w) + q * 4);
+        if (MODE == 0) {
+          s[0] += xv.x; s[1] += xv.y; s[2] += xv.z; s[3] += xv.w;
+          p[0] += xv.x * xv.x; p[1] += xv.y * xv.y; p[2] += xv.z * xv.z; p[3] += xv.w * xv.w;
+        } else {
+          float4 g = ldq<T>((const T*)dz.p + vox_off(dz, b, t, h, w) + q * 4);
+          if (fwd.relu) {
+            Affine na = fwd; na.relu = 0;
+            const float4 z = affine4(xv, na, q * 4);
+            if (!(z.x > 0.f)) g.x = 0.f;
+            if (!(z.y > 0.f)) g.y = 0.f;
+            if (!(z.z > 0.f)) g.z = 0.f;
+            if (!(z.w > 0.f)) g.w = 0.f;
+          }
+          s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+          p[0] += g.x * (xv.x - mu.x) * is.x; p[1] += g.y * (xv.y - mu.y) * is.y;
+          p[2] += g.z * (xv.z - mu.z) * is.z; p[3] += g.w * (xv.w - mu.w) * is.w;
+        }
+      }
+    }
+    __syncthreads();
+    if (r < R) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[threadIdx.x * 8 + e] = s[e]; red[threadIdx.x * 8 + 4 + e] = p[e]; }
+    }
+    __syncthreads();
+    if (r == 0) {
+      for (int rr = 1; rr < R; ++rr)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += red[(rr * Qb + q0) * 8 + e]; p[e] += red[(rr * Qb + q0) * 8 + 4 + e]; }
+      float* o = partials + (long)blockIdx.x * 2 * x.C + q * 4;
+      *(float4*)o = make_float4(s[0], s[1], s[2], s[3]);
+      *(float4*)(o + x.C) = make_float4(p[0], p[1], p[2], p[3]);
+    }
+  }
+}
+
+template <int MODE>
+static int launch_channel_reduce(const VinetTensor* x, const VinetTensor* dz, int dtype, VinetAffine fwd,
+                                 const float* mean, const float* invstd, float* partials, void* stream) {
+  const long nvox = view_voxels(*x);
+  const int rows = stats_rows_for(nvox);
+  const long vb = (nvox + rows - 1) / rows;
+  const TView xv = make_view(*x), dv = dz ? make_view(*dz) : xv;
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL((channel_reduce_kernel<T, MODE>), dim3(rows), dim3(256), 0,
+                                          (hipStream_t)stream, xv, dv, make_affine(fwd), mean, invstd, nvox, vb, partials);)
+  return vn_launch_status("channel_reduce");
+}
+
+extern "C" int vinet_channel_stats(const VinetTensor* x, int32_t dtype, float* partials, void* stream) {
+  VN_CHECK_ARG(x && partials && quad_ok(*x, esize(dtype)), "channel_stats: bad arguments");
+  VinetAffine none = {nullptr, nullptr, 0};
+  return launch_channel_reduce<0>(x, nullptr, dtype, none, nullptr, nullptr, partials, stream);
+}
+
+extern "C" int vinet_bn_bwd_reduce(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,
+                                   const float* mean, const float* invstd, float* partials, void* stream) {
+  VN_CHECK_ARG(dz && x_raw && partials && mean && invstd && quad_ok(*dz, esize(dtype)) && quad_ok(*x_raw, esize(dtype)) &&
+                   same_dims(*dz, *x_raw), "bn_bwd_reduce: bad arguments");
+  return launch_channel_reduce<1>(x_raw, dz, dtype, fwd, mean, invstd, partials, stream);
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int C, double count,
+                                       const float* scale, int train, float* dgamma, float* dbeta,
+                                       const float* invstd, float* c1, float* c2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, p = 0.0;
+  for (int r = 0; r < rows; ++r) { s += (double)partials[((long)r * 2) * C + c]; p += (double)partials[((long)r * 2 + 1) * C + c]; }
+  if (dgamma) dgamma[c] += (float)p;
+  if (dbeta) dbeta[c] += (float)s;
+  if (c1) c1[c] = train ? (float)(s / count) : 0.f;
+  if (c2) c2[c] = train ? (float)(p / count) : 0.f;
+}
+
+extern "C" int vinet_bn_bwd_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* scale,
+                                     int32_t train, float* dgamma_acc, float* dbeta_acc, const float* invstd, float* c1,
+                                     float* c2, void* stream) {
+  VN_CHECK_ARG(partials && rows > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials, rows, C,
+                     count, scale, train, dgamma_acc, dbeta_acc, invstd, c1, c2);
+  return vn_launch_status("bn_bwd_finalize");
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(TView dz, TView x, Affine fwd, const float* mean, const float* invstd,
+                                    const float* c1, const float* c2, TView dx, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Q = x.C / 4;
+  const int q = (int)(i % Q);
+  const long vox = i / Q;
+  int b, t, h, w;
+  decode_vox(x, vox, b, t, h, w);
+  const float4 xv = ldq<T>((const T*)x.p + vox_off(x, b, t, h, w) + q * 4);
+  float4 g = ldq<T>((const T*)dz.p + vox_off(dz, b, t, h, w) + q * 4);
+  const float4 sc = *(const float4*)(fwd.scale + q * 4);
+  if (fwd.relu) {
+    const float4 sh = *(const float4*)(fwd.shift + q * 4);
+    if (!(fmaf(xv.x, sc.x, sh.x) > 0.f)) g.x = 0.f;
+    if (!(fmaf(xv.y, sc.y, sh.y) > 0.f)) g.y = 0.f;
+    if (!(fmaf(xv.z, sc.z, sh.z) > 0.f)) g.z = 0.f;
+    if (!(fmaf(xv.w, sc.w, sh.w) > 0.f)) g.w = 0.f;
+  }
+  const float4 mu = *(const float4*)(mean + q * 4), is = *(const float4*)(invstd + q * 4);
+  const float4 a1 = *(const float4*)(c1 + q * 4), a2 = *(const float4*)(c2 + q * 4);
+  float4 o;
+  o.x = sc.x * (g.x - a1.x - (xv.x - mu.x) * is.x * a2.x);
+  o.y = sc.y * (g.y - a1.y - (xv.y - mu.y) * is.y * a2.y);
+  o.z = sc.z * (g.z - a1.z - (xv.z - mu.z) * is.z * a2.z);
+  o.w = sc.w * (g.w - a1.w - (xv.w - mu.w) * is.w * a2.w);
+  stq<T>((T*)dx.p + vox_off(dx, b, t, h, w) + q * 4, o);
+}
+
+extern "C" int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,
+                                  const float* mean, const float* invstd, const float* c1, const float* c2,
+                                  const VinetTensor* dx, void* stream) {
+  VN_CHECK_ARG(dz && x_raw && dx && fwd.scale && fwd.shift && mean && invstd && c1 && c2, "bn_bwd_apply: null argument");
+  VN_CHECK_ARG(quad_ok(*dz, esize(dtype)) && quad_ok(*x_raw, esize(dtype)) && quad_ok(*dx, esize(dtype)) &&
+                   same_dims(*dz, *x_raw) && same_dims(*dz, *dx), "bn_bwd_apply: bad views");
+  const long total = view_voxels(*dz) * (dz->C / 4);
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+                                          (hipStream_t)stream, make_view(*dz), make_view(*x_raw), make_affine(fwd), mean,
+                                          invstd, c1, c2, make_view(*dx), total);)
+  return vn_launch_status("bn_bwd_apply");
+}
+
+template <typename TG, typename TZ, typename TO>
+__global__ void act_bwd_kernel(TView dz, TView z, int act, TView dy, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Q = z.C / 4;
+  const int q = (int)(i % Q);
+  const long vox = i / Q;
+  int b, t, h, w;
+  decode_vox(z, vox, b, t, h, w);
+  const float4 zv = ldq<TZ>((const TZ*)z.p + vox_off(z, b, t, h, w) + q * 4);
+  float4 g = ldq<TG>((const TG*)dz.p + vox_off(dz, b, t, h, w) + q * 4);
+  if (act == VINET_ACT_RELU) {
+    if (!(zv.x > 0.f)) g.x = 0.f;
+    if (!(zv.y > 0.f)) g.y = 0.f;
+    if (!(zv.z > 0.f)) g.z = 0.f;
+    if (!(zv.w > 0.f)) g.w = 0.f;
+  } else if (act == VINET_ACT_SIGMOID) {
+    g.x *= zv.x * (1.f - zv.x); g.y *= zv.y * (1.f - zv.y); g.z *= zv.z * (1.f - zv.z); g.w *= zv.w * (1.f - zv.w);
+  }
+  stq<TO>((TO*)dy.p + vox_off(dy, b, t, h, w) + q * 4, g);
+}
+
+extern "C" int vinet_act_bwd(const VinetTensor* dz, int32_t dz_dtype, const VinetTensor* z, int32_t z_dtype,
+                             int32_t act, const VinetTensor* dy, int32_t dy_dtype, void* stream) {
+  VN_CHECK_ARG(dz && z && dy && quad_ok(*dz, esize(dz_dtype)) && quad_ok(*z, esize(z_dtype)) &&
+                   quad_ok(*dy, esize(dy_dtype)) && same_dims(*dz, *z) && same_dims(*dz, *dy), "act_bwd: bad views");
+  const long total = view_voxels(*z) * (z->C / 4);
+  const dim3 g(ew_grid(total)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  const TView a = make_view(*dz), b = make_view(*z), c = make_view(*dy);
+#define ACT_CASE(D1, T1, D2, T2, D3, T3) \
+  if (dz_dtype == D1 && z_dtype == D2 && dy_dtype == D3) { hipLaunchKernelGGL((act_bwd_kernel<T1, T2, T3>), g, blk, 0, s, a, b, act, c, total); return vn_launch_status("act_bwd"); }
+  ACT_CASE(VINET_F32, float, VINET_F32, float, VINET_F32, float)
+  ACT_CASE(VINET_BF16, bf16_t, VINET_BF16, bf16_t, VINET_BF16, bf16_t)
+  ACT_CASE(VINET_F32, float, VINET_F32, float, VINET_BF16, bf16_t)
+  ACT_CASE(VINET_F32, float, VINET_BF16, bf16_t, VINET_BF16, bf16_t)
+  ACT_CASE(VINET_BF16, bf16_t, VINET_F32, float, VINET_BF16, bf16_t)
+#undef ACT_CASE
+  vinet_set_error("act_bwd: unsupported dtype combination %d/%d/%d", dz_dtype, z_dtype, dy_dtype);
+  return -1;
+}
+
+__global__ void channel_sum_finalize_kernel(const float* __restrict__ partials, int rows, int C, int Cout, float* out,
+                                            int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Cout) return;
+  double s = 0.0;
+  for (int c = j; c < C; c += Cout)
+    for (int r = 0; r < rows; ++r) s += (double)partials[((long)r * 2) * C + c];
+  out[j] = accumulate ? out[j] + (float)s : (float)s;
+}
+
+extern "C" int vinet_channel_sum(const VinetTensor* x, int32_t dtype, float* workspace, int32_t Cout, float* out,
+                                 int32_t accumulate, void* stream) {
+  VN_CHECK_ARG(x && workspace && out && Cout > 0 && quad_ok(*x, esize(dtype)) && x->C % Cout == 0, "channel_sum: bad arguments");
+  VinetAffine none = {nullptr, nullptr, 0};
+  int rc = launch_channel_reduce<0>(x, nullptr, dtype, none, nullptr, nullptr, workspace, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((Cout + 63) / 64), dim3(64), 0, (hipStream_t)stream, workspace,
+                     stats_rows_for(view_voxels(*x)), x->C, Cout, out, accumulate);
+  return vn_launch_status("channel_sum");
+}
+
+// ============================================================================
+// MaxPool3d
+// ============================================================================
+struct PoolP { int kT, kH, kW, sT, sH, sW, pT, pH, pW; };
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(PoolP p, TView x, Affine pre, TView y, uint8_t* __restrict__ argmax, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Q = y.C / 4;
+  const int q = (int)(i % Q);
+  const long vox = i / Q;
+  int b, to, ho, wo;
+  decode_vox(y, vox, b, to, ho, wo);
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {0, 0, 0, 0};
+  for (int kt = 0; kt < p.kT; ++kt) {
+    const int t = to * p.sT - p.pT + kt;
+    if ((unsigned)t >= (unsigned)x.T) continue;
+    for (int kh = 0; kh < p.kH; ++kh) {
+      const int h = ho * p.sH - p.pH + kh;
+      if ((unsigned)h >= (unsigned)x.H) continue;
+      for (int kw = 0; kw < p.kW; ++kw) {
+        const int w = wo * p.sW - p.pW + kw;
+        if ((unsigned)w >= (unsigned)x.W) continue;
+        float4 v = ldq<T>((const T*)x.p + vox_off(x, b, t, h, w) + q * 4);
+        v = affine4(v, pre, q * 4);
+        const int tap = (kt * p.kH + kh) * p.kW + kw;
+        const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (f[e] > best[e] || (f[e] != f[e] && best[e] == best[e])) { best[e] = f[e]; bi[e] = tap; }
+      }
+    }
+  }
+  stq<T>((T*)y.p + vox_off(y, b, to, ho, wo) + q * 4, make_float4(best[0], best[1], best[2], best[3]));
+  if (argmax) *(uint32_t*)(argmax + vox * y.C + q * 4) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+}
+
+extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, VinetAffine pre, const VinetTensor* y,
+                               uint8_t* argmax, void* stream) {
+  VN_CHECK_ARG(d && x && y && quad_ok(*x, esize(d->dtype)) && quad_ok(*y, esize(d->dtype)) && x->C == y->C && x->B == y->B,
+               "maxpool3d: bad views");
+  VN_CHECK_ARG(d->kT * d->kH * d->kW <= 255 && d->kT > 0 && d->kH > 0 && d->kW > 0, "maxpool3d: window too large");
+  const PoolP p = {d->kT, d->kH, d->kW, d->sT, d->sH, d->sW, d->pT, d->pH, d->pW};
+  const long total = view_voxels(*y) * (y->C / 4);
+  DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+                                             (hipStream_t)stream, p, make_view(*x), make_affine(pre), make_view(*y), argmax, total);)
+  return vn_launch_status("maxpool3d");
+}
+
+// backward as a gather over the (at most ceil(k/s)^3) windows covering each input voxel
+template <typename T>
+__global__ void maxpool_bwd_kernel(PoolP p, TView dy, const uint8_t* __restrict__ argmax, TView dx, int accumulate,
+                                   long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Q = dx.C / 4;
+  const int q = (int)(i % Q);
+  const long vox = i / Q;
+  int b, t, h, w;
+  decode_vox(dx, vox, b, t, h, w);
+  float g[4] = {0, 0, 0, 0};
+  // windows: o*s - pad <= pos <= o*s - pad + k - 1
+  const int to1 = min((t + p.pT) / p.sT, dy.T - 1), ho1 = min((h + p.pH) / p.sH, dy.H - 1), wo1 = min((w + p.pW) / p.sW, dy.W - 1);
+  const int to0 = max(0, (t + p.pT - p.kT + p.sT) / p.sT), ho0 = max(0, (h + p.pH - p.kH + p.sH) / p.sH),
+            wo0 = max(0, (w + p.pW - p.kW + p.sW) / p.sW);
+  for (int to = to0; to <= to1; ++to) {
+    const int kt = t + p.pT - to * p.sT;
+    if (kt < 0 || kt >= p.kT) continue;
+    for (int ho = ho0; ho <= ho1; ++ho) {
+      const int kh = h + p.pH - ho * p.sH;
+      if (kh < 0 || kh >= p.kH) continue;
+      for (int wo = wo0; wo <= wo1; ++wo) {
+        const int kw = w + p.pW - wo * p.sW;
+        if (kw < 0 || kw >= p.kW) continue;
+        const uint32_t tap = (uint32_t)((kt * p.kH + kh) * p.kW + kw);
+        const long ovox = (((long)b * dy.T + to) * dy.H + ho) * dy.W + wo;
+        const uint32_t am = *(const uint32_t*)(argmax + ovox * dy.C + q * 4);
+        if (am == 0xffffffffu) continue;
+        const float4 d = ldq<T>((const T*)dy.p + vox_off(dy, b, to, ho, wo) + q * 4);
+        if ((am & 0xff) == tap) g[0] += d.x;
+        if (((am >> 8) & 0xff) == tap) g[1] += d.y;
+        if (((am >> 16) & 0xff) == tap) g[2] += d.z;
+        if (((am >> 24) & 0xff) == tap) g[3] += d.w;
+      }
+    }
+  }
+  T* dst = (T*)dx.p + vox_off(dx, b, t, h, w) + q * 4;
+  if (accumulate) { const float4 o = ldq<T>(dst); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
+  stq<T>(dst, make_float4(g[0], g[1], g[2], g[3]));
+}
+
+extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy, const uint8_t* argmax,
+                                   const VinetTensor* dx, int32_t accumulate, void* stream) {
+  VN_CHECK_ARG(d && dy && dx && argmax && quad_ok(*dy, esize(d->dtype)) && quad_ok(*dx, esize(d->dtype)) &&
+                   dx->C == dy->C && dx->B == dy->B, "maxpool3d_bwd: bad views");
+  const PoolP p = {d->kT, d->kH, d->kW, d->sT, d->sH, d->sW, d->pT, d->pH, d->pW};
+  const long total = view_voxels(*dx) * (dx->C / 4);
+  DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+                                             (hipStream_t)stream, p, make_view(*dy), argmax, make_view(*dx), accumulate, total);)
+  return vn_launch_status("maxpool3d_bwd");
+}
+
+// ============================================================================
+// Upsample (1,2,2) trilinear, align_corners=False  (separable .25/.75 stencil)
+// ============================================================================
+template <typename T>
+__global__ void upsample2x_kernel(TView x, TView y, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Q = y.C / 4;
+  const int q = (int)(i % Q);
+  const long vox = i / Q;
+  int b, t, ho, wo;
+  decode_vox(y, vox, b, t, ho, wo);
+  // src = max((o + .5)/2 - .5, 0); i0 = floor(src); l1 = src - i0; i1 = i0 + (i0 < n-1)
+  const float sh = fmaxf((ho + 0.5f) * 0.5f - 0.5f, 0.f), sw = fmaxf((wo + 0.5f) * 0.5f - 0.5f, 0.f);
+  const int h0 = (int)sh, w0 = (int)sw;
+  const int h1 = h0 + (h0 < x.H - 1 ? 1 : 0), w1 = w0 + (w0 < x.W - 1 ? 1 : 0);
+  const float lh1 = sh - h0, lh0 = 1.f - lh1, lw1 = sw - w0, lw0 = 1.f - lw1;
+  const T* base = (const T*)x.p;
+  const float4 v00 = ldq<T>(base + vox_off(x, b, t, h0, w0) + q * 4), v01 = ldq<T>(base + vox_off(x, b, t, h0, w1) + q * 4);
+  const float4 v10 = ldq<T>(base + vox_off(x, b, t, h1, w0) + q * 4), v11 = ldq<T>(base + vox_off(x, b, t, h1, w1) + q * 4);
+  float4 o;
+  o.x = lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
+  o.y = lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
+  o.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
+  o.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
+  stq<T>((T*)y.p + vox_off(y, b, t, ho, wo) + q * 4, o);
+}
+
+extern "C" int vinet_upsample2x(const VinetTensor* x, const VinetTensor* y, int32_t dtype, void* stream) {
+  VN_CHECK_ARG(x && y && quad_ok(*x, esize(dtype)) && quad_ok(*y, esize(dtype)) && x->C == y->C && x->B == y->B &&
+                   x->T == y->T && y->H == 2 * x->H && y->W == 2 * x->W, "upsample2x: bad views");
+  const long total = view_voxels(*y) * (y->C / 4);
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL(upsample2x_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                          make_view(*x), make_view(*y), total);)
+  return vn_launch_status("upsample2x");
+}
+
+// 1-D transpose stencil: input i receives from outputs 2i-1 (.25), 2i (.75 or 1 at i=0),
+// 2i+1 (.75 or 1 at i=n-1), 2i+2 (.25)
+VN_DEV void up_bwd_taps(int i, int n, int* o, float* wgt) {
+  o[0] = 2 * i - 1; wgt[0] = i >= 1 ? 0.25f : 0.f;
+  o[1] = 2 * i;     wgt[1] = i == 0 ? 1.f : 0.75f;
+  o[2] = 2 * i + 1; wgt[2] = i == n - 1 ? 1.f : 0.75f;
+  o[3] = 2 * i + 2; wgt[3] = i <= n - 2 ? 0.25f : 0.f;
+}
+
+template <typename T>
+__global__ void upsample2x_bwd_kernel(TView dy, TView dx, int accumulate, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Q = dx.C / 4;
+  const int q = (int)(i % Q);
+  const long vox = i / Q;
+  int b, t, h, w;
+  decode_vox(dx, vox, b, t, h, w);
+  int oh[4], ow[4];
+  float wh[4], ww[4];
+  up_bwd_taps(h, dx.H, oh, wh);
+  up_bwd_taps(w, dx.W, ow, ww);
+  float4 g = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (wh[a] == 0.f) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (ww[c] == 0.f) continue;
+      const float k = wh[a] * ww[c];
+      const float4 d = ldq<T>((const T*)dy.p + vox_off(dy, b, t, oh[a], ow[c]) + q * 4);
+      g.x += k * d.x; g.y += k * d.y; g.z += k * d.z; g.w += k * d.w;
+    }
+  }
+  T* dst = (T*)dx.p + vox_off(dx, b, t, h, w) + q * 4;
+  if (accumulate) { const float4 o = ldq<T>(dst); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+  stq<T>(dst, g);
+}
+
+extern "C" int vinet_upsample2x_bwd(const VinetTensor* dy, const VinetTensor* dx, int32_t dtype, int32_t accumulate,
+                                    void* stream) {
+  VN_CHECK_ARG(dy && dx && quad_ok(*dy, esize(dtype)) && quad_ok(*dx, esize(dtype)) && dx->C == dy->C && dx->B == dy->B &&
+                   dx->T == dy->T && dy->H == 2 * dx->H && dy->W == 2 * dx->W, "upsample2x_bwd: bad views");
+  const long total = view_voxels(*dx) * (dx->C / 4);
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+                                          (hipStream_t)stream, make_view(*dy), make_view(*dx), accumulate, total);)
+  return vn_launch_status("upsample2x_bwd");
+}
+
+__global__ void fill_f32_kernel(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+extern "C" int vinet_fill_f32(float* p, int64_t n, float value, void* stream) {
+  VN_CHECK_ARG(p && n >= 0, "fill_f32: bad arguments");
+  if (n == 0) return 0;
+  int grid = ew_grid(n); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, (long)n, value);
+  return vn_launch_status("fill_f32");
+}

@@ -1,0 +1,685 @@
+"""Host-side engine of the MI355X ViNet path.
+
+Everything a module forward/backward does on the device goes through this file
+as calls into libvinet_hip.so (vinet_amd/_lib.py): there are no torch compute
+kernels on the path.  torch is used for device memory (caching allocator),
+streams, autograd *entry points* and torch.distributed.
+
+Concepts
+  View  channels-last 5-D view [B][T][H][W][C] of a flat torch buffer, with W
+        stride `ld` (channel slices of a concat buffer) and batch stride `sB`
+        (T slices of a longer buffer).
+  Act   a View plus a *pending* per-channel affine(+ReLU).  In training mode a
+        conv stores its raw output and BatchNorm's scale/shift only exist once
+        the whole tensor has been reduced, so BN+ReLU is applied by whichever
+        kernel loads the tensor next (conv / wgrad / pool loaders) instead of in
+        a separate pass over HBM.  `Act.grad` is always the gradient w.r.t. the
+        transformed value.
+  Tape  list of backward closures recorded during a training forward; run in
+        reverse by the single autograd node that wraps a root module call.
+"""
+import ctypes as C
+import itertools
+import math
+
+import torch
+
+from . import _lib as L
+
+F32, BF16 = L.F32, L.BF16
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+ESIZE = {F32: 4, BF16: 2}
+EG = {F32: 4, BF16: 8}          # elements per 16 bytes
+
+_DEFAULT_DTYPE = BF16
+_WEIGHTS_EPOCH = 0
+
+
+def set_default_dtype(name):
+    """'bf16' (throughput path, default) or 'fp32' (exact parity path)."""
+    global _DEFAULT_DTYPE
+    _DEFAULT_DTYPE = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "float32": F32}[str(name).replace("torch.", "")]
+
+
+def default_dtype():
+    return _DEFAULT_DTYPE
+
+
+def bump_weights_epoch():
+    """Called by anything that rewrites parameters behind torch's back (the fused
+    Adam kernel): invalidates every cached weight pack."""
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+
+
+def rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def _stream_for(device):
+    if device.type == "cuda":
+        return torch.cuda.current_stream(device).cuda_stream
+    if not L.is_test_double():
+        raise RuntimeError("vinet_amd runs on MI355X only: tensor on %s and no HIP device (no CPU fallback)" % device)
+    return 0
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class View:
+    __slots__ = ("buf", "off", "B", "T", "H", "W", "C", "ld", "sB", "dt")
+
+    def __init__(self, buf, off, B, T, H, W, Cc, ld, sB, dt):
+        self.buf, self.off, self.B, self.T, self.H, self.W, self.C, self.ld, self.sB, self.dt = buf, off, B, T, H, W, Cc, ld, sB, dt
+
+    @staticmethod
+    def alloc(B, T, H, W, Cc, dt, device, zero=False):
+        n = B * T * H * W * Cc
+        buf = (torch.zeros if zero else torch.empty)(n, dtype=TORCH_DT[dt], device=device)
+        return View(buf, 0, B, T, H, W, Cc, Cc, T * H * W * Cc, dt)
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    @property
+    def nvox(self):
+        return self.B * self.T * self.H * self.W
+
+    def ptr(self):
+        return self.buf.data_ptr() + self.off * ESIZE[self.dt]
+
+    def ct(self):
+        return L.CTensor(self.ptr(), self.B, self.T, self.H, self.W, self.C, self.ld, self.sB)
+
+    def chan(self, c0, c1):
+        assert 0 <= c0 < c1 <= self.C
+        return View(self.buf, self.off + c0, self.B, self.T, self.H, self.W, c1 - c0, self.ld, self.sB, self.dt)
+
+    def tslice(self, t0, t1):
+        assert 0 <= t0 < t1 <= self.T
+        return View(self.buf, self.off + t0 * self.H * self.W * self.ld, self.B, t1 - t0, self.H, self.W, self.C, self.ld, self.sB, self.dt)
+
+    def quads(self):
+        """dense view reinterpreted as [1,1,1,n/4,4] (C==1 tensors for quad kernels)."""
+        assert self.ld == self.C and self.sB == self.T * self.H * self.W * self.C
+        n = self.nvox * self.C
+        assert n % 4 == 0
+        return View(self.buf, self.off, 1, 1, 1, n // 4, 4, 4, n, self.dt)
+
+    def torch5(self):
+        """[B,T,H,W,C] strided torch view (tests / debugging)."""
+        return torch.as_strided(self.buf, (self.B, self.T, self.H, self.W, self.C),
+                                (self.sB, self.H * self.W * self.ld, self.W * self.ld, self.ld, 1), self.off)
+
+    def same_dims(self, o):
+        return (self.B, self.T, self.H, self.W, self.C) == (o.B, o.T, o.H, o.W, o.C)
+
+
+class Act:
+    """activation = view + pending affine/relu + gradient bookkeeping."""
+    __slots__ = ("v", "scale", "shift", "relu", "_grad", "grad_ready", "needs_grad", "parent", "pc0", "pt0")
+
+    def __init__(self, v, scale=None, shift=None, relu=False, needs_grad=False):
+        self.v, self.scale, self.shift, self.relu = v, scale, shift, relu
+        self._grad, self.grad_ready, self.needs_grad = None, False, needs_grad
+        self.parent, self.pc0, self.pt0 = None, 0, 0
+
+    @property
+    def plain(self):
+        return self.scale is None and not self.relu
+
+    def affine(self):
+        return L.CAffine(_ptr(self.scale), _ptr(self.shift), 1 if self.relu else 0)
+
+    def sub_chan(self, c0, c1):
+        """channel slice sharing gradient storage with self (concat member)."""
+        a = Act(self.v.chan(c0, c1), None if self.scale is None else self.scale[c0:c1],
+                None if self.shift is None else self.shift[c0:c1], self.relu, self.needs_grad)
+        a.parent, a.pc0, a.pt0 = self, c0, None
+        return a
+
+    def sub_t(self, t0, t1):
+        a = Act(self.v.tslice(t0, t1), self.scale, self.shift, self.relu, self.needs_grad)
+        a.parent, a.pt0, a.pc0 = self, t0, None
+        return a
+
+    def root(self):
+        a = self
+        while a.parent is not None:
+            a = a.parent
+        return a
+
+    # ---- gradients ------------------------------------------------------
+    def grad_view(self, dt=None, zero=False):
+        """gradient storage (allocated on first use; slices resolve into the parent's)."""
+        if self.parent is not None:
+            g = self.parent.grad_view(dt, zero)
+            if self.pt0 is None:
+                return g.chan(self.pc0, self.pc0 + self.v.C)
+            return g.tslice(self.pt0, self.pt0 + self.v.T)
+        if self._grad is None:
+            v = self.v
+            self._grad = View.alloc(v.B, v.T, v.H, v.W, v.C, v.dt if dt is None else dt, v.device, zero=zero)
+            if zero:
+                self.grad_ready = True
+        return self._grad
+
+    def is_grad_ready(self):
+        return self.root().grad_ready
+
+    def mark_grad_ready(self):
+        self.root().grad_ready = True
+
+
+class Ctx:
+    """one forward(/backward) pass: dtype, mode, stream, tape."""
+
+    def __init__(self, device, dt=None, training=False, record=False):
+        self.lib = L.get()
+        self.device = device
+        self.dt = _DEFAULT_DTYPE if dt is None else dt
+        self.training = training
+        self.tape = [] if record else None
+        self.stream = _stream_for(device)
+
+    @property
+    def recording(self):
+        return self.tape is not None
+
+    def f32(self, n, zero=False):
+        return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.device)
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(*args)
+        if rc != 0:
+            L.check(rc, name)
+
+    def record(self, fn):
+        if self.tape is not None:
+            self.tape.append(fn)
+
+    def run_backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+
+# ----------------------------------------------------------------------------
+# import / export at module boundaries
+# ----------------------------------------------------------------------------
+
+def import_ncdhw(ctx, t, cpad=None, needs_grad=False):
+    """fp32 NCDHW-logical torch tensor (any strides) -> Act (channels-last, ctx.dt)."""
+    assert t.dim() == 5 and t.dtype == torch.float32, "expected fp32 [B,C,T,H,W]"
+    B, Cc, T, H, W = t.shape
+    cp = rup(Cc, EG[ctx.dt]) if cpad is None else cpad
+    v = View.alloc(B, T, H, W, cp, ctx.dt, t.device)
+    sb, sc, st, sh, sw = t.stride()
+    ctx.call("vinet_import_ncdhw", t.data_ptr(), sb, sc, st, sh, sw, Cc, C.byref(v.ct()), ctx.dt, ctx.stream)
+    a = Act(v, needs_grad=needs_grad)
+    return a
+
+
+def export_ncdhw(ctx, a, channels=None):
+    """Act -> fp32 contiguous NCDHW tensor (pending affine applied)."""
+    v = a.v
+    Cc = v.C if channels is None else channels
+    out = torch.empty((v.B, v.C, v.T, v.H, v.W), dtype=torch.float32, device=v.device)
+    sb, sc, st, sh, sw = out.stride()
+    ctx.call("vinet_export_ncdhw", C.byref(v.ct()), v.dt, a.affine(), out.data_ptr(), sb, sc, st, sh, sw, 0, ctx.stream)
+    return out[:, :Cc] if Cc != v.C else out
+
+
+def export_grad_ncdhw(ctx, a, channels):
+    g = a.grad_view()
+    out = torch.empty((g.B, g.C, g.T, g.H, g.W), dtype=torch.float32, device=g.device)
+    sb, sc, st, sh, sw = out.stride()
+    ctx.call("vinet_export_ncdhw", C.byref(g.ct()), g.dt, L.CAffine(None, None, 0), out.data_ptr(), sb, sc, st, sh, sw, 0, ctx.stream)
+    return out[:, :channels] if channels != g.C else out
+
+
+def import_grad_ncdhw(ctx, a, gt):
+    """seed a.grad from an fp32 NCDHW gradient tensor."""
+    g = a.grad_view()
+    B, Cc, T, H, W = gt.shape
+    sb, sc, st, sh, sw = gt.stride()
+    ctx.call("vinet_import_ncdhw", gt.data_ptr(), sb, sc, st, sh, sw, Cc, C.byref(g.ct()), g.dt, ctx.stream)
+    a.mark_grad_ready()
+
+
+def materialize(ctx, a, dst=None, out_dt=None):
+    """apply the pending affine (or just copy / convert) into `dst`; returns a plain Act."""
+    v = a.v
+    if dst is None:
+        dt = ctx.dt if out_dt is None else out_dt
+        dst = Act(View.alloc(v.B, v.T, v.H, v.W, v.C, dt, v.device))
+    out = dst.v
+    assert out.same_dims(v) and dst.plain
+    ctx.call("vinet_copy_affine", C.byref(v.ct()), v.dt, a.affine(), C.byref(out.ct()), out.dt, 0, ctx.stream)
+    dst.needs_grad = a.needs_grad
+    if ctx.recording and a.needs_grad:
+        def bwd():
+            dg = dst.grad_view()
+            tg = a.grad_view()
+            ctx.call("vinet_copy_affine", C.byref(dg.ct()), dg.dt, L.CAffine(None, None, 0), C.byref(tg.ct()), tg.dt,
+                     1 if a.is_grad_ready() else 0, ctx.stream)
+            a.mark_grad_ready()
+        ctx.record(bwd)
+    return dst
+
+
+def new_concat(ctx, B, T, H, W, Ctot, pending):
+    """destination of a channel concat; `pending` reserves per-channel scale/shift
+    vectors that the member convs' BN finalize kernels fill in place."""
+    v = View.alloc(B, T, H, W, Ctot, ctx.dt, ctx.device)
+    if pending:
+        return Act(v, ctx.f32(Ctot), ctx.f32(Ctot), relu=True, needs_grad=True)
+    return Act(v, needs_grad=True)
+
+
+# ----------------------------------------------------------------------------
+# convolution plans
+# ----------------------------------------------------------------------------
+
+def _phase_taps_1d(I, O, k, s, p):
+    """dgrad of a 1-D strided conv as per-phase stride-1 correlations over dy.
+
+    returns list of (r, Q, [(offset, k_index), ...]): input positions r, r+s, ...
+    (Q of them) equal  sum_j dy[q + offset_j] * w[k_index_j].
+    """
+    out = []
+    for r in range(s):
+        if r >= I:
+            continue
+        Q = (I - r + s - 1) // s
+        d0 = (r + p) % s
+        e = (r + p - d0) // s
+        taps = []
+        j = 0
+        while d0 + s * j < k:
+            taps.append((e - j, d0 + s * j))
+            j += 1
+        out.append((r, Q, taps))
+    return out
+
+
+class ConvPlan:
+    """static description of one nn.Conv3d: geometry, parameters, cached packs and tap tables."""
+
+    def __init__(self, weight, bias, kernel, stride, padding, stem=False):
+        self.weight, self.bias = weight, bias
+        self.k, self.s, self.p = tuple(kernel), tuple(stride), tuple(padding)
+        self.N, self.Cin = weight.shape[0], weight.shape[1]
+        self.ntaps = self.k[0] * self.k[1] * self.k[2]
+        self.stem = stem
+        if stem:
+            assert self.k == (1, 7, 7) and self.Cin == 3 and self.p[2] == 3
+        self._packs = {}
+        self._taps = {}
+
+    # ---- geometry ---------------------------------------------------------
+    def out_dims(self, T, H, W):
+        return tuple((d + 2 * p - k) // s + 1 for d, k, s, p in zip((T, H, W), self.k, self.s, self.p))
+
+    def kp(self, transpose=False):
+        if self.stem and not transpose:
+            return 32
+        return rup(self.N if transpose else self.Cin, 32)
+
+    # ---- device-side constant tables --------------------------------------
+    def _dev_taps(self, key, rows, device):
+        k = (key, str(device))
+        t = self._taps.get(k)
+        if t is None:
+            t = torch.tensor(rows, dtype=torch.int32).reshape(-1, 4).to(device)
+            self._taps[k] = t
+        return t
+
+    def fwd_taps(self, device):
+        kT, kH, kW = self.k
+        pT, pH, pW = self.p
+        if self.stem:
+            rows = [(0, kh - pH, -pW, kh) for kh in range(kH)]
+        else:
+            rows = [(kt - pT, kh - pH, kw - pW, (kt * kH + kh) * kW + kw)
+                    for kt in range(kT) for kh in range(kH) for kw in range(kW)]
+        return self._dev_taps("fwd", rows, device), len(rows)
+
+    def dgrad_phases(self, in_dims, out_dims, device):
+        """list of dicts describing one vinet_conv3d launch per stride phase."""
+        kT, kH, kW = self.k
+        per = [_phase_taps_1d(I, O, k, s, p) for I, O, k, s, p in zip(in_dims, out_dims, self.k, self.s, self.p)]
+        phases = []
+        full = True
+        for (rT, QT, tT), (rH, QH, tH), (rW, QW, tW) in itertools.product(*per):
+            rows = [(oT_, oH_, oW_, (a * kH + b) * kW + c) for (oT_, a) in tT for (oH_, b) in tH for (oW_, c) in tW]
+            if not rows:
+                full = False
+                continue
+            key = ("dg", in_dims, rT, rH, rW)
+            phases.append(dict(taps=self._dev_taps(key, rows, device), ntaps=len(rows), Q=(QT, QH, QW), r=(rT, rH, rW)))
+        covered = all(len(p_) == min(s, I) for p_, s, I in zip(per, self.s, in_dims))
+        return phases, (full and covered)
+
+    # ---- packed weights -----------------------------------------------------
+    def packed(self, ctx, transpose=False):
+        key = (ctx.dt, transpose, str(ctx.device))
+        stamp = (self.weight._version, _WEIGHTS_EPOCH, self.weight.data_ptr())
+        ent = self._packs.get(key)
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
+        w = self.weight.detach()
+        assert w.dtype == torch.float32 and w.is_contiguous()
+        if self.stem and not transpose:
+            n = 7 * self.N * 32
+        elif not transpose:
+            n = self.ntaps * self.N * self.kp(False)
+        else:
+            n = self.ntaps * self.Cin * self.kp(True)
+        buf = ent[1] if ent is not None else torch.empty(n, dtype=TORCH_DT[ctx.dt], device=ctx.device)
+        ctx.call("vinet_pack_weights", w.data_ptr(), self.N, self.Cin, self.ntaps, 1 if transpose else 0,
+                 1 if (self.stem and not transpose) else 0, ctx.dt, buf.data_ptr(), ctx.stream)
+        self._packs[key] = (stamp, buf)
+        return buf
+
+
+class BNState:
+    """parameters/buffers of one BatchNorm + per-forward scratch."""
+
+    def __init__(self, gamma, beta, running_mean, running_var, eps, momentum):
+        self.gamma, self.beta, self.rm, self.rv, self.eps, self.momentum = gamma, beta, running_mean, running_var, eps, momentum
+        self.steps = 0   # forwards in training mode since the counter buffer was last synced
+
+
+def _param_grad(p):
+    """fp32 gradient buffer of a parameter that kernels accumulate into."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n_pad=None):
+    """x -> conv (-> BN) (-> act).  Returns the output Act.
+
+    training + bn : raw conv output is stored; statistics come from the conv
+                    epilogue; the result carries a pending (scale, shift, relu).
+    eval + bn     : BN folded into the conv epilogue together with ReLU.
+    no bn         : bias / activation in the epilogue.
+    `dst`         : optional destination Act (channel / T slice of a concat buffer).
+    `n_pad`       : store into a channel-padded output (N not a multiple of the vector width).
+    """
+    lib_dt = ctx.dt
+    xv = x.v
+    oT, oH, oW = plan.out_dims(xv.T, xv.H, xv.W)
+    Ny = plan.N if n_pad is None else n_pad
+    odt = lib_dt if out_dt is None else out_dt
+    if dst is None:
+        dst = Act(View.alloc(xv.B, oT, oH, oW, Ny, odt, xv.device))
+    out = dst.v
+    scale_out, shift_out = dst.scale, dst.shift
+    assert (out.B, out.T, out.H, out.W, out.C) == (xv.B, oT, oH, oW, Ny), "conv output view mismatch"
+    taps, ntaps = plan.fwd_taps(ctx.device)
+    w = plan.packed(ctx, False)
+
+    d = L.CConvDesc()
+    d.dtype, d.out_dtype, d.mode = lib_dt, out.dt, (L.CONV_STEM if plan.stem else L.CONV_GENERIC)
+    d.x, d.y = xv.ct(), out.ct()
+    d.oT, d.oH, d.oW = oT, oH, oW
+    d.sT, d.sH, d.sW = plan.s
+    d.omT = d.omH = d.omW = 1
+    d.ooT = d.ooH = d.ooW = 0
+    d.ntaps, d.taps, d.w, d.Kp = ntaps, taps.data_ptr(), w.data_ptr(), plan.kp(False)
+    d.pre = x.affine()
+    d.accumulate = 0
+    d.n_valid = plan.N if Ny != plan.N else 0
+    M = xv.B * oT * oH * oW
+
+    train_bn = bn is not None and ctx.training
+    keep = {}
+    res = dst
+    res.needs_grad = True
+    if bn is None:
+        d.out_scale, d.out_shift = None, _ptr(plan.bias)
+        d.act, d.stats = act, None
+        ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+        res.scale = res.shift = None
+        res.relu = False
+    elif not train_bn:
+        scale = ctx.f32(plan.N) if scale_out is None else scale_out
+        shift = ctx.f32(plan.N) if shift_out is None else shift_out
+        if ctx.recording:
+            # eval-mode BN with gradients: keep the raw conv output (+bias), BN(+ReLU) stays pending
+            invstd = ctx.f32(plan.N)
+            ctx.call("vinet_bn_fold", _ptr(bn.gamma), _ptr(bn.beta), bn.rm.data_ptr(), bn.rv.data_ptr(), None,
+                     float(bn.eps), plan.N, scale.data_ptr(), shift.data_ptr(), invstd.data_ptr(), ctx.stream)
+            d.out_scale, d.out_shift, d.act, d.stats = None, _ptr(plan.bias), L.ACT_NONE, None
+            ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+            res.scale, res.shift, res.relu = scale, shift, (act == L.ACT_RELU)
+            keep.update(mean=bn.rm, invstd=invstd)
+        else:
+            ctx.call("vinet_bn_fold", _ptr(bn.gamma), _ptr(bn.beta), bn.rm.data_ptr(), bn.rv.data_ptr(),
+                     _ptr(plan.bias), float(bn.eps), plan.N, scale.data_ptr(), shift.data_ptr(), None, ctx.stream)
+            d.out_scale, d.out_shift, d.act, d.stats = scale.data_ptr(), shift.data_ptr(), act, None
+            ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+            res.scale = res.shift = None
+            res.relu = False
+    else:
+        bm = ctx.lib.vinet_conv3d_tile_m(C.byref(d))
+        rows = (M + bm - 1) // bm
+        stats = ctx.f32(rows * 2 * plan.N)
+        d.out_scale, d.out_shift, d.act, d.stats = None, _ptr(plan.bias), L.ACT_NONE, stats.data_ptr()
+        ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+        scale = ctx.f32(plan.N) if scale_out is None else scale_out
+        shift = ctx.f32(plan.N) if shift_out is None else shift_out
+        mean, invstd = ctx.f32(plan.N), ctx.f32(plan.N)
+        ctx.call("vinet_bn_finalize", stats.data_ptr(), rows, plan.N, float(M), _ptr(bn.gamma), _ptr(bn.beta),
+                 float(bn.eps), float(bn.momentum), bn.rm.data_ptr(), bn.rv.data_ptr(), mean.data_ptr(),
+                 invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctx.stream)
+        bn.steps += 1
+        res.scale, res.shift, res.relu = scale, shift, (act == L.ACT_RELU)
+        keep.update(mean=mean, invstd=invstd)
+
+    if ctx.recording:
+        ctx.record(lambda: _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M))
+    return res
+
+
+def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
+    out = res.v
+    dz = res.grad_view()
+    assert res.is_grad_ready(), "conv backward reached before any consumer produced a gradient"
+    Ny = out.C
+    # ---- through BN / activation: dz -> dy (w.r.t. the raw conv output) --------
+    if bn is not None:
+        rows = ctx.lib.vinet_stats_rows(C.byref(dz.ct()))
+        ws = ctx.f32(rows * 2 * Ny)
+        fwd = res.affine()
+        ctx.call("vinet_bn_bwd_reduce", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
+                 keep["invstd"].data_ptr(), ws.data_ptr(), ctx.stream)
+        c1, c2 = ctx.f32(Ny), ctx.f32(Ny)
+        dg = _param_grad(bn.gamma) if bn.gamma is not None and bn.gamma.requires_grad else None
+        db = _param_grad(bn.beta) if bn.beta is not None and bn.beta.requires_grad else None
+        ctx.call("vinet_bn_bwd_finalize", ws.data_ptr(), rows, Ny, float(M), res.scale.data_ptr(), 1 if train_bn else 0,
+                 _ptr(dg), _ptr(db), keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), ctx.stream)
+        ctx.call("vinet_bn_bwd_apply", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
+                 keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), C.byref(dz.ct()), ctx.stream)
+        dy = dz
+    elif act != L.ACT_NONE:
+        if dz.dt == ctx.dt:
+            dy = dz
+        else:
+            dy = View.alloc(dz.B, dz.T, dz.H, dz.W, dz.C, ctx.dt, dz.device)
+        ctx.call("vinet_act_bwd", C.byref(dz.ct()), dz.dt, C.byref(out.ct()), out.dt, act, C.byref(dy.ct()), dy.dt, ctx.stream)
+    else:
+        dy = dz
+        if dz.dt != ctx.dt:
+            dy = View.alloc(dz.B, dz.T, dz.H, dz.W, dz.C, ctx.dt, dz.device)
+            ctx.call("vinet_copy_affine", C.byref(dz.ct()), dz.dt, L.CAffine(None, None, 0), C.byref(dy.ct()), dy.dt, 0, ctx.stream)
+    # ---- bias ------------------------------------------------------------------
+    if plan.bias is not None and plan.bias.requires_grad:
+        rows = ctx.lib.vinet_stats_rows(C.byref(dy.ct()))
+        ws = ctx.f32(rows * 2 * Ny)
+        gb = _param_grad(plan.bias)
+        # channel-padded head: pad-channel gradients are exactly zero, so folding
+        # channels modulo N leaves the real sums untouched
+        assert Ny % plan.N == 0 and (Ny == plan.N or plan.N == 1)
+        ctx.call("vinet_channel_sum", C.byref(dy.ct()), dy.dt, ws.data_ptr(), plan.N, gb.data_ptr(), 1, ctx.stream)
+    # ---- weight gradient ---------------------------------------------------------
+    if plan.weight.requires_grad:
+        taps, ntaps = plan.fwd_taps(ctx.device)
+        kp = plan.kp(False)
+        nsl = 7 if plan.stem else plan.ntaps
+        dw = ctx.f32(nsl * Ny * kp, zero=True)
+        wd = L.CWgradDesc()
+        wd.dtype, wd.mode = ctx.dt, (L.CONV_STEM if plan.stem else L.CONV_GENERIC)
+        wd.x, wd.dy = x.v.ct(), dy.ct()
+        wd.sT, wd.sH, wd.sW = plan.s
+        wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), kp
+        wd.pre = x.affine()
+        ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream)
+        if Ny != plan.N:
+            assert plan.ntaps == 1, "channel-padded outputs are only supported for 1x1x1 convs"
+        gw = _param_grad(plan.weight)
+        ctx.call("vinet_unpack_wgrad", dw.data_ptr(), plan.N, plan.Cin, plan.ntaps, 1 if plan.stem else 0, 1,
+                 gw.data_ptr(), ctx.stream)
+    # ---- data gradient -------------------------------------------------------------
+    if x.needs_grad:
+        xv = x.v
+        phases, full = plan.dgrad_phases((xv.T, xv.H, xv.W), (out.T, out.H, out.W), ctx.device)
+        ready = x.is_grad_ready()
+        dx = x.grad_view(zero=(not ready and not full))
+        acc = 1 if x.is_grad_ready() else 0
+        wt = plan.packed(ctx, True)
+        for ph in phases:
+            d = L.CConvDesc()
+            d.dtype, d.out_dtype, d.mode = ctx.dt, dx.dt, L.CONV_GENERIC
+            d.x, d.y = dy.ct(), dx.ct()
+            d.oT, d.oH, d.oW = ph["Q"]
+            d.sT = d.sH = d.sW = 1
+            d.omT, d.omH, d.omW = plan.s
+            d.ooT, d.ooH, d.ooW = ph["r"]
+            d.ntaps, d.taps, d.w, d.Kp = ph["ntaps"], ph["taps"].data_ptr(), wt.data_ptr(), plan.kp(True)
+            d.pre = L.CAffine(None, None, 0)
+            d.out_scale = d.out_shift = None
+            d.act, d.accumulate, d.stats = L.ACT_NONE, acc, None
+            d.n_valid = plan.Cin if xv.C != plan.Cin else 0
+            ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+        x.mark_grad_ready()
+
+
+# ----------------------------------------------------------------------------
+# pooling / upsample
+# ----------------------------------------------------------------------------
+
+def maxpool_forward(ctx, x, k, s, p, dst=None):
+    xv = x.v
+    od = tuple((d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((xv.T, xv.H, xv.W), k, s, p))
+    if dst is None:
+        dst = Act(View.alloc(xv.B, od[0], od[1], od[2], xv.C, xv.dt, xv.device))
+    out = dst.v
+    assert (out.T, out.H, out.W, out.C) == (od[0], od[1], od[2], xv.C) and dst.plain
+    pd = L.CPoolDesc(xv.dt, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
+    rec = ctx.recording and x.needs_grad
+    am = torch.empty(out.nvox * out.C, dtype=torch.uint8, device=xv.device) if rec else None
+    ctx.call("vinet_maxpool3d", C.byref(pd), C.byref(xv.ct()), x.affine(), C.byref(out.ct()), _ptr(am), ctx.stream)
+    dst.needs_grad = x.needs_grad
+    if rec:
+        def bwd():
+            dy = dst.grad_view()
+            if dy.ld != dy.C or dy.sB != dy.T * dy.H * dy.W * dy.C:
+                raise RuntimeError("maxpool backward expects a dense output gradient")
+            dx = x.grad_view()
+            ctx.call("vinet_maxpool3d_bwd", C.byref(pd), C.byref(dy.ct()), am.data_ptr(), C.byref(dx.ct()),
+                     1 if x.is_grad_ready() else 0, ctx.stream)
+            x.mark_grad_ready()
+        ctx.record(bwd)
+    return dst
+
+
+def upsample2x_forward(ctx, x, dst=None):
+    assert x.plain, "upsample input must be materialised"
+    xv = x.v
+    if dst is None:
+        dst = Act(View.alloc(xv.B, xv.T, 2 * xv.H, 2 * xv.W, xv.C, xv.dt, xv.device))
+    out = dst.v
+    assert dst.plain
+    ctx.call("vinet_upsample2x", C.byref(xv.ct()), C.byref(out.ct()), xv.dt, ctx.stream)
+    dst.needs_grad = x.needs_grad
+    if ctx.recording and x.needs_grad:
+        def bwd():
+            dy = dst.grad_view()
+            dx = x.grad_view()
+            ctx.call("vinet_upsample2x_bwd", C.byref(dy.ct()), C.byref(dx.ct()), dx.dt, 1 if x.is_grad_ready() else 0, ctx.stream)
+            x.mark_grad_ready()
+        ctx.record(bwd)
+    return dst
+
+
+# ----------------------------------------------------------------------------
+# autograd entry point: one node per root module call
+# ----------------------------------------------------------------------------
+
+class _TapeFn(torch.autograd.Function):
+    """Runs `body.run` on the engine.  Forward records the tape; backward seeds
+    the output gradients, replays the tape (which accumulates parameter
+    gradients straight into `.grad`) and returns the input gradients."""
+
+    @staticmethod
+    def forward(fctx, body, n_in, *tensors):
+        inputs = tensors[:n_in]
+        ectx = body.make_ctx(inputs[0].device, record=True)
+        outs, state = body.run(ectx, inputs, [t.requires_grad for t in inputs])
+        fctx.body, fctx.ectx, fctx.state, fctx.n_par = body, ectx, state, len(tensors) - n_in
+        return tuple(outs)
+
+    @staticmethod
+    def backward(fctx, *gouts):
+        ectx = fctx.ectx
+        ectx.stream = _stream_for(ectx.device)
+        gin = fctx.body.seed(ectx, fctx.state, gouts)
+        return (None, None) + tuple(gin) + (None,) * fctx.n_par
+
+
+def run_root(body, inputs, params):
+    """Dispatch a root module call: one autograd node when gradients are wanted,
+    a plain engine call otherwise.  Returns a tuple of output tensors."""
+    want = torch.is_grad_enabled() and (any(t.requires_grad for t in inputs) or any(p.requires_grad for p in params))
+    if want:
+        # parameters are passed so autograd sees the dependency; their gradients
+        # are accumulated into `.grad` by the tape itself
+        return _TapeFn.apply(body, len(inputs), *inputs, *[p for p in params if p.requires_grad])
+    ectx = body.make_ctx(inputs[0].device, record=False)
+    outs, _ = body.run(ectx, inputs, [False] * len(inputs))
+    return tuple(outs)
+
+
+class BlockBody:
+    """root wrapper for modules mapping NCDHW fp32 tensors to NCDHW fp32 tensors
+    (BasicConv3d, SepConv3d, Mixed_*, BackBoneS3D, decoders used standalone)."""
+
+    def __init__(self, module, fwd, cpad=None):
+        self.module, self.fwd, self.cpad = module, fwd, cpad
+
+    def make_ctx(self, device, record):
+        return Ctx(device, getattr(self.module, "compute_dtype", None), self.module.training, record)
+
+    def run(self, ectx, inputs, req):
+        acts = [import_ncdhw(ectx, t, self.cpad, needs_grad=r) for t, r in zip(inputs, req)]
+        outs = self.fwd(ectx, *acts)
+        outs = list(outs) if isinstance(outs, (list, tuple)) else [outs]
+        tens = [export_ncdhw(ectx, o, self.out_channels(o)) for o in outs]
+        return tens, (acts, outs, [t.shape[1] for t in inputs])
+
+    @staticmethod
+    def out_channels(o):
+        return o.v.C
+
+    def seed(self, ectx, state, gouts):
+        acts, outs, cin = state
+        for o, g in zip(outs, gouts):
+            import_grad_ncdhw(ectx, o, g)
+        ectx.run_backward()
+        return [export_grad_ncdhw(ectx, a, c) if (a.needs_grad and a.is_grad_ready()) else None for a, c in zip(acts, cin)]

@@ -1,0 +1,319 @@
+"""ViNet / AViNet on MI355X -- drop-in for the reference's model.py.
+
+`VideoSaliencyModel(...)(x[B,3,T,H,W]) -> [B,H,W]` and
+`VideoAudioSaliencyModel(...)(x, audio[B,1,L,1]) -> [B,H,W]` keep the reference's
+constructor signatures, attribute names (`backbone`, `decoder`, `visual_model`,
+`audionet`, `maxpool`, `bilinear`) and state_dict keys (model.py:72-112, 191-249),
+so `load_state_dict(torch.load(ckpt))`, `train.py` and `generate_result*.py`
+work unchanged.  All device work runs in libvinet_hip.so via vinet_amd.engine.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import engine as E
+from .model_utils import (BasicConv3d, BNParams2d, ConvParams, Mixed_3b, Mixed_3c, Mixed_4b, Mixed_4c, Mixed_4d,
+                          Mixed_4e, Mixed_4f, Mixed_5b, Mixed_5c, SepConv3d, _Block, _Marker)
+
+
+def _pool_marker(k, s, p):
+    return _Marker("maxpool3d", kernel_size=k, stride=s, padding=p)
+
+
+class BackBoneS3D(_Block):
+    """S3D encoder, model.py:690-743.  Returns [y0, y1, y2, y3]."""
+    _cpad = 4
+
+    def __init__(self):
+        super().__init__()
+        self.base1 = nn.Sequential(
+            SepConv3d(3, 64, kernel_size=7, stride=2, padding=3),
+            _pool_marker((1, 3, 3), (1, 2, 2), (0, 1, 1)),
+            BasicConv3d(64, 64, kernel_size=1, stride=1),
+            SepConv3d(64, 192, kernel_size=3, stride=1, padding=1),
+        )
+        self.maxp2 = _pool_marker((1, 3, 3), (1, 2, 2), (0, 1, 1))
+        self.base2 = nn.Sequential(Mixed_3b(), Mixed_3c())
+        self.maxp3 = _pool_marker((3, 3, 3), (2, 2, 2), (1, 1, 1))
+        self.base3 = nn.Sequential(Mixed_4b(), Mixed_4c(), Mixed_4d(), Mixed_4e(), Mixed_4f())
+        self.maxt4 = _pool_marker((2, 1, 1), (2, 1, 1), (0, 0, 0))
+        self.maxp4 = _pool_marker((1, 2, 2), (1, 2, 2), (0, 0, 0))
+        self.base4 = nn.Sequential(Mixed_5b(), Mixed_5c())
+
+    def _fwd(self, ctx, x):
+        y = self.base1[0]._fwd(ctx, x)
+        y = E.maxpool_forward(ctx, y, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        y = self.base1[2]._fwd(ctx, y)
+        y3 = self.base1[3]._fwd(ctx, y)
+        y = E.maxpool_forward(ctx, y3, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        y2 = self.base2[1]._fwd(ctx, self.base2[0]._fwd(ctx, y))
+        y = E.maxpool_forward(ctx, y2, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+        for blk in self.base3:
+            y = blk._fwd(ctx, y)
+        y1 = y
+        y = E.maxpool_forward(ctx, y1, (2, 1, 1), (2, 1, 1), (0, 0, 0))
+        y = E.maxpool_forward(ctx, y, (1, 2, 2), (1, 2, 2), (0, 0, 0))
+        y0 = self.base4[1]._fwd(ctx, self.base4[0]._fwd(ctx, y))
+        return [y0, y1, y2, y3]
+
+
+# tail of convtsp4 per clip length (model.py:277-283 / 339-346 / 401-408 / 463-469):
+#   k5   = temporal kernel (= stride) of the 64->32 conv
+#   tail = convs after the last upsample: (cin, cout, kT, bias); "relu" between them
+DECODER_TAILS = {
+    32: dict(k5=2, tail=[(32, 32, 2, False), "relu", (32, 1, 1, True)]),
+    16: dict(k5=2, tail=[(32, 1, 1, True)]),
+    8: dict(k5=1, tail=[(32, 1, 1, True)]),
+    48: dict(k5=2, tail=[(32, 32, 3, True), "relu", (32, 1, 1, True)]),
+}
+
+
+class _DecoderConvUp(nn.Module):
+    """Hierarchical decoder, model.py:251-498.  The T-concats with the skip
+    connections (model.py:290,296,302) are buffers the upsample kernel and the
+    skip's BN-apply kernel write into side by side; the following conv's T stride
+    equals its T kernel, so its windows straddle the seam exactly as in the reference."""
+    _clips = 32
+
+    def __init__(self):
+        super().__init__()
+        spec = DECODER_TAILS[self._clips]
+        self.upsampling = _Marker("upsample", scale_factor=(1, 2, 2), mode="trilinear")
+
+        def stage(cin, cout, kt):
+            return [ConvParams(cin, cout, kernel_size=(kt, 3, 3), stride=(kt, 1, 1), padding=(0, 1, 1), bias=False),
+                    _Marker("relu"), self.upsampling]
+
+        self.convtsp1 = nn.Sequential(*stage(1024, 832, 1))
+        self.convtsp2 = nn.Sequential(*stage(832, 480, 3))
+        self.convtsp3 = nn.Sequential(*stage(480, 192, 5))
+        tail = []
+        for item in spec["tail"]:
+            if item == "relu":
+                tail.append(_Marker("relu"))
+            else:
+                cin, cout, kt, bias = item
+                tail.append(ConvParams(cin, cout, kernel_size=(kt, 1, 1), stride=(kt, 1, 1), bias=bias))
+        self.convtsp4 = nn.Sequential(*stage(192, 64, 5), *stage(64, 32, spec["k5"]), *tail, _Marker("sigmoid"))
+
+    # -- engine forward: returns the channel-padded fp32 head Act [B,1,H,W,Np] ----
+    def _conv_relu_up(self, ctx, conv, x, skip=None):
+        z = E.conv_forward(ctx, conv.plan(), x, act=L.ACT_RELU)
+        zv = z.v
+        if skip is None:
+            return E.upsample2x_forward(ctx, z)
+        sv = skip.v
+        assert (sv.H, sv.W, sv.C) == (2 * zv.H, 2 * zv.W, zv.C), "skip connection shape mismatch"
+        cat = E.Act(E.View.alloc(zv.B, zv.T + sv.T, sv.H, sv.W, zv.C, ctx.dt, ctx.device), needs_grad=True)
+        E.upsample2x_forward(ctx, z, cat.sub_t(0, zv.T))
+        E.materialize(ctx, skip, cat.sub_t(zv.T, zv.T + sv.T))
+        return cat
+
+    def _fwd(self, ctx, y0, y1, y2, y3):
+        z = self._conv_relu_up(ctx, self.convtsp1[0], y0, y1)
+        z = self._conv_relu_up(ctx, self.convtsp2[0], z, y2)
+        z = self._conv_relu_up(ctx, self.convtsp3[0], z, y3)
+        z = self._conv_relu_up(ctx, self.convtsp4[0], z)
+        z = self._conv_relu_up(ctx, self.convtsp4[3], z)
+        convs = [m for m in list(self.convtsp4)[6:] if isinstance(m, ConvParams)]
+        for conv in convs[:-1]:
+            z = E.conv_forward(ctx, conv.plan(), z, act=L.ACT_RELU)
+        head = convs[-1]
+        npad = E.rup(head.out_channels, E.EG[ctx.dt])
+        return E.conv_forward(ctx, head.plan(), z, act=L.ACT_SIGMOID, out_dt=E.F32, n_pad=npad)
+
+    def forward(self, y0, y1, y2, y3):
+        body = _MapBody(self, lambda ctx, *a: self._fwd(ctx, *a), n_feature_inputs=4)
+        return E.run_root(body, [y0, y1, y2, y3], list(self.parameters()))[0]
+
+
+class DecoderConvUp(_DecoderConvUp):
+    _clips = 32
+
+
+class DecoderConvUp16(_DecoderConvUp):
+    _clips = 16
+
+
+class DecoderConvUp8(_DecoderConvUp):
+    _clips = 8
+
+
+class DecoderConvUp48(_DecoderConvUp):
+    _clips = 48
+
+
+class _MapBody:
+    """root wrapper for callables that end in the decoder head: NCDHW fp32 inputs
+    (video clip and/or feature maps, audio) -> saliency map [B,H,W] fp32."""
+
+    def __init__(self, module, fwd, n_feature_inputs=0, video=False, audio=False):
+        self.module, self.fwd = module, fwd
+        self.video, self.audio, self.nfeat = video, audio, n_feature_inputs
+
+    def make_ctx(self, device, record):
+        return E.Ctx(device, getattr(self.module, "compute_dtype", None), self.module.training, record)
+
+    def run(self, ectx, inputs, req):
+        acts = []
+        for i, (t, r) in enumerate(zip(inputs, req)):
+            if self.video and i == 0:
+                acts.append(E.import_ncdhw(ectx, t, 4, needs_grad=r))
+            elif self.audio and i == len(inputs) - 1:
+                # [B,1,L,1] waveform -> [B, T=L, 1, 1, Cpad]
+                acts.append(E.import_ncdhw(ectx, t.unsqueeze(-1), None, needs_grad=r))
+            else:
+                acts.append(E.import_ncdhw(ectx, t, None, needs_grad=r))
+        head = self.fwd(ectx, *acts)
+        hv = head.v
+        assert hv.T == 1 and hv.dt == E.F32
+        planes = torch.empty((hv.C, hv.B, hv.H, hv.W), dtype=torch.float32, device=hv.device)
+        ectx.call("vinet_export_ncdhw", C.byref(hv.ct()), hv.dt, L.CAffine(None, None, 0), planes.data_ptr(),
+                  hv.H * hv.W, hv.B * hv.H * hv.W, 0, hv.W, 1, 0, ectx.stream)
+        return [planes[0]], (acts, head, [t.shape[1] for t in inputs])
+
+    def seed(self, ectx, state, gouts):
+        acts, head, cin = state
+        g = gouts[0]
+        if g.dtype != torch.float32:
+            g = g.float()
+        gv = head.grad_view()
+        ectx.call("vinet_import_ncdhw", g.data_ptr(), g.stride(0), 0, 0, g.stride(1), g.stride(2), 1, C.byref(gv.ct()),
+                  gv.dt, ectx.stream)
+        head.mark_grad_ready()
+        ectx.run_backward()
+        outs = []
+        for i, (a, c) in enumerate(zip(acts, cin)):
+            if a.needs_grad and a.is_grad_ready():
+                gt = E.export_grad_ncdhw(ectx, a, c)
+                if self.audio and i == len(acts) - 1:
+                    gt = gt.squeeze(-1)
+                outs.append(gt)
+            else:
+                outs.append(None)
+        return outs
+
+
+class VideoSaliencyModel(nn.Module):
+    """model.py:72-112 (use_upsample=True, num_hier=3; the ablation decoders and the
+    undefined DecoderConvT are out of scope)."""
+    compute_dtype = None
+
+    def __init__(self, transformer_in_channel=32, nhead=4, use_upsample=True, num_hier=3, num_clips=32):
+        super().__init__()
+        if not use_upsample or num_hier != 3 or num_clips not in DECODER_TAILS:
+            raise NotImplementedError("vinet_amd implements use_upsample=True, num_hier=3, num_clips in {8,16,32,48}")
+        self.backbone = BackBoneS3D()
+        self.num_hier = num_hier
+        self.decoder = {8: DecoderConvUp8, 16: DecoderConvUp16, 32: DecoderConvUp, 48: DecoderConvUp48}[num_clips]()
+
+    def _fwd(self, ctx, x):
+        y0, y1, y2, y3 = self.backbone._fwd(ctx, x)
+        return self.decoder._fwd(ctx, y0, y1, y2, y3)
+
+    def forward(self, x):
+        body = _MapBody(self, self._fwd, video=True)
+        return E.run_root(body, [x], list(self.parameters()))[0]
+
+
+# --------------------------------------------------------------------------
+# audio branch (model.py:746-825, 191-249)
+# --------------------------------------------------------------------------
+
+# (cin, cout, k, pad, pool) per SoundNet layer; stride is always (2, 1)
+SOUNDNET_LAYERS = [(1, 16, 64, 32, 8), (16, 32, 32, 16, 8), (32, 64, 16, 8, 0), (64, 128, 8, 4, 0),
+                   (128, 256, 4, 2, 4), (256, 512, 4, 2, 0), (512, 1024, 4, 2, 0)]
+
+
+class _Conv2dParams(nn.Conv2d):
+    """(k,1) Conv2d parameter holder; runs as a (k,1,1) conv with the waveform axis as T."""
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("parameters only")
+
+    def plan(self):
+        p = self.__dict__.get("_vinet_plan")
+        if p is None or p.weight is not self.weight or p.bias is not self.bias:
+            # [N, Cin, k, 1] has the same flat layout as [N, Cin, k, 1, 1]
+            p = _Conv2dPlan(self)
+            self.__dict__["_vinet_plan"] = p
+        return p
+
+
+class _Conv2dPlan(E.ConvPlan):
+    def __init__(self, conv):
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        super().__init__(conv.weight, conv.bias, (k, 1, 1), (s, 1, 1), (p, 0, 0))
+
+
+class SoundNet(nn.Module):
+    """model.py:746-825: seven (k,1)/stride-2 convs + BN2d + ReLU with three max-pools
+    on a raw waveform [B,1,L,1] -> [B,1024,3,1].  conv8_objs / conv8_scns exist in
+    the checkpoint but are never used in forward (model.py:788-791)."""
+    compute_dtype = None
+
+    def __init__(self):
+        super().__init__()
+        for i, (cin, cout, k, p, pool) in enumerate(SOUNDNET_LAYERS, 1):
+            setattr(self, "conv%d" % i, _Conv2dParams(cin, cout, kernel_size=(k, 1), stride=(2, 1), padding=(p, 0)))
+            setattr(self, "batchnorm%d" % i, BNParams2d(cout, eps=1e-5, momentum=0.1))
+            setattr(self, "relu%d" % i, _Marker("relu"))
+            if pool:
+                setattr(self, "maxpool%d" % i, _Marker("maxpool2d", kernel_size=(pool, 1), stride=(pool, 1)))
+        self.conv8_objs = _Conv2dParams(1024, 1000, kernel_size=(8, 1), stride=(2, 1))
+        self.conv8_scns = _Conv2dParams(1024, 401, kernel_size=(8, 1), stride=(2, 1))
+
+    def _fwd(self, ctx, x):
+        for i, (_, _, _, _, pool) in enumerate(SOUNDNET_LAYERS, 1):
+            conv, bn = getattr(self, "conv%d" % i), getattr(self, "batchnorm%d" % i)
+            x = E.conv_forward(ctx, conv.plan(), x, bn=bn.state(), act=L.ACT_RELU)
+            if ctx.training:
+                bn.note_training_step()
+            if pool:
+                x = E.maxpool_forward(ctx, x, (pool, 1, 1), (pool, 1, 1), (0, 0, 0))
+        return x
+
+    def forward(self, waveform):
+        body = E.BlockBody(self, self._fwd)
+        out = E.run_root(body, [waveform.unsqueeze(-1)], list(self.parameters()))[0]
+        return out.squeeze(-1)
+
+
+class VideoAudioSaliencyModel(nn.Module):
+    """model.py:191-249, use_transformer=False.  Unlike the reference the SoundNet
+    weights are not read from ./soundnet8_final.pth inside the constructor
+    (model.py:224); call `load_soundnet(path)` or load a full state_dict."""
+    compute_dtype = None
+
+    def __init__(self, use_transformer=False, transformer_in_channel=32, num_encoder_layers=3, nhead=4,
+                 use_upsample=True, num_hier=3, num_clips=32):
+        super().__init__()
+        if use_transformer:
+            raise NotImplementedError("transformer fusion is out of scope (SURVEY.md section 2)")
+        self.use_transformer = False
+        self.visual_model = VideoSaliencyModel(transformer_in_channel, nhead, use_upsample, num_hier, num_clips)
+        self.audionet = SoundNet()
+        self.maxpool = _Marker("maxpool3d", kernel_size=(4, 1, 1), stride=(2, 1, 2), padding=(0, 0, 0))
+        self.bilinear = _BilinearParams(42, 3, 4 * 7 * 12)
+
+    def load_soundnet(self, path="./soundnet8_final.pth"):
+        self.audionet.load_state_dict(torch.load(path, map_location="cpu"))
+
+    def _fwd(self, ctx, x, audio):
+        from .fusion import bilinear_forward
+        a = self.audionet._fwd(ctx, audio)                               # [B, 3, 1, 1, 1024]
+        y0, y1, y2, y3 = self.visual_model.backbone._fwd(ctx, x)
+        y0 = E.maxpool_forward(ctx, y0, (4, 1, 1), (2, 1, 2), (0, 0, 0))  # [B, 1, 7, 6, 1024]
+        fused = bilinear_forward(ctx, self.bilinear, y0, a, (4, 7, 12))
+        return self.visual_model.decoder._fwd(ctx, fused, y1, y2, y3)
+
+    def forward(self, x, audio):
+        body = _MapBody(self, self._fwd, video=True, audio=True)
+        return E.run_root(body, [x, audio], list(self.parameters()))[0]
+
+
+class _BilinearParams(nn.Bilinear):
+    def forward(self, a, b):  # pragma: no cover
+        raise RuntimeError("parameters only")
