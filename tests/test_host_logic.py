@@ -186,4 +186,6 @@ def test_train_step_matches_reference():
     assert float(loss1) < float(loss0) - 0.2
     sd = m.state_dict()
     for k in [n for n in z.files if n.startswith("state:")]:
-        _close(sd[k[6:]], z[k], 2e-4)
+        # base4 statistics come from 12 samples/channel on weights that already took one
+        # sign-descent step: only the large-M stem statistics are tight
+        _close(sd[k[6:]], z[k], 5e-5 if "base1" in k else 2e-3)
