@@ -1,0 +1,168 @@
+"""Model-level parity cases shared by the CPU host-logic tests (C ABI served by
+tests/abi_emulator.py) and the GPU parity tests (real libvinet_hip.so).  Every
+case compares vinet_amd against golden vectors captured from the reference."""
+import json
+
+import numpy as np
+import torch
+
+from oracle import vinet_cpu as O
+from tests import goldens as G
+from vinet_amd import engine as E
+from vinet_amd import synth
+
+
+def close(a, b, tol, what=""):
+    a, b = torch.as_tensor(a).detach().cpu(), torch.as_tensor(b).detach().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    d = float((a.double() - b.double()).abs().max())
+    assert d <= tol, "%s: max abs diff %g > %g" % (what, d, tol)
+    return d
+
+
+def blocks():
+    from vinet_amd import model_utils as MU
+    return {
+        "basic_16_32": lambda: MU.BasicConv3d(16, 32, 1, 1),
+        "sep_16_32_k3": lambda: MU.SepConv3d(16, 32, 3, 1, 1),
+        "sep_3_64_k7s2": lambda: MU.SepConv3d(3, 64, 7, 2, 3),
+        "mixed_3b": lambda: MU.Mixed_3b(),
+    }
+
+
+def block_case(name, mode, dev, ftol=2e-5, gtol=2e-4):
+    z, meta = G.load("block_" + name)
+    m = blocks()[name]()
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), meta["seed"]))
+    m = m.to(dev)
+    m.train(mode == "train")
+    x = synth.normal("x_" + name, tuple(meta["in_shape"]), meta["seed"]).to(dev).requires_grad_(True)
+    y = m(x)
+    close(y, z[mode + "_y"], ftol * max(1.0, float(np.abs(z[mode + "_y"]).max())), name + " y")
+    proj = synth.normal("proj_" + name, tuple(y.shape), meta["seed"]).to(dev)
+    (y * proj).sum().backward()
+    close(x.grad, z[mode + "_gx"], gtol * max(1.0, float(np.abs(z[mode + "_gx"]).max())), name + " gx")
+    for k, p in m.named_parameters():
+        ref = torch.as_tensor(z[mode + "_g:" + k])
+        close(p.grad, ref, gtol * max(1.0, float(ref.abs().max())), name + " grad " + k)
+    if mode == "train":
+        for k, v in m.state_dict().items():
+            if "running" in k:
+                close(v, z["train_stat:" + k], max(1e-5, ftol), name + " " + k)
+
+
+def losses_case(dev, vtol=2e-6, gtol=1e-7):
+    from vinet_amd import loss as VL
+    z, meta = G.load("loss")
+    for tag, (B, H, W) in {"full": (2, 224, 384), "small": (3, 40, 56)}.items():
+        s = synth.uniform("loss_s_" + tag, (B, H, W), meta["seed"], 0.01, 0.99).to(dev)
+        g = synth.gt_map(B, H, W, meta["seed"]).to(dev)
+        for fn in ("kldiv", "cc", "similarity"):
+            si = s.clone().requires_grad_(True)
+            v = getattr(VL, fn)(si, g)
+            v.backward()
+            close(v, z["%s_%s" % (tag, fn)], vtol, "%s %s" % (tag, fn))
+            if tag == "small":
+                close(si.grad, z["small_%s_grad" % fn], gtol, "%s grad" % fn)
+            else:
+                st = z["full_%s_gradstats" % fn]
+                gd = si.grad.double().cpu()
+                assert abs(float((gd * gd).sum()) - st[1]) <= 1e-4 * st[1]
+        v64 = VL.kldiv(s, g.double())
+        assert v64.dtype == torch.float64
+        assert abs(float(v64) - float(z["%s_kldiv_gt64" % tag])) < 1e-6
+
+
+def decoder8_case(dev, ftol=2e-5, gtol=3e-4):
+    from vinet_amd import model as VM
+    z, meta = G.load("decoder8")
+    m = VM.DecoderConvUp8()
+    m.load_state_dict(G.state_dict_for(m, meta["seed"], z, meta))
+    m = m.to(dev)
+    ys = [synth.normal("dec_y%d" % i, tuple(s), meta["seed"]).abs().to(dev).requires_grad_(True) for i, s in enumerate(meta["shapes"])]
+    o = m(*ys)
+    close(o, z["out"], ftol, "decoder out")
+    proj = synth.normal("dec_proj", tuple(o.shape), meta["seed"]).to(dev)
+    (o * proj).sum().backward()
+    for i in (0, 1):
+        ref = z["gy%d" % i]
+        close(ys[i].grad, ref, gtol * max(1.0, float(np.abs(ref).max())), "gy%d" % i)
+    for i in (2, 3):
+        ref = z["gy%d_head" % i]
+        close(ys[i].grad.reshape(-1)[:4096], ref, gtol * max(1.0, float(np.abs(ref).max())), "gy%d" % i)
+    for k, p in m.named_parameters():
+        ref = z["gp_head:" + k]
+        close(p.grad.reshape(-1)[:2048], ref, gtol * max(1.0, float(np.abs(ref).max())), "decoder grad " + k)
+
+
+def e2e_case(tag, dev, tol=1e-4, argmax=True):
+    """forward parity on the float map (north_star: 1e-3 abs) and bit-exact argmax."""
+    from vinet_amd import model as VM
+    z, meta = G.load("e2e_" + tag)
+    m = VM.VideoSaliencyModel(num_clips=meta["clips"]).eval()
+    m.load_state_dict(G.state_dict_for(m, meta["weight_seed"], z, meta))
+    m = m.to(dev)
+    x = synth.clip(1, meta["clips"], meta["H"], meta["W"], meta["clip_seed"]).to(dev).permute(0, 2, 1, 3, 4)
+    with torch.no_grad():
+        y = m(x)
+    assert y.shape == (1, meta["H"], meta["W"])
+    d = close(y, z["y"], tol, "e2e " + tag)
+    if argmax:
+        assert int(y.reshape(-1).argmax()) == meta["argmax"], "argmax differs (top-2 gap %g)" % meta["top2_gap"]
+    return d, meta
+
+
+def train_step_case(dev, make_optimizer=None):
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    from vinet_amd import optim as VO
+    z, meta = G.load("train_step")
+    B, T, H, W = meta["B"], meta["T"], meta["H"], meta["W"]
+    x = synth.clip(B, T, H, W, meta["seed"]).permute(0, 2, 1, 3, 4)
+    gt = synth.gt_map(B, H, W, meta["seed"])
+    m = VM.VideoSaliencyModel(num_clips=8)
+    m.load_state_dict(G.state_dict_for(m, meta["seed"], z, meta))
+    m = m.to(dev).train()
+    xd, gd = x.to(dev), gt.to(dev)
+    opt = (make_optimizer or VO.Adam)([p for p in m.parameters() if p.requires_grad], lr=meta["lr"])
+    opt.zero_grad()
+    pred = m(xd)
+    loss0 = VL.kldiv(pred, gd)
+    loss0.backward()
+    close(pred, z["pred"], 2e-5, "train pred")
+    close(loss0, z["loss0"], 1e-5, "train loss0")
+    # Gradients: with B=2 the deepest BatchNorms see 12 samples per channel and the
+    # reference's own fp32 gradients sit ~1.5e-2 (relative) from the fp64 truth there.
+    # Criterion: we must be as close to the fp64 oracle as the fp32 reference is.
+    params = dict(m.named_parameters())
+    truth, ref32 = {}, {}
+    for dt, store in ((torch.float64, truth), (torch.float32, ref32)):
+        o = O.VideoSaliencyModel(num_clips=8)
+        o.load_state_dict(G.state_dict_for(o, meta["seed"], z, meta))
+        o = o.to(dt).train()
+        O.kldiv(o(x.to(dt)), gt.to(dt)).backward()
+        store.update({k: p.grad.double() for k, p in o.named_parameters()})
+    worst = 0.0
+    for k, p in params.items():
+        t = truth[k]
+        e_ref = float((ref32[k] - t).norm() / (t.norm() + 1e-30))
+        e_me = float((p.grad.double().cpu() - t).norm() / (t.norm() + 1e-30))
+        assert e_me <= 3.0 * e_ref + 2e-4, "%s: rel err %.3e vs reference-fp32 %.3e" % (k, e_me, e_ref)
+        worst = max(worst, e_me)
+    assert worst < 5e-2
+    names = json.loads(str(z["grad_names"]))
+    gq = np.array([float((params[k].grad.double() ** 2).sum()) for k in names])
+    np.testing.assert_allclose(gq, z["grad_sqsum"], rtol=8e-2, atol=1e-12)
+    opt.step()
+    with torch.no_grad():
+        loss1 = VL.kldiv(m(xd), gd)      # train-mode forward: second running-stat update, as in the fixture
+    # Adam's first step is sign descent (m/sqrt(v) = +-1): fp32-noise-level gradient
+    # entries flip sign between implementations, so loss1 agrees to ~1e-3, not 1e-5
+    close(loss1, z["loss1"], 3e-3, "train loss1")
+    assert float(loss1) < float(loss0) - 0.2
+    sd = m.state_dict()
+    for k in [n for n in z.files if n.startswith("state:")]:
+        # base4 statistics come from 12 samples/channel on weights that already took one
+        # sign-descent step: only the large-M stem statistics are tight
+        close(sd[k[6:]], z[k], 5e-5 if "base1" in k else 2e-3, k)
+    return worst

@@ -1,0 +1,532 @@
+"""Every C-ABI entry point of libvinet_hip.so on a real MI355X against the CPU
+model of the same contract (tests/abi_emulator.py), on identical descriptors and
+seeded inputs.  fp32 must agree to fp32 round-off; bf16 to bf16 round-off."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.abi_emulator import AbiEmulator
+from vinet_amd import _lib as L
+from vinet_amd import engine as E
+from vinet_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DTS = [E.F32, E.BF16]
+TOL = {E.F32: 2e-5, E.BF16: 2e-2}
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _lib():
+    return L.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rand(name, shape, seed=0, scale=1.0):
+    return synth.normal(name, shape, seed) * scale
+
+
+class Pair:
+    """the same tensor on CPU (for the emulator) and on the GPU (for the library)."""
+
+    def __init__(self, t):
+        self.cpu = t.contiguous().clone()
+        self.gpu = self.cpu.to(_dev())
+
+    def ptr(self, side):
+        return (self.cpu if side == "cpu" else self.gpu).data_ptr()
+
+    def get(self, side):
+        return self.cpu if side == "cpu" else self.gpu.cpu()
+
+
+def view_pair(B, T, H, W, Cc, dt, name, seed=0, ld=None, c_off=0, t_total=None, t_off=0, fill=None):
+    """a View backed by a Pair; optionally a channel slice (ld > C) and/or T slice of a bigger buffer."""
+    ld = Cc if ld is None else ld
+    tt = T if t_total is None else t_total
+    n = B * tt * H * W * ld
+    base = _rand(name, (n,), seed) if fill is None else torch.full((n,), float(fill))
+    base = base.to(E.TORCH_DT[dt])
+    p = Pair(base)
+    off = t_off * H * W * ld + c_off
+
+    def mk(side):
+        buf = p.cpu if side == "cpu" else p.gpu
+        return E.View(buf, off, B, T, H, W, Cc, ld, tt * H * W * ld, dt)
+    return p, mk
+
+
+def fvec(name, n, seed=0, lo=None, hi=None):
+    t = _rand(name, (n,), seed) if lo is None else synth.uniform(name, (n,), seed, lo, hi)
+    return Pair(t.float())
+
+
+def _cmp(a, b, tol, what=""):
+    a, b = a.float(), b.float()
+    scale = max(1.0, float(b.abs().max()))
+    d = float((a - b).abs().max())
+    assert d <= tol * scale, "%s: max abs diff %g (scale %g) > %g" % (what, d, scale, tol * scale)
+
+
+def run_both(fn, make_args):
+    """make_args(side) -> args list.  Runs the emulator on CPU args and the library on GPU args."""
+    emu = AbiEmulator()
+    rc = getattr(emu, fn)(*make_args("cpu"))
+    assert rc == 0
+    lib = _lib()
+    rc = getattr(lib, fn)(*make_args("gpu"))
+    if rc != 0:
+        raise AssertionError("%s rc=%d: %s" % (fn, rc, lib.vinet_last_error().decode()))
+    torch.cuda.synchronize()
+
+
+# ----------------------------------------------------------------------------
+def test_library_loads_and_abi():
+    lib = _lib()
+    assert lib.vinet_abi_version() == L.ABI_VERSION
+
+
+def test_tr16_fragment_mapping():
+    """ds_read_tr16_b64: lane l must receive tile[k = (l>>4)*8 + j][i = l&15], j = 0..7."""
+    lib = _lib()
+    fn = lib.vinet_selftest_tr16
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+    out = torch.zeros(64 * 8, dtype=torch.int16, device=_dev())
+    assert fn(out.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().view(64, 8).numpy().astype(np.int64)
+    exp = np.array([[((l >> 4) * 8 + j) * 16 + (l & 15) for j in range(8)] for l in range(64)])
+    if not (got == exp).all():
+        bad = [(l, got[l].tolist(), exp[l].tolist()) for l in range(64) if (got[l] != exp[l]).any()][:6]
+        raise AssertionError("tr16 mapping differs, e.g. (lane, got, expected): %s" % bad)
+
+
+# ---- convolution ---------------------------------------------------------------
+CONV_CASES = [
+    # name, (B,T,H,W), Cin, N, k, s, p, extras
+    ("pw_192_64", (2, 3, 7, 9), 192, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), {}),
+    ("pw_pre_stats", (2, 3, 7, 9), 96, 48, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(pre=True, stats=True)),
+    ("sp_3x3", (1, 2, 9, 11), 32, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(pre=True)),
+    ("tm_3x1", (1, 5, 6, 7), 64, 208, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(stats=True)),
+    ("tm_7s2", (1, 9, 5, 6), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), dict(epi=True, act=1)),
+    ("dec_3x3x3", (2, 6, 5, 7), 64, 160, (3, 3, 3), (3, 1, 1), (0, 1, 1), dict(act=1)),
+    ("dec_5x3x3_bigK", (1, 5, 4, 6), 480, 192, (5, 3, 3), (5, 1, 1), (0, 1, 1), dict(act=1)),
+    ("small_n16", (1, 2, 8, 8), 192, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), {}),
+    ("cin24", (1, 2, 6, 6), 24, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(pre=True)),
+    ("wide_n384", (1, 1, 7, 12), 832, 384, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(stats=True)),
+    ("concat_slice_out", (1, 2, 6, 6), 64, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(out_ld=96, out_coff=32, stats=True)),
+    ("tslice_in", (2, 3, 5, 5), 32, 32, (3, 3, 3), (3, 1, 1), (0, 1, 1), dict(in_ttotal=5, in_toff=1)),
+    ("accumulate", (1, 2, 6, 6), 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(accumulate=True)),
+    ("head_pad", (2, 1, 8, 12), 32, 1, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(epi_shift=True, act=2, out_f32=True, head=True)),
+    ("big_m", (2, 4, 28, 48), 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(stats=True)),
+]
+
+
+def _fwd_taps(k, p):
+    return [(kt - p[0], kh - p[1], kw - p[2], (kt * k[1] + kh) * k[2] + kw)
+            for kt in range(k[0]) for kh in range(k[1]) for kw in range(k[2])]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d(case, dt):
+    name, (B, T, H, W), Cin, N, k, s, p, ex = case
+    oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
+    xp, xmk = view_pair(B, T, H, W, Cin, dt, "x" + name, 1, t_total=ex.get("in_ttotal"), t_off=ex.get("in_toff", 0))
+    head = ex.get("head", False)
+    Ny = (E.EG[dt] if head else N)
+    odt = E.F32 if ex.get("out_f32") else dt
+    yp, ymk = view_pair(B, oT, oH, oW, Ny, odt, "y" + name, 2, ld=ex.get("out_ld"), c_off=ex.get("out_coff", 0))
+    Kp = E.rup(Cin, 32)
+    ntaps = k[0] * k[1] * k[2]
+    wmaster = _rand("w" + name, (N, Cin, ntaps), 3, 1.0 / math.sqrt(Cin * ntaps))
+    wpk = torch.zeros(ntaps, N, Kp)
+    wpk[:, :, :Cin] = wmaster.permute(2, 0, 1)
+    wp = Pair(wpk.to(E.TORCH_DT[dt]))
+    taps = Pair(torch.tensor(_fwd_taps(k, p), dtype=torch.int32))
+    pre_s, pre_h = fvec("ps" + name, Cin, 4, 0.5, 1.5), fvec("ph" + name, Cin, 5)
+    os_, oh_ = fvec("os" + name, N, 6, 0.5, 1.5), fvec("oh" + name, N, 7)
+    M = B * oT * oH * oW
+    rows = (M + 63) // 64
+    stats = Pair(torch.zeros(rows * 2 * N))
+
+    def mk(side):
+        d = L.CConvDesc()
+        d.dtype, d.out_dtype, d.mode = dt, odt, 0
+        d.x, d.y = xmk(side).ct(), ymk(side).ct()
+        d.oT, d.oH, d.oW = oT, oH, oW
+        d.sT, d.sH, d.sW = s
+        d.omT = d.omH = d.omW = 1
+        d.ntaps, d.taps, d.w, d.Kp = ntaps, taps.ptr(side), wp.ptr(side), Kp
+        d.pre = L.CAffine(pre_s.ptr(side), pre_h.ptr(side), 1) if ex.get("pre") else L.CAffine(None, None, 0)
+        d.out_scale = os_.ptr(side) if ex.get("epi") else None
+        d.out_shift = oh_.ptr(side) if (ex.get("epi") or ex.get("epi_shift")) else None
+        d.act = ex.get("act", 0)
+        d.accumulate = 1 if ex.get("accumulate") else 0
+        d.stats = stats.ptr(side) if ex.get("stats") else None
+        d.n_valid = N if head else 0
+        return [C.byref(d), _stream() if side == "gpu" else 0]
+
+    run_both("vinet_conv3d", mk)
+    _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "conv " + name)
+    if ex.get("stats"):
+        d0 = mk("gpu")[0]._obj
+        bm = _lib().vinet_conv3d_tile_m(C.byref(d0))
+        assert bm == AbiEmulator().vinet_conv3d_tile_m(d0)
+        r = (M + bm - 1) // bm
+        sg = stats.get("gpu")[:r * 2 * N].view(r, 2, N).double().sum(0)
+        sc = stats.get("cpu")[:r * 2 * N].view(r, 2, N).double().sum(0)
+        _cmp(sg, sc, 1e-4 if dt == E.F32 else 2e-2, "conv stats " + name)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv3d_stem_mode(dt):
+    B, T, H, W, N = 2, 3, 18, 22, 64
+    oH, oW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    x = torch.zeros(B, T, H, W, 4)
+    x[..., :3] = _rand("stemx", (B, T, H, W, 3), 1)
+    xp = Pair(x.reshape(-1).to(E.TORCH_DT[dt]))
+    yp, ymk = view_pair(B, T, oH, oW, N, dt, "stemy", 2)
+    wm = _rand("stemw", (N, 3, 49), 3, 1.0 / math.sqrt(147))
+    wpk = torch.zeros(7, N, 32)
+    for kh in range(7):
+        for kw in range(7):
+            wpk[kh, :, kw * 4:kw * 4 + 3] = wm[:, :, kh * 7 + kw]
+    wp = Pair(wpk.to(E.TORCH_DT[dt]))
+    taps = Pair(torch.tensor([(0, kh - 3, -3, kh) for kh in range(7)], dtype=torch.int32))
+
+    def mk(side):
+        d = L.CConvDesc()
+        d.dtype, d.out_dtype, d.mode = dt, dt, 1
+        buf = xp.cpu if side == "cpu" else xp.gpu
+        d.x = E.View(buf, 0, B, T, H, W, 4, 4, T * H * W * 4, dt).ct()
+        d.y = ymk(side).ct()
+        d.oT, d.oH, d.oW = T, oH, oW
+        d.sT, d.sH, d.sW = 1, 2, 2
+        d.omT = d.omH = d.omW = 1
+        d.ntaps, d.taps, d.w, d.Kp = 7, taps.ptr(side), wp.ptr(side), 32
+        d.pre = L.CAffine(None, None, 0)
+        return [C.byref(d), _stream() if side == "gpu" else 0]
+
+    run_both("vinet_conv3d", mk)
+    _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "stem conv")
+    # and against torch's conv3d directly (fp32 only): the emulator itself is checked here
+    if dt == E.F32:
+        ref = torch.nn.functional.conv3d(x[..., :3].permute(0, 4, 1, 2, 3), wm.view(N, 3, 1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3))
+        _cmp(yp.get("gpu").view(B, T, oH, oW, N).permute(0, 4, 1, 2, 3), ref, 2e-5, "stem vs torch")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv3d_phase_output_mapping(dt):
+    """dgrad-style launch: iteration space Q, output written at o*om+oo into a larger tensor"""
+    B, Q, N, Cin = 1, (3, 4, 5), 32, 64
+    xp, xmk = view_pair(B, 3, 4, 5, Cin, dt, "phx", 1)
+    yp, ymk = view_pair(B, 6, 4, 10, N, dt, "phy", 2, fill=0.5)
+    Kp = 64
+    wp = Pair(_rand("phw", (2 * N * Kp,), 3, 0.1).to(E.TORCH_DT[dt]))
+    taps = Pair(torch.tensor([(0, 0, 0, 0), (1, 0, -1, 1)], dtype=torch.int32))
+
+    def mk(side):
+        d = L.CConvDesc()
+        d.dtype, d.out_dtype, d.mode = dt, dt, 0
+        d.x, d.y = xmk(side).ct(), ymk(side).ct()
+        d.oT, d.oH, d.oW = Q
+        d.sT = d.sH = d.sW = 1
+        d.omT, d.omH, d.omW = 2, 1, 2
+        d.ooT, d.ooH, d.ooW = 1, 0, 1
+        d.ntaps, d.taps, d.w, d.Kp = 2, taps.ptr(side), wp.ptr(side), Kp
+        d.pre = L.CAffine(None, None, 0)
+        d.accumulate = 1
+        return [C.byref(d), _stream() if side == "gpu" else 0]
+
+    run_both("vinet_conv3d", mk)
+    _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "phase mapping")
+
+
+WGRAD_CASES = [
+    ("pw", (2, 3, 7, 9), 96, 48, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),
+    ("sp3", (1, 2, 9, 11), 32, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), True),
+    ("t7s2", (1, 9, 5, 6), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), False),
+    ("dec", (2, 6, 5, 7), 64, 160, (3, 3, 3), (3, 1, 1), (0, 1, 1), True),
+    ("splitk", (2, 4, 28, 48), 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),
+    ("cin24_n208", (1, 2, 6, 6), 24, 208, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv3d_wgrad(case, dt):
+    name, (B, T, H, W), Cin, N, k, s, p, pre = case
+    oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
+    xp, xmk = view_pair(B, T, H, W, Cin, dt, "wx" + name, 1)
+    dp, dmk = view_pair(B, oT, oH, oW, N, dt, "wd" + name, 2)
+    ntaps = k[0] * k[1] * k[2]
+    Kp = E.rup(Cin, 32)
+    dw = Pair(torch.zeros(ntaps * N * Kp))
+    taps = Pair(torch.tensor(_fwd_taps(k, p), dtype=torch.int32))
+    ps, ph = fvec("wps" + name, Cin, 4, 0.5, 1.5), fvec("wph" + name, Cin, 5)
+
+    def mk(side):
+        d = L.CWgradDesc()
+        d.dtype, d.mode = dt, 0
+        d.x, d.dy = xmk(side).ct(), dmk(side).ct()
+        d.sT, d.sH, d.sW = s
+        d.ntaps, d.taps, d.dw, d.Kp = ntaps, taps.ptr(side), dw.ptr(side), Kp
+        d.pre = L.CAffine(ps.ptr(side), ph.ptr(side), 1) if pre else L.CAffine(None, None, 0)
+        return [C.byref(d), _stream() if side == "gpu" else 0]
+
+    run_both("vinet_conv3d_wgrad", mk)
+    _cmp(dw.get("gpu"), dw.get("cpu"), 3e-5 if dt == E.F32 else 2e-2, "wgrad " + name)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv3d_wgrad_stem(dt):
+    B, T, H, W, N = 1, 2, 18, 22, 64
+    oH, oW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    x = torch.zeros(B, T, H, W, 4)
+    x[..., :3] = _rand("wsx", (B, T, H, W, 3), 1)
+    xp = Pair(x.reshape(-1).to(E.TORCH_DT[dt]))
+    dp, dmk = view_pair(B, T, oH, oW, N, dt, "wsd", 2)
+    dw = Pair(torch.zeros(7 * N * 32))
+    taps = Pair(torch.tensor([(0, kh - 3, -3, kh) for kh in range(7)], dtype=torch.int32))
+
+    def mk(side):
+        d = L.CWgradDesc()
+        d.dtype, d.mode = dt, 1
+        buf = xp.cpu if side == "cpu" else xp.gpu
+        d.x = E.View(buf, 0, B, T, H, W, 4, 4, T * H * W * 4, dt).ct()
+        d.dy = dmk(side).ct()
+        d.sT, d.sH, d.sW = 1, 2, 2
+        d.ntaps, d.taps, d.dw, d.Kp = 7, taps.ptr(side), dw.ptr(side), 32
+        d.pre = L.CAffine(None, None, 0)
+        return [C.byref(d), _stream() if side == "gpu" else 0]
+
+    run_both("vinet_conv3d_wgrad", mk)
+    _cmp(dw.get("gpu"), dw.get("cpu"), 3e-5 if dt == E.F32 else 2e-2, "wgrad stem")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_pack_unpack(dt):
+    N, Cin, nt = 48, 24, 9
+    w = Pair(_rand("pw", (N * Cin * nt,), 1))
+    for transpose in (0, 1):
+        n = nt * (N if not transpose else Cin) * E.rup(Cin if not transpose else N, 32)
+        out = Pair(torch.zeros(n).to(E.TORCH_DT[dt]))
+        run_both("vinet_pack_weights", lambda s: [w.ptr(s), N, Cin, nt, transpose, 0, dt, out.ptr(s), _stream() if s == "gpu" else 0])
+        assert torch.equal(out.get("gpu"), out.get("cpu"))
+    ws = Pair(_rand("pws", (64 * 3 * 49,), 2))
+    outs = Pair(torch.zeros(7 * 64 * 32).to(E.TORCH_DT[dt]))
+    run_both("vinet_pack_weights", lambda s: [ws.ptr(s), 64, 3, 49, 0, 1, dt, outs.ptr(s), _stream() if s == "gpu" else 0])
+    assert torch.equal(outs.get("gpu"), outs.get("cpu"))
+    if dt == E.F32:
+        dw = Pair(_rand("udw", (nt * N * 32,), 3))
+        g = Pair(_rand("ug", (N * Cin * nt,), 4))
+        run_both("vinet_unpack_wgrad", lambda s: [dw.ptr(s), N, Cin, nt, 0, 1, g.ptr(s), _stream() if s == "gpu" else 0])
+        _cmp(g.get("gpu"), g.get("cpu"), 1e-6, "unpack")
+        dws = Pair(_rand("udws", (7 * 64 * 32,), 5))
+        gs = Pair(torch.zeros(64 * 3 * 49))
+        run_both("vinet_unpack_wgrad", lambda s: [dws.ptr(s), 64, 3, 49, 1, 0, gs.ptr(s), _stream() if s == "gpu" else 0])
+        _cmp(gs.get("gpu"), gs.get("cpu"), 1e-6, "unpack stem")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_import_export_copy(dt):
+    B, Cc, T, H, W = 2, 3, 4, 6, 10
+    base = _rand("imp", (B, T, Cc, H, W), 1)     # train.py hands over a permuted view of this
+    src = Pair(base)
+    sb, st, sc, sh, sw = base.stride()
+    dp, dmk = view_pair(B, T, H, W, 4, dt, "impd", 2)
+    run_both("vinet_import_ncdhw", lambda s: [src.ptr(s), sb, sc, st, sh, sw, Cc, C.byref(dmk(s).ct()), dt, _stream() if s == "gpu" else 0])
+    assert torch.equal(dp.get("gpu"), dp.get("cpu"))
+    got = dp.get("gpu").float().view(B, T, H, W, 4)
+    assert torch.equal(got[..., 3], torch.zeros_like(got[..., 3]))
+    _cmp(got[..., :3], base.permute(0, 1, 3, 4, 2).to(E.TORCH_DT[dt]).float(), 0.0, "import values")
+    # export with a pending affine
+    Cx = 16
+    xp, xmk = view_pair(B, T, H, W, Cx, dt, "expx", 3, ld=24, c_off=8)
+    sc_, sh_ = fvec("exps", Cx, 4, 0.5, 1.5), fvec("exph", Cx, 5)
+    out = Pair(torch.zeros(B, Cx, T, H, W))
+    osb, osc, ost, osh, osw = out.cpu.stride()
+    run_both("vinet_export_ncdhw", lambda s: [C.byref(xmk(s).ct()), dt, L.CAffine(sc_.ptr(s), sh_.ptr(s), 1), out.ptr(s), osb, osc, ost, osh, osw, 0, _stream() if s == "gpu" else 0])
+    _cmp(out.get("gpu"), out.get("cpu"), 1e-6, "export")
+    for odt in DTS:
+        yp, ymk = view_pair(B, T, H, W, Cx, odt, "cpy", 6, t_total=T + 2, t_off=1)
+        run_both("vinet_copy_affine", lambda s: [C.byref(xmk(s).ct()), dt, L.CAffine(sc_.ptr(s), sh_.ptr(s), 1), C.byref(ymk(s).ct()), odt, 1, _stream() if s == "gpu" else 0])
+        _cmp(yp.get("gpu"), yp.get("cpu"), 1e-6 if odt == E.F32 else 1e-2, "copy_affine")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("Cc", [16, 24, 64, 208, 528, 1024])
+def test_bn_kernels(dt, Cc):
+    B, T, H, W = 2, 3, 5, 7
+    xp, xmk = view_pair(B, T, H, W, Cc, dt, "bnx", 1)
+    gp, gmk = view_pair(B, T, H, W, Cc, dt, "bng", 2)
+    rows = AbiEmulator().vinet_stats_rows(xmk("cpu").ct())
+    assert _lib().vinet_stats_rows(C.byref(xmk("gpu").ct())) == rows
+    part = Pair(torch.zeros(rows * 2 * Cc))
+    run_both("vinet_channel_stats", lambda s: [C.byref(xmk(s).ct()), dt, part.ptr(s), _stream() if s == "gpu" else 0])
+    _cmp(part.get("gpu").view(rows, 2, Cc).double().sum(0), part.get("cpu").view(rows, 2, Cc).double().sum(0), 1e-5, "channel_stats")
+    # finalize
+    n = float(B * T * H * W)
+    gam, bet = fvec("g", Cc, 3, 0.5, 1.5), fvec("b", Cc, 4)
+    rm, rv = fvec("rm", Cc, 5), fvec("rv", Cc, 6, 0.5, 1.5)
+    mean, istd, sc, sh = [Pair(torch.zeros(Cc)) for _ in range(4)]
+    stats = Pair(part.cpu.clone())
+    run_both("vinet_bn_finalize", lambda s: [stats.ptr(s), rows, Cc, n, gam.ptr(s), bet.ptr(s), 1e-3, 0.001, rm.ptr(s), rv.ptr(s), mean.ptr(s), istd.ptr(s), sc.ptr(s), sh.ptr(s), _stream() if s == "gpu" else 0])
+    for a, nm in ((mean, "mean"), (istd, "invstd"), (sc, "scale"), (sh, "shift"), (rm, "rm"), (rv, "rv")):
+        _cmp(a.get("gpu"), a.get("cpu"), 2e-6, "bn_finalize " + nm)
+    # fold
+    fs, fh, fi = [Pair(torch.zeros(Cc)) for _ in range(3)]
+    cb = fvec("cb", Cc, 7)
+    run_both("vinet_bn_fold", lambda s: [gam.ptr(s), bet.ptr(s), rm.ptr(s), rv.ptr(s), cb.ptr(s), 1e-3, Cc, fs.ptr(s), fh.ptr(s), fi.ptr(s), _stream() if s == "gpu" else 0])
+    for a in (fs, fh, fi):
+        _cmp(a.get("gpu"), a.get("cpu"), 2e-6, "bn_fold")
+    # backward
+    aff = lambda s: L.CAffine(sc.ptr(s), sh.ptr(s), 1)
+    part2 = Pair(torch.zeros(rows * 2 * Cc))
+    run_both("vinet_bn_bwd_reduce", lambda s: [C.byref(gmk(s).ct()), C.byref(xmk(s).ct()), dt, aff(s), mean.ptr(s), istd.ptr(s), part2.ptr(s), _stream() if s == "gpu" else 0])
+    _cmp(part2.get("gpu").view(rows, 2, Cc).double().sum(0), part2.get("cpu").view(rows, 2, Cc).double().sum(0), 2e-5, "bn_bwd_reduce")
+    dg, db, c1, c2 = [Pair(torch.zeros(Cc)) for _ in range(4)]
+    p2 = Pair(part2.cpu.clone())
+    run_both("vinet_bn_bwd_finalize", lambda s: [p2.ptr(s), rows, Cc, n, sc.ptr(s), 1, dg.ptr(s), db.ptr(s), istd.ptr(s), c1.ptr(s), c2.ptr(s), _stream() if s == "gpu" else 0])
+    for a in (dg, db, c1, c2):
+        _cmp(a.get("gpu"), a.get("cpu"), 2e-6, "bn_bwd_finalize")
+    dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "bndx", 8)
+    run_both("vinet_bn_bwd_apply", lambda s: [C.byref(gmk(s).ct()), C.byref(xmk(s).ct()), dt, aff(s), mean.ptr(s), istd.ptr(s), c1.ptr(s), c2.ptr(s), C.byref(dxmk(s).ct()), _stream() if s == "gpu" else 0])
+    _cmp(dxp.get("gpu"), dxp.get("cpu"), 1e-5 if dt == E.F32 else 2e-2, "bn_bwd_apply")
+    # channel_sum with folding
+    out = Pair(torch.ones(Cc // 4))
+    ws = Pair(torch.zeros(rows * 2 * Cc))
+    run_both("vinet_channel_sum", lambda s: [C.byref(xmk(s).ct()), dt, ws.ptr(s), Cc // 4, out.ptr(s), 1, _stream() if s == "gpu" else 0])
+    _cmp(out.get("gpu"), out.get("cpu"), 2e-5, "channel_sum")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_act_bwd(dt):
+    B, T, H, W, Cc = 2, 2, 5, 6, 32
+    zp, zmk = view_pair(B, T, H, W, Cc, dt, "az", 1)
+    gp, gmk = view_pair(B, T, H, W, Cc, dt, "ag", 2)
+    for act in (1, 2):
+        yp, ymk = view_pair(B, T, H, W, Cc, dt, "ay", 3)
+        run_both("vinet_act_bwd", lambda s: [C.byref(gmk(s).ct()), dt, C.byref(zmk(s).ct()), dt, act, C.byref(ymk(s).ct()), dt, _stream() if s == "gpu" else 0])
+        _cmp(yp.get("gpu"), yp.get("cpu"), 1e-6 if dt == E.F32 else 1e-2, "act_bwd")
+    # mixed: fp32 dz and z (head), activation-dtype dy
+    zp, zmk = view_pair(1, 1, 1, 96, 4, E.F32, "az2", 4)
+    gp, gmk = view_pair(1, 1, 1, 96, 4, E.F32, "ag2", 5)
+    yp, ymk = view_pair(1, 1, 1, 96, 4, dt, "ay2", 6)
+    run_both("vinet_act_bwd", lambda s: [C.byref(gmk(s).ct()), E.F32, C.byref(zmk(s).ct()), E.F32, 2, C.byref(ymk(s).ct()), dt, _stream() if s == "gpu" else 0])
+    _cmp(yp.get("gpu"), yp.get("cpu"), 1e-6 if dt == E.F32 else 1e-2, "act_bwd mixed")
+
+
+POOLS = [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (1, 1, 1), (1, 1, 1)),
+         ((2, 1, 1), (2, 1, 1), (0, 0, 0)), ((1, 2, 2), (1, 2, 2), (0, 0, 0)), ((4, 1, 1), (2, 1, 2), (0, 0, 0)),
+         ((8, 1, 1), (8, 1, 1), (0, 0, 0))]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("ksp", POOLS, ids=[str(p[0]) + str(p[1]) for p in POOLS])
+def test_maxpool(dt, ksp):
+    k, s, p = ksp
+    B, T, H, W, Cc = 2, 8, 9, 10, 24
+    od = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
+    xp, xmk = view_pair(B, T, H, W, Cc, dt, "px", 1)
+    yp, ymk = view_pair(B, od[0], od[1], od[2], Cc, dt, "py", 2)
+    am = Pair(torch.zeros(B * od[0] * od[1] * od[2] * Cc, dtype=torch.uint8))
+    ps, ph = fvec("pps", Cc, 3, -1.5, 1.5), fvec("pph", Cc, 4)
+
+    def pd():
+        return L.CPoolDesc(dt, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
+    run_both("vinet_maxpool3d", lambda sd: [C.byref(pd()), C.byref(xmk(sd).ct()), L.CAffine(ps.ptr(sd), ph.ptr(sd), 1), C.byref(ymk(sd).ct()), am.ptr(sd), _stream() if sd == "gpu" else 0])
+    _cmp(yp.get("gpu"), yp.get("cpu"), 1e-6 if dt == E.F32 else 1e-2, "maxpool")
+    # ReLU creates ties at 0: indices may only differ where the pooled value is 0
+    diff = am.get("gpu") != am.get("cpu")
+    assert not bool((diff & (yp.get("cpu").float() != 0)).any())
+    gp, gmk = view_pair(B, od[0], od[1], od[2], Cc, dt, "pg", 5)
+    dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "pdx", 6)
+    amc = Pair(am.cpu.clone())
+    run_both("vinet_maxpool3d_bwd", lambda sd: [C.byref(pd()), C.byref(gmk(sd).ct()), amc.ptr(sd), C.byref(dxmk(sd).ct()), 1, _stream() if sd == "gpu" else 0])
+    _cmp(dxp.get("gpu"), dxp.get("cpu"), 1e-5 if dt == E.F32 else 2e-2, "maxpool bwd")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_upsample(dt):
+    B, T, H, W, Cc = 2, 3, 5, 7, 32
+    xp, xmk = view_pair(B, T, H, W, Cc, dt, "ux", 1)
+    yp, ymk = view_pair(B, T, 2 * H, 2 * W, Cc, dt, "uy", 2, t_total=T + 2, t_off=2)
+    run_both("vinet_upsample2x", lambda s: [C.byref(xmk(s).ct()), C.byref(ymk(s).ct()), dt, _stream() if s == "gpu" else 0])
+    _cmp(yp.get("gpu"), yp.get("cpu"), 1e-6 if dt == E.F32 else 1e-2, "upsample")
+    dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "udx", 3)
+    run_both("vinet_upsample2x_bwd", lambda s: [C.byref(ymk(s).ct()), C.byref(dxmk(s).ct()), dt, 1, _stream() if s == "gpu" else 0])
+    _cmp(dxp.get("gpu"), dxp.get("cpu"), 1e-5 if dt == E.F32 else 2e-2, "upsample bwd")
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+@pytest.mark.parametrize("g64", [0, 1])
+def test_losses(which, g64):
+    B, H, W = 3, 40, 56
+    s = Pair(synth.uniform("ls", (B, H, W), 1, 0.01, 0.99))
+    g = synth.gt_map(B, H, W, 2)
+    g = Pair(g.double() if g64 else g)
+    saved = Pair(torch.zeros(B * 8, dtype=torch.float64))
+    loss = Pair(torch.zeros(1))
+    run_both("vinet_loss_fwd", lambda sd: [which, s.ptr(sd), g.ptr(sd), g64, B, H * W, saved.ptr(sd), loss.ptr(sd), _stream() if sd == "gpu" else 0])
+    _cmp(loss.get("gpu"), loss.get("cpu"), 1e-6, "loss fwd")
+    gs = Pair(torch.tensor([0.7]))
+    ds = Pair(torch.zeros(B, H, W))
+    savedg = saved.gpu.clone()
+
+    def mk(sd):
+        sv = saved.cpu if sd == "cpu" else savedg
+        return [which, s.ptr(sd), g.ptr(sd), g64, B, H * W, sv.data_ptr(), gs.ptr(sd), -1.0, 0, ds.ptr(sd), _stream() if sd == "gpu" else 0]
+    run_both("vinet_loss_bwd", mk)
+    a, b = ds.get("gpu"), ds.get("cpu")
+    assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, "loss bwd %g vs scale %g" % (float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_adam_and_fill():
+    n = 10007
+    n4 = (n + 3) // 4 * 4
+    p, g = Pair(_rand("ap", (n4,), 1)), Pair(_rand("ag", (n4,), 2, 0.01))
+    m, v = Pair(torch.zeros(n4)), Pair(torch.zeros(n4))
+    for step in (1, 2, 3):
+        bc1, bc2 = 1 - 0.9 ** step, 1 - 0.999 ** step
+        run_both("vinet_adam_step", lambda s: [p.ptr(s), g.ptr(s), m.ptr(s), v.ptr(s), n, 1e-4, 0.9, 0.999, 1e-8, bc1, bc2, 1.0, _stream() if s == "gpu" else 0])
+    _cmp(p.get("gpu"), p.get("cpu"), 1e-6, "adam p")
+    # against torch.optim.Adam
+    tp = torch.nn.Parameter(_rand("ap", (n4,), 1)[:n].clone())
+    opt = torch.optim.Adam([tp], lr=1e-4)
+    for _ in range(3):
+        tp.grad = _rand("ag", (n4,), 2, 0.01)[:n].clone()
+        opt.step()
+    _cmp(p.get("gpu")[:n], tp.detach(), 1e-6, "adam vs torch")
+    f = Pair(torch.zeros(1000))
+    run_both("vinet_fill_f32", lambda s: [f.ptr(s), 1000, 3.5, _stream() if s == "gpu" else 0])
+    assert torch.equal(f.get("gpu"), f.get("cpu"))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_bilinear(dt):
+    B, Cc, I, J, O = 2, 64, 42, 3, 336
+    x1 = Pair(_rand("b1", (B * I * Cc,), 1).to(E.TORCH_DT[dt]))
+    x2 = Pair(_rand("b2", (B * J * Cc,), 2).to(E.TORCH_DT[dt]))
+    w, bias = Pair(_rand("bw", (O * I * J,), 3, 0.1)), Pair(_rand("bb", (O,), 4))
+    out = Pair(torch.zeros(B * O * Cc).to(E.TORCH_DT[dt]))
+    run_both("vinet_bilinear_fwd", lambda s: [x1.ptr(s), x2.ptr(s), dt, w.ptr(s), bias.ptr(s), B, Cc, I, J, O, out.ptr(s), _stream() if s == "gpu" else 0])
+    _cmp(out.get("gpu"), out.get("cpu"), 2e-5 if dt == E.F32 else 2e-2, "bilinear fwd")
+    do = Pair(_rand("bdo", (B * O * Cc,), 5).to(E.TORCH_DT[dt]))
+    d1 = Pair(torch.zeros(B * I * Cc).to(E.TORCH_DT[dt]))
+    d2 = Pair(torch.zeros(B * J * Cc).to(E.TORCH_DT[dt]))
+    dw, db = Pair(torch.zeros(O * I * J)), Pair(torch.zeros(O))
+    run_both("vinet_bilinear_bwd", lambda s: [x1.ptr(s), x2.ptr(s), do.ptr(s), dt, w.ptr(s), B, Cc, I, J, O, d1.ptr(s), d2.ptr(s), dw.ptr(s), db.ptr(s), _stream() if s == "gpu" else 0])
+    for a, nm in ((d1, "dx1"), (d2, "dx2"), (dw, "dw"), (db, "dbias")):
+        _cmp(a.get("gpu"), a.get("cpu"), 5e-5 if dt == E.F32 else 3e-2, "bilinear bwd " + nm)
