@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""ViNet training throughput on MI355X (BASELINE.json metric: clips/sec training,
+32x224x384 bf16, 1/2/4/8 GPUs).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = synthetic batch already in HBM -> forward -> kldiv -> backward ->
+(RCCL all-reduce of the flat gradient buffer when N > 1) -> fused Adam, all on the
+hand-written HIP kernels of libvinet_hip.so.  Weak scaling: the per-GPU batch is
+fixed.  Prints ONE JSON line on rank 0 with the roofline of the dominant kernel
+site (HIP events on the launch stream, measured inside the timed region) and the
+CPU baseline (PyTorch-CPU oracle on the box's host cores, rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
+# algorithmic work per clip at 32x224x384 (training)
+TRAIN_GFLOP_PER_CLIP = 675.0
+TRAIN_MB_PER_CLIP = 3014.7
+STEP_MB_PER_GPU = 1119.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step (train.py default global batch 8)")
+    ap.add_argument("--clip", type=int, default=32)
+    ap.add_argument("--height", type=int, default=224)
+    ap.add_argument("--width", type=int, default=384)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--profile-all", action="store_true", help="print the per-site HIP-event table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """the PyTorch-CPU oracle (same aten ops as the reference, fp32) on the host cores"""
+    from oracle import vinet_cpu as O
+    from vinet_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = O.VideoSaliencyModel(num_clips=args.clip)
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 0))
+    x = synth.clip(1, args.clip, args.height, args.width, 0).permute(0, 2, 1, 3, 4)
+    gt = synth.gt_map(1, args.height, args.width, 0)
+    if args.mode == "train":
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+
+        def step():
+            opt.zero_grad()
+            O.kldiv(m(x), gt).backward()
+            opt.step()
+    else:
+        m.eval()
+
+        def step():
+            with torch.no_grad():
+                m(x)
+    step()  # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        step()
+    dt = (time.perf_counter() - t0) / args.cpu_steps
+    return dict(value=1.0 / dt, unit="clips/s", cores=cores, kind="port",
+                sample="%d %s step(s) of batch 1 at %dx%dx%d fp32 with the PyTorch-CPU oracle (oracle/vinet_cpu.py), %d threads"
+                       % (args.cpu_steps, args.mode, args.clip, args.height, args.width, cores))
+
+
+def main():
+    args = parse()
+    from vinet_amd import _lib, engine, loss, model, optim, parallel, synth
+    rank, world, local, dev = parallel.init_from_env()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    _lib.load()
+    engine.set_default_dtype(args.dtype)
+
+    B = args.batch
+    m = model.VideoSaliencyModel(num_clips=args.clip)
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 0))
+    m = m.to(dev)
+    # synthetic clip as the loaders hand it over: [B,T,3,H,W], permuted like train.py:205
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    x = torch.randn((B, args.clip, 3, args.height, args.width), generator=g, device=dev).permute(0, 2, 1, 3, 4)
+    gt = synth.gt_map(B, args.height, args.width, rank).to(dev)
+
+    if args.mode == "train":
+        m.train()
+        opt = optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+        parallel.broadcast_parameters(opt)
+
+        def step():
+            opt.zero_grad()
+            l = loss.kldiv(m(x), gt)
+            l.backward()
+            parallel.allreduce_gradients(opt)
+            opt.step()
+            return l
+    else:
+        m.eval()
+
+        def step():
+            with torch.no_grad():
+                return m(x)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up; the last warm-up step is bracketed site by site to find the dominant kernel site
+    for i in range(max(args.warmup, 1)):
+        if i == max(args.warmup, 1) - 1:
+            prof = engine.Profiler()
+            engine.set_profiler(prof)
+        step()
+    table = prof.summary()
+    engine.set_profiler(None)
+    dom = max(table.items(), key=lambda kv: kv[1]["ms"])[0]
+    if args.profile_all and rank == 0:
+        tot = sum(v["ms"] for v in table.values())
+        for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])[:40]:
+            print("%8.3f ms %5.1f%% x%-3d %s" % (v["ms"], 100 * v["ms"] / tot, v["count"], k), file=sys.stderr)
+        print("sum of bracketed kernel time %.3f ms" % tot, file=sys.stderr)
+
+    # ---- timed region: only the dominant site is bracketed (2 events per launch)
+    prof = engine.Profiler(only=[dom])
+    engine.set_profiler(prof)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    t1 = time.perf_counter()
+    engine.set_profiler(None)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    domstat = prof.summary()[dom]
+
+    if rank == 0:
+        clips = world * B * args.steps
+        value = clips / elapsed
+        w = domstat["work"] or {}
+        avg_s = domstat["ms"] / domstat["count"] / 1e3
+        flops, byts = w.get("flops", 0.0), w.get("bytes", 0.0)
+        ai = flops / max(byts, 1.0)
+        ridge = MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if ai > ridge:
+            roof = dict(bound="mfma", achieved=flops / avg_s / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s")
+        else:
+            roof = dict(bound="hbm", achieved=byts / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof.update(traffic=None, kernel=dom, launches=domstat["count"], avg_us=avg_s * 1e6,
+                    algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=byts)
+        per_gpu = value / world
+        out = {
+            "metric": "clips/sec training (32x224x384 bf16)" if args.mode == "train" else "inference clips/sec (one output frame per clip)",
+            "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "ViNet DHF1K %s, %dx%dx%d %s, %d clip(s)/GPU/step, kldiv + fused Adam, %s"
+                                   % ("training" if args.mode == "train" else "inference", args.clip, args.height,
+                                      args.width, args.dtype, B,
+                                      "1xMI355X" if world == 1 else "%dxMI355X RCCL all-reduce" % world),
+                       "global_batch": world * B, "local_batch": B, "clip": [args.clip, args.height, args.width],
+                       "parallelism": "dp%d" % world},
+            "roofline": roof,
+            "whole_step": {
+                "hbm_frac_of_8TBs": per_gpu * (TRAIN_MB_PER_CLIP + STEP_MB_PER_GPU / B) * 1e6 / (HBM_PEAK_GBS * 1e9),
+                "mfma_frac_of_2.5PF": per_gpu * TRAIN_GFLOP_PER_CLIP * 1e9 / (MFMA_BF16_PEAK_TF * 1e12),
+            } if (args.mode == "train" and (args.clip, args.height, args.width) == (32, 224, 384)) else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,37 @@ def rup(a, b):
     return (a + b - 1) // b * b
 
 
+class Profiler:
+    """HIP-event timing of library calls on torch's current stream (which is the
+    stream every kernel is launched on).  `only` restricts bracketing to a set of
+    call-site keys so a timed benchmark region can measure ONE kernel site with two
+    event records per launch and nothing else."""
+
+    def __init__(self, only=None):
+        self.only = None if only is None else set(only)
+        self.records = []
+
+    def want(self, key):
+        return self.only is None or key in self.only
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, e0, e1, work in self.records:
+            a = agg.setdefault(key, dict(count=0, ms=0.0, work=work))
+            a["count"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+        return agg
+
+
+PROFILER = None
+
+
+def set_profiler(p):
+    global PROFILER
+    PROFILER = p
+
+
 def _stream_for(device):
     if device.type == "cuda":
         return torch.cuda.current_stream(device).cuda_stream
@@ -192,8 +223,16 @@ class Ctx:
     def f32(self, n, zero=False):
         return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.device)
 
-    def call(self, name, *args):
-        rc = getattr(self.lib, name)(*args)
+    def call(self, name, *args, tag=None, work=None):
+        prof = PROFILER
+        if prof is not None and self.device.type == "cuda" and prof.want(tag or name):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = getattr(self.lib, name)(*args)
+            e1.record()
+            prof.records.append((tag or name, e0, e1, work))
+        else:
+            rc = getattr(self.lib, name)(*args)
         if rc != 0:
             L.check(rc, name)
 
@@ -321,6 +360,10 @@ class ConvPlan:
         self._taps = {}
 
     # ---- geometry ---------------------------------------------------------
+    def site(self, xv):
+        """human-readable call-site key for profiles: channels, kernel, stride, input extent"""
+        return "%d->%d k%dx%dx%d s%dx%dx%d in%dx%dx%dx%d" % ((self.Cin, self.N) + self.k + self.s + (xv.B, xv.T, xv.H, xv.W))
+
     def out_dims(self, T, H, W):
         return tuple((d + 2 * p - k) // s + 1 for d, k, s, p in zip((T, H, W), self.k, self.s, self.p))
 
@@ -436,6 +479,11 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     d.accumulate = 0
     d.n_valid = plan.N if Ny != plan.N else 0
     M = xv.B * oT * oH * oW
+    site = plan.site(xv)
+    es = ESIZE[lib_dt]
+    work = dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
+                bytes=float(xv.nvox * plan.Cin * es + M * plan.N * ESIZE[out.dt] + plan.N * plan.Cin * plan.ntaps * es))
+    conv_tag = "conv_fwd " + site
 
     train_bn = bn is not None and ctx.training
     keep = {}
@@ -444,7 +492,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     if bn is None:
         d.out_scale, d.out_shift = None, _ptr(plan.bias)
         d.act, d.stats = act, None
-        ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+        ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
         res.scale = res.shift = None
         res.relu = False
     elif not train_bn:
@@ -456,14 +504,14 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
             ctx.call("vinet_bn_fold", _ptr(bn.gamma), _ptr(bn.beta), bn.rm.data_ptr(), bn.rv.data_ptr(), None,
                      float(bn.eps), plan.N, scale.data_ptr(), shift.data_ptr(), invstd.data_ptr(), ctx.stream)
             d.out_scale, d.out_shift, d.act, d.stats = None, _ptr(plan.bias), L.ACT_NONE, None
-            ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+            ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
             res.scale, res.shift, res.relu = scale, shift, (act == L.ACT_RELU)
             keep.update(mean=bn.rm, invstd=invstd)
         else:
             ctx.call("vinet_bn_fold", _ptr(bn.gamma), _ptr(bn.beta), bn.rm.data_ptr(), bn.rv.data_ptr(),
                      _ptr(plan.bias), float(bn.eps), plan.N, scale.data_ptr(), shift.data_ptr(), None, ctx.stream)
             d.out_scale, d.out_shift, d.act, d.stats = scale.data_ptr(), shift.data_ptr(), act, None
-            ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+            ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
             res.scale = res.shift = None
             res.relu = False
     else:
@@ -471,7 +519,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         rows = (M + bm - 1) // bm
         stats = ctx.f32(rows * 2 * plan.N)
         d.out_scale, d.out_shift, d.act, d.stats = None, _ptr(plan.bias), L.ACT_NONE, stats.data_ptr()
-        ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+        ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
         scale = ctx.f32(plan.N) if scale_out is None else scale_out
         shift = ctx.f32(plan.N) if shift_out is None else shift_out
         mean, invstd = ctx.f32(plan.N), ctx.f32(plan.N)
@@ -539,7 +587,10 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         wd.sT, wd.sH, wd.sW = plan.s
         wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), kp
         wd.pre = x.affine()
-        ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream)
+        es = ESIZE[ctx.dt]
+        ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream, tag="conv_wgrad " + plan.site(x.v),
+                 work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
+                           bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
         if Ny != plan.N:
             assert plan.ntaps == 1, "channel-padded outputs are only supported for 1x1x1 convs"
         gw = _param_grad(plan.weight)
@@ -566,7 +617,11 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             d.out_scale = d.out_shift = None
             d.act, d.accumulate, d.stats = L.ACT_NONE, acc, None
             d.n_valid = plan.Cin if xv.C != plan.Cin else 0
-            ctx.call("vinet_conv3d", C.byref(d), ctx.stream)
+            es = ESIZE[ctx.dt]
+            nph = len(phases)
+            ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag="conv_dgrad " + plan.site(xv),
+                     work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps / nph,
+                               bytes=float(xv.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * es) / nph))
         x.mark_grad_ready()
 
 
