@@ -113,6 +113,10 @@ typedef struct VinetConvDesc {
 int vinet_conv3d(const VinetConvDesc* desc, void* stream);
 /* BM of the tile configuration vinet_conv3d will pick for this problem. */
 int vinet_conv3d_tile_m(const VinetConvDesc* desc);
+/* Tile configuration (MT, NT, WARPS_M, WARPS_N) vinet_conv3d will pick, i.e. the
+ * template arguments of the conv_igemm_kernel instantiation that will run
+ * (profilers report kernels by that name). */
+int vinet_conv3d_config(const VinetConvDesc* desc, int32_t out_cfg[4]);
 
 /* Weight gradient: dw[slice_tap][n][c] (+)= sum_m dy[m][n] * pre(x[m shifted by tap])[c]
  * (the wgrad half of convolution_backward, train.py:216).  `dw` is fp32

@@ -134,6 +134,12 @@ class AbiEmulator:
         d = _deref(d)
         return _tile_m(d.dtype, d.mode, d.x.B * d.oT * d.oH * d.oW, d.y.C)
 
+    def vinet_conv3d_config(self, d, out):
+        bm = self.vinet_conv3d_tile_m(d)
+        for i, v in enumerate((bm // 64, 1, 4, 1)):
+            out[i] = v
+        return 0
+
     def _taps(self, d):
         return np.ctypeslib.as_array((C.c_int32 * (4 * d.ntaps)).from_address(d.taps)).reshape(-1, 4)
 

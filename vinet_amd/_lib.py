@@ -54,6 +54,7 @@ _PT, _PC, _PW, _PP = C.POINTER(CTensor), C.POINTER(CConvDesc), C.POINTER(CWgradD
 SIGNATURES = {
     "vinet_conv3d": [_PC, _vp],
     "vinet_conv3d_tile_m": [_PC],
+    "vinet_conv3d_config": [_PC, C.POINTER(C.c_int32)],
     "vinet_conv3d_wgrad": [_PW, _vp],
     "vinet_pack_weights": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "vinet_unpack_wgrad": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -95,6 +95,14 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C).BM();
 }
 
+extern "C" int vinet_conv3d_config(const VinetConvDesc* d, int32_t out_cfg[4]) {
+  if (!d || !out_cfg) return -1;
+  const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C);
+  out_cfg[0] = t.MT; out_cfg[1] = t.NT; out_cfg[2] = t.WM; out_cfg[3] = t.WN;
+  return 0;
+}
+
 extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
   ConvArgs a;
   ConvTile t;

@@ -365,25 +365,36 @@ extern "C" int vinet_bn_bwd_reduce(const VinetTensor* dz, const VinetTensor* x_r
   return launch_channel_reduce<1>(x_raw, dz, dtype, fwd, mean, invstd, partials, stream);
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int C, double count,
-                                       const float* scale, int train, float* dgamma, float* dbeta,
-                                       const float* invstd, float* c1, float* c2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one workgroup per channel: rows are reduced in parallel (fp64), lane 0 finishes
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int C,
+                                                              double count, const float* scale, int train, float* dgamma,
+                                                              float* dbeta, const float* invstd, float* c1, float* c2) {
+  const int c = blockIdx.x;
   double s = 0.0, p = 0.0;
-  for (int r = 0; r < rows; ++r) { s += (double)partials[((long)r * 2) * C + c]; p += (double)partials[((long)r * 2 + 1) * C + c]; }
-  if (dgamma) dgamma[c] += (float)p;
-  if (dbeta) dbeta[c] += (float)s;
-  if (c1) c1[c] = train ? (float)(s / count) : 0.f;
-  if (c2) c2[c] = train ? (float)(p / count) : 0.f;
+  for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+    s += (double)partials[((long)r * 2) * C + c];
+    p += (double)partials[((long)r * 2 + 1) * C + c];
+  }
+  __shared__ double red[2][4];
+  s = wave_sum_d(s); p = wave_sum_d(p);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = p; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    p = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (dgamma) dgamma[c] += (float)p;
+    if (dbeta) dbeta[c] += (float)s;
+    if (c1) c1[c] = train ? (float)(s / count) : 0.f;
+    if (c2) c2[c] = train ? (float)(p / count) : 0.f;
+  }
 }
 
 extern "C" int vinet_bn_bwd_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* scale,
                                      int32_t train, float* dgamma_acc, float* dbeta_acc, const float* invstd, float* c1,
                                      float* c2, void* stream) {
   VN_CHECK_ARG(partials && rows > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials, rows, C,
-                     count, scale, train, dgamma_acc, dbeta_acc, invstd, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, rows, C, count,
+                     scale, train, dgamma_acc, dbeta_acc, invstd, c1, c2);
   return vn_launch_status("bn_bwd_finalize");
 }
 
@@ -472,14 +483,23 @@ extern "C" int vinet_act_bwd(const VinetTensor* dz, int32_t dz_dtype, const Vine
   return -1;
 }
 
-__global__ void channel_sum_finalize_kernel(const float* __restrict__ partials, int rows, int C, int Cout, float* out,
-                                            int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= Cout) return;
+__global__ __launch_bounds__(256) void channel_sum_finalize_kernel(const float* __restrict__ partials, int rows, int C,
+                                                                   int Cout, float* out, int accumulate) {
+  const int j = blockIdx.x;
   double s = 0.0;
-  for (int c = j; c < C; c += Cout)
-    for (int r = 0; r < rows; ++r) s += (double)partials[((long)r * 2) * C + c];
-  out[j] = accumulate ? out[j] + (float)s : (float)s;
+  const int per = C / Cout;   // channels folded onto output j: j, j + Cout, ...
+  for (int e = threadIdx.x; e < rows * per; e += blockDim.x) {
+    const int r = e / per, c = j + (e % per) * Cout;
+    s += (double)partials[((long)r * 2) * C + c];
+  }
+  __shared__ double red[4];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = red[0] + red[1] + red[2] + red[3];
+    out[j] = accumulate ? out[j] + (float)s : (float)s;
+  }
 }
 
 extern "C" int vinet_channel_sum(const VinetTensor* x, int32_t dtype, float* workspace, int32_t Cout, float* out,
@@ -488,7 +508,7 @@ extern "C" int vinet_channel_sum(const VinetTensor* x, int32_t dtype, float* wor
   VinetAffine none = {nullptr, nullptr, 0};
   int rc = launch_channel_reduce<0>(x, nullptr, dtype, none, nullptr, nullptr, workspace, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((Cout + 63) / 64), dim3(64), 0, (hipStream_t)stream, workspace,
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, workspace,
                      stats_rows_for(view_voxels(*x)), x->C, Cout, out, accumulate);
   return vn_launch_status("channel_sum");
 }

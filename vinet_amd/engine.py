@@ -444,6 +444,12 @@ def _param_grad(p):
     return p.grad
 
 
+def _conv_kernel_name(ctx, d):
+    cfg = (C.c_int32 * 4)()
+    ctx.lib.vinet_conv3d_config(C.byref(d), cfg)
+    return "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>" % ("bf16" if d.dtype == BF16 else "float", cfg[0], cfg[1], cfg[2], cfg[3], d.mode)
+
+
 def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n_pad=None):
     """x -> conv (-> BN) (-> act).  Returns the output Act.
 
@@ -483,7 +489,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     es = ESIZE[lib_dt]
     work = dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
                 bytes=float(xv.nvox * plan.Cin * es + M * plan.N * ESIZE[out.dt] + plan.N * plan.Cin * plan.ntaps * es))
-    conv_tag = "conv_fwd " + site
+    conv_tag = _conv_kernel_name(ctx, d) + " | fwd " + site if PROFILER is not None else None
 
     train_bn = bn is not None and ctx.training
     keep = {}
@@ -588,7 +594,8 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), kp
         wd.pre = x.affine()
         es = ESIZE[ctx.dt]
-        ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream, tag="conv_wgrad " + plan.site(x.v),
+        ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
+                 tag="conv_wgrad_kernel<%s,%d> | wgrad %s" % ("bf16" if ctx.dt == BF16 else "float", wd.mode, plan.site(x.v)),
                  work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
                            bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
         if Ny != plan.N:
@@ -619,7 +626,8 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             d.n_valid = plan.Cin if xv.C != plan.Cin else 0
             es = ESIZE[ctx.dt]
             nph = len(phases)
-            ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag="conv_dgrad " + plan.site(xv),
+            ctx.call("vinet_conv3d", C.byref(d), ctx.stream,
+                     tag=(_conv_kernel_name(ctx, d) + " | dgrad " + plan.site(xv)) if PROFILER is not None else None,
                      work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps / nph,
                                bytes=float(xv.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * es) / nph))
         x.mark_grad_ready()
