@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Inference harness -- counterpart of generate_result.py:48-104 on the MI355X path.
+
+`sliding_window_schedule(n_frames, T)` reproduces the reference's frame schedule
+(generate_result.py:58-73): every frame i >= T-1 is predicted from the clip
+[i-T+1 .. i]; the first T-1 frames are predicted from the TIME-REVERSED clip that
+starts at them (torch.flip on dim 2).  `predict_video(model, frames)` runs that
+schedule on a [N,3,H,W] tensor of preprocessed frames and returns [N,H,W] maps.
+Image decoding / cv2.resize / Gaussian blur / PNG writing (generate_result.py:77-104)
+are host post-processing, a "next" row of SURVEY.md section 8(f).
+"""
+import argparse
+
+import torch
+
+
+def sliding_window_schedule(n_frames, T):
+    """[(output frame, [clip frame indices in model order], flipped)] in the reference's call order."""
+    out = []
+    if n_frames < 2 * T - 1:
+        return out
+    for i in range(n_frames):
+        if i >= T - 1:
+            clip = list(range(i - T + 1, i + 1))
+            out.append((i, clip, False))
+            if i < 2 * T - 2:
+                out.append((i - T + 1, clip[::-1], True))
+    return out
+
+
+@torch.no_grad()
+def predict_video(model, frames, T, batch=1):
+    """frames [N,3,H,W] (normalised, on the model's device) -> saliency [N,H,W]."""
+    N = frames.shape[0]
+    sched = sliding_window_schedule(N, T)
+    assert sched, "more frames are needed (N >= 2T-1)"
+    maps = torch.empty((N,) + tuple(frames.shape[2:]), dtype=torch.float32, device=frames.device)
+    model.eval()
+    for s in range(0, len(sched), batch):
+        chunk = sched[s:s + batch]
+        idx = torch.tensor([c[1] for c in chunk], device=frames.device)
+        clips = frames[idx].permute(0, 2, 1, 3, 4)          # [b,T,3,H,W] -> [b,3,T,H,W] (generate_result.py:65)
+        y = model(clips)
+        for j, (o, _, _) in enumerate(chunk):
+            maps[o] = y[j]
+    return maps
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--file_weight', default="./saved_models/ViNet_DHF1K.pt", type=str)
+    p.add_argument('--nhead', default=4, type=int)
+    p.add_argument('--num_encoder_layers', default=3, type=int)
+    p.add_argument('--transformer_in_channel', default=32, type=int)
+    p.add_argument('--save_path', default='/ssd_scratch/cvit/samyak/Results/theatre_hollywood', type=str)
+    p.add_argument('--start_idx', default=-1, type=int)
+    p.add_argument('--num_parts', default=4, type=int)
+    p.add_argument('--path_indata', default='/ssd_scratch/cvit/samyak/DHF1K/val', type=str)
+    p.add_argument('--multi_frame', default=0, type=int)
+    p.add_argument('--decoder_upsample', default=1, type=int)
+    p.add_argument('--num_decoder_layers', default=-1, type=int)
+    p.add_argument('--num_hier', default=3, type=int)
+    p.add_argument('--clip_size', default=32, type=int)
+    p.add_argument('--synthetic_frames', default=0, type=int, help="run the schedule on N synthetic 224x384 frames and report fps")
+    p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
+    p.add_argument('--batch', default=1, type=int)
+    return p
+
+
+def main(argv=None):
+    import os
+    import time
+    from . import engine, model, synth
+    args = build_parser().parse_args(argv)
+    print(args)
+    dev = torch.device('cuda')
+    engine.set_default_dtype(args.compute_dtype)
+    m = model.VideoSaliencyModel(transformer_in_channel=args.transformer_in_channel, nhead=args.nhead,
+                                 use_upsample=bool(args.decoder_upsample), num_hier=args.num_hier, num_clips=args.clip_size)
+    if os.path.isfile(args.file_weight):
+        m.load_state_dict(torch.load(args.file_weight, map_location="cpu"))
+    else:
+        print("weight file? using procedural weights")
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), 0))
+    m = m.to(dev).eval()
+    assert args.synthetic_frames > 0, "image decoding is out of scope here; use --synthetic_frames N"
+    frames = synth.clip(1, args.synthetic_frames, 224, 384, 0)[0].to(dev)
+    predict_video(m, frames[:2 * args.clip_size - 1], args.clip_size, args.batch)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    maps = predict_video(m, frames, args.clip_size, args.batch)
+    torch.cuda.synchronize()
+    n_calls = len(sliding_window_schedule(args.synthetic_frames, args.clip_size))
+    print("%d model calls for %d frames in %.3f s -> %.1f fps" % (n_calls, args.synthetic_frames, time.time() - t0, n_calls / (time.time() - t0)))
+    return maps
+
+
+if __name__ == "__main__":
+    main()

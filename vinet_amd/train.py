@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Training driver -- counterpart of the reference's train.py on the MI355X path.
+
+Keeps the reference's flag names and defaults (train.py:21-66), the
+`permute((0,2,1,3,4))` input convention (train.py:205), Adam(lr) (train.py:188),
+the seeds (train.py:90-91), the log format (train.py:222,226) and the best-val
+checkpoint rule (train.py:280-290), but is importable (argparse runs in main()),
+uses one process per GPU with an RCCL all-reduce instead of nn.DataParallel
+(train.py:181-185), and can run on synthetic clips (`--dataset synthetic`) because
+the benchmark box has no datasets.  Dataset decoding (dataloader.py) is a "next"
+row of SURVEY.md section 8(f): pass any torch Dataset yielding
+(clip [T,3,H,W], gt [H,W]) through `run(args, train_dataset, val_dataset)`.
+
+    python -m vinet_amd.train --dataset synthetic --no_epochs 1 --batch_size 8
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m vinet_amd.train ...
+"""
+import argparse
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def _bool(v):
+    # the reference uses type=bool (any non-empty string is True, train.py:24-31); accept real booleans too
+    if isinstance(v, bool):
+        return v
+    return str(v).lower() not in ("", "0", "false", "no")
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--no_epochs', default=40, type=int)
+    p.add_argument('--lr', default=1e-4, type=float)
+    p.add_argument('--kldiv', default=True, type=_bool)
+    p.add_argument('--cc', default=False, type=_bool)
+    p.add_argument('--nss', default=False, type=_bool)
+    p.add_argument('--sim', default=False, type=_bool)
+    p.add_argument('--nss_emlnet', default=False, type=_bool)
+    p.add_argument('--nss_norm', default=False, type=_bool)
+    p.add_argument('--l1', default=False, type=_bool)
+    p.add_argument('--lr_sched', default=False, type=_bool)
+    p.add_argument('--optim', default="Adam", type=str)
+    p.add_argument('--kldiv_coeff', default=1.0, type=float)
+    p.add_argument('--step_size', default=5, type=int)
+    p.add_argument('--cc_coeff', default=-1.0, type=float)
+    p.add_argument('--sim_coeff', default=-1.0, type=float)
+    p.add_argument('--nss_coeff', default=1.0, type=float)
+    p.add_argument('--nss_emlnet_coeff', default=1.0, type=float)
+    p.add_argument('--nss_norm_coeff', default=1.0, type=float)
+    p.add_argument('--l1_coeff', default=1.0, type=float)
+    p.add_argument('--batch_size', default=8, type=int)       # GLOBAL batch, as in the reference
+    p.add_argument('--log_interval', default=5, type=int)
+    p.add_argument('--no_workers', default=4, type=int)
+    p.add_argument('--model_val_path', default="enet_transformer.pt", type=str)
+    p.add_argument('--clip_size', default=32, type=int)
+    p.add_argument('--nhead', default=4, type=int)
+    p.add_argument('--num_encoder_layers', default=3, type=int)
+    p.add_argument('--num_decoder_layers', default=3, type=int)
+    p.add_argument('--transformer_in_channel', default=32, type=int)
+    p.add_argument('--train_path_data', default="/ssd_scratch/cvit/samyak/DHF1K/annotation", type=str)
+    p.add_argument('--val_path_data', default="/ssd_scratch/cvit/samyak/DHF1K/val", type=str)
+    p.add_argument('--decoder_upsample', default=1, type=int)
+    p.add_argument('--frame_no', default="last", type=str)
+    p.add_argument('--load_weight', default="None", type=str)
+    p.add_argument('--num_hier', default=3, type=int)
+    p.add_argument('--dataset', default="DHF1KDataset", type=str)
+    p.add_argument('--alternate', default=1, type=int)
+    p.add_argument('--spatial_dim', default=-1, type=int)
+    p.add_argument('--split', default=-1, type=int)
+    p.add_argument('--use_sound', default=False, type=_bool)
+    p.add_argument('--use_transformer', default=False, type=_bool)
+    p.add_argument('--use_vox', default=False, type=_bool)
+    # additions of this build
+    p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
+    p.add_argument('--synthetic_steps', default=20, type=int, help="steps per epoch with --dataset synthetic")
+    p.add_argument('--height', default=224, type=int)
+    p.add_argument('--width', default=384, type=int)
+    return p
+
+
+class SyntheticClips(torch.utils.data.Dataset):
+    """(clip [T,3,H,W] ~ N(0,1), gt [H,W] blobs) with the shapes DHF1KDataset yields (dataloader.py:283-300)."""
+
+    def __init__(self, n, clip, h, w, sound=False):
+        self.n, self.clip, self.h, self.w, self.sound = n, clip, h, w, sound
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        from . import synth
+        x = synth.clip(1, self.clip, self.h, self.w, seed=i)[0]
+        g = synth.gt_map(1, self.h, self.w, seed=i)[0]
+        if self.sound:
+            return x, g, synth.audio(1, 70560, seed=i)[0]
+        return x, g
+
+
+def build_model(args):
+    from . import model
+    if args.use_sound:
+        return model.VideoAudioSaliencyModel(
+            transformer_in_channel=args.transformer_in_channel, nhead=args.nhead, use_transformer=args.use_transformer,
+            num_encoder_layers=args.num_encoder_layers, use_upsample=bool(args.decoder_upsample),
+            num_hier=args.num_hier, num_clips=args.clip_size)
+    return model.VideoSaliencyModel(use_upsample=bool(args.decoder_upsample), num_hier=args.num_hier, num_clips=args.clip_size)
+
+
+def remap_s3d_kinetics(weight_dict, backbone):
+    """S3D Kinetics-400 checkpoint -> BackBoneS3D keys: `base.N.*` -> `base{1..4}.M.*` with the
+    split points [0, 5, 8, 14] (train.py:141-172)."""
+    model_dict = backbone.state_dict()
+    sn_list = [0, 5, 8, 14]
+    for name, param in weight_dict.items():
+        if 'module' in name:
+            name = '.'.join(name.split('.')[1:])
+        if 'base.' in name:
+            bn = int(name.split('.')[1])
+            sn = max(s for s in sn_list if bn >= s)
+            name = 'base%d.%d.' % (sn_list.index(sn) + 1, bn - sn) + '.'.join(name.split('.')[2:])
+        if name in model_dict and param.size() == model_dict[name].size():
+            model_dict[name].copy_(param)
+        else:
+            print(' name/size? ' + name)
+    backbone.load_state_dict(model_dict)
+
+
+def train_epoch(model, optimizer, loader, epoch, device, args, world=1):
+    from . import parallel
+    from .utils import AverageMeter, loss_func
+    model.train()
+    tic = time.time()
+    total_loss, cur_loss = AverageMeter(), AverageMeter()
+    for idx, sample in enumerate(loader):
+        img_clips = sample[0].to(device).permute((0, 2, 1, 3, 4))
+        gt_sal = sample[1].to(device)
+        optimizer.zero_grad()
+        if args.use_sound or args.use_vox:
+            pred_sal = model(img_clips, sample[2].to(device))
+        else:
+            pred_sal = model(img_clips)
+        assert pred_sal.size() == gt_sal.size()
+        loss = loss_func(pred_sal, gt_sal, args)
+        loss.backward()
+        parallel.allreduce_gradients(optimizer)
+        optimizer.step()
+        lv = float(parallel.allreduce_scalar_mean(loss.detach()))
+        total_loss.update(lv)
+        cur_loss.update(lv)
+        if idx % args.log_interval == (args.log_interval - 1):
+            print('[{:2d}, {:5d}] avg_loss : {:.5f}, time:{:3f} minutes'.format(epoch, idx, cur_loss.avg, (time.time() - tic) / 60))
+            cur_loss.reset()
+            sys.stdout.flush()
+    print('[{:2d}, train] avg_loss : {:.5f}'.format(epoch, total_loss.avg))
+    sys.stdout.flush()
+    return total_loss.avg
+
+
+def validate(model, loader, epoch, device, args):
+    """train.py:231-272 without the host round trip (cv2.resize + blur of the prediction are a
+    'next' row): losses are taken at the network's output resolution."""
+    from .loss import cc, similarity
+    from .utils import AverageMeter, loss_func
+    model.eval()
+    tic = time.time()
+    tl, tc, ts = AverageMeter(), AverageMeter(), AverageMeter()
+    with torch.no_grad():
+        for sample in loader:
+            img_clips = sample[0].to(device).permute((0, 2, 1, 3, 4))
+            gt_sal = sample[1].to(device)
+            pred_sal = model(img_clips, sample[2].to(device)) if (args.use_sound or args.use_vox) else model(img_clips)
+            tl.update(float(loss_func(pred_sal, gt_sal, args)))
+            tc.update(float(cc(pred_sal, gt_sal)))
+            ts.update(float(similarity(pred_sal, gt_sal)))
+    print('[{:2d}, val] avg_loss : {:.5f} cc_loss : {:.5f} sim_loss : {:.5f}, time : {:3f}'.format(
+        epoch, tl.avg, tc.avg, ts.avg, (time.time() - tic) / 60))
+    sys.stdout.flush()
+    return tl.avg
+
+
+def run(args, train_dataset=None, val_dataset=None):
+    from . import engine, optim, parallel
+    rank, world, local, device = parallel.init_from_env()
+    engine.set_default_dtype(args.compute_dtype)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = build_model(args)
+    if args.load_weight != "None":
+        sd = torch.load(args.load_weight, map_location="cpu")
+        (model.visual_model if (args.use_sound or args.use_vox) else model).load_state_dict(sd)
+    model.to(device)
+    assert args.batch_size % world == 0, "--batch_size is the global batch and must divide over the ranks"
+    local_bs = args.batch_size // world
+    if train_dataset is None:
+        assert args.dataset == "synthetic", "pass datasets to run() or use --dataset synthetic (loaders are out of scope)"
+        train_dataset = SyntheticClips(args.synthetic_steps * args.batch_size, args.clip_size, args.height, args.width, args.use_sound)
+        val_dataset = SyntheticClips(2 * world, args.clip_size, args.height, args.width, args.use_sound)
+    sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True) if world > 1 else None
+    train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=local_bs, shuffle=(sampler is None), sampler=sampler,
+                                               num_workers=args.no_workers, drop_last=True)
+    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=1, shuffle=False, num_workers=0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    optimizer = optim.Adam(params, lr=args.lr)
+    parallel.broadcast_parameters(optimizer)
+    best_loss = None
+    for epoch in range(args.no_epochs):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        train_epoch(model, optimizer, train_loader, epoch, device, args, world)
+        val_loss = validate(model, val_loader, epoch, device, args)
+        if epoch == 0:
+            val_loss = np.inf
+            best_loss = val_loss
+        if val_loss <= best_loss and rank == 0:
+            best_loss = val_loss
+            print('[{:2d},  save, {}]'.format(epoch, args.model_val_path))
+            torch.save(model.state_dict(), args.model_val_path)
+        print()
+    return model
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print(args)
+    run(args)
+
+
+if __name__ == "__main__":
+    main()
