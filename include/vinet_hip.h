@@ -113,10 +113,9 @@ typedef struct VinetConvDesc {
 int vinet_conv3d(const VinetConvDesc* desc, void* stream);
 /* BM of the tile configuration vinet_conv3d will pick for this problem. */
 int vinet_conv3d_tile_m(const VinetConvDesc* desc);
-/* Tile configuration (MT, NT, WARPS_M, WARPS_N) vinet_conv3d will pick, i.e. the
- * template arguments of the conv_igemm_kernel instantiation that will run
+/* Name of the kernel instantiation vinet_conv3d will launch for this problem
  * (profilers report kernels by that name). */
-int vinet_conv3d_config(const VinetConvDesc* desc, int32_t out_cfg[4]);
+int vinet_conv3d_kernel_name(const VinetConvDesc* desc, char* buf, int32_t n);
 
 /* Weight gradient: dw[slice_tap][n][c] (+)= sum_m dy[m][n] * pre(x[m shifted by tap])[c]
  * (the wgrad half of convolution_backward, train.py:216).  `dw` is fp32
@@ -254,6 +253,9 @@ int vinet_bilinear_bwd(const void* x1, const void* x2, const void* dout, int32_t
                        void* stream);
 
 /* misc */
+/* Tuning / A-B switches (process-wide): "dma" (1 = use the LDS-DMA conv kernel where
+ * legal, default 1), "wgrad_tr" (1 = hardware transpose reads in wgrad, default 1). */
+int vinet_set_option(const char* name, int32_t value);
 int vinet_fill_f32(float* p, int64_t n, float value, void* stream);
 int vinet_abi_version(void);
 const char* vinet_last_error(void);

@@ -125,6 +125,9 @@ class AbiEmulator:
     def vinet_last_error(self):
         return self.err
 
+    def vinet_set_option(self, name, value):
+        return 0
+
     def vinet_fill_f32(self, p, n, value, stream):
         _f32(p, n)[:] = value
         return 0
@@ -134,10 +137,7 @@ class AbiEmulator:
         d = _deref(d)
         return _tile_m(d.dtype, d.mode, d.x.B * d.oT * d.oH * d.oW, d.y.C)
 
-    def vinet_conv3d_config(self, d, out):
-        bm = self.vinet_conv3d_tile_m(d)
-        for i, v in enumerate((bm // 64, 1, 4, 1)):
-            out[i] = v
+    def vinet_conv3d_kernel_name(self, d, buf, n):
         return 0
 
     def _taps(self, d):

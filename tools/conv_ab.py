@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""In-process A/B timing of vinet_conv3d / vinet_conv3d_wgrad on real layer shapes.
+
+    python tools/conv_ab.py [--lib PATH ...] [--sites fwd|all]
+
+Each library given with --lib (default: the in-tree one) is dlopen'ed separately;
+every site is timed with HIP events, interleaved over the variants (library x
+option), median of several rounds.  This is the tool behind the tile / pipeline
+choices recorded in DESIGN.md -- never compare numbers from different runs."""
+import argparse
+import ctypes as C
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from vinet_amd import _lib as L
+
+# (name, B,T,H,W, Cin, N, k, s, p)  -- ViNet-32 layers at 32x224x384, batch 8
+SITES = [
+    ("stem_t 64->64 7x1x1/2", 8, 32, 112, 192, 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0)),
+    ("b1.3s 64->192 1x3x3", 8, 16, 56, 96, 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("b1.3t 192->192 3x1x1", 8, 16, 56, 96, 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("3c pw 256->128", 8, 16, 28, 48, 256, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("3c s 128->192 1x3x3", 8, 16, 28, 48, 128, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("4f pw 528->256", 8, 8, 14, 24, 528, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("5c s 192->384 1x3x3", 8, 4, 7, 12, 192, 384, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dec2 832->480 3x3x3/3", 8, 12, 14, 24, 832, 480, (3, 3, 3), (3, 1, 1), (0, 1, 1)),
+    ("dec3 480->192 5x3x3/5", 8, 20, 28, 48, 480, 192, (5, 3, 3), (5, 1, 1), (0, 1, 1)),
+    ("dec4 192->64 5x3x3/5", 8, 20, 56, 96, 192, 64, (5, 3, 3), (5, 1, 1), (0, 1, 1)),
+]
+
+
+def bind(path):
+    lib = C.CDLL(path)
+    for name, argtypes in L.SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = L._RESTYPE.get(name, C.c_int)
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", action="append")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--wgrad", action="store_true")
+    args = ap.parse_args()
+    libs = [(os.path.basename(p), bind(p)) for p in (args.lib or [L.LIB_PATH])]
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    variants = []
+    for ln, lib in libs:
+        variants.append((ln + ":dma", lib, dict(dma=1), False))
+        variants.append((ln + ":dma+pre", lib, dict(dma=1), True))
+        variants.append((ln + ":igemm", lib, dict(dma=0), False))
+        variants.append((ln + ":igemm+pre", lib, dict(dma=0), True))
+    print("%-26s" % "site" + "".join("%22s" % v[0][-21:] for v in variants) + "   (ms | TF/s)")
+    for (name, B, T, H, W, Cin, N, k, s, p) in SITES:
+        oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
+        x = torch.randn(B * T * H * W * Cin, device=dev).bfloat16()
+        y = torch.empty(B * oT * oH * oW * N, device=dev, dtype=torch.bfloat16)
+        ntaps = k[0] * k[1] * k[2]
+        Kp = (Cin + 31) // 32 * 32
+        w = (torch.randn(ntaps * N * Kp, device=dev) * 0.05).bfloat16()
+        taps = torch.tensor([(a - p[0], b - p[1], c - p[2], (a * k[1] + b) * k[2] + c) for a in range(k[0]) for b in range(k[1]) for c in range(k[2])],
+                            dtype=torch.int32, device=dev)
+        sc, sh = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev)
+        dw = torch.zeros(ntaps * N * Kp, device=dev)
+        flops = 2.0 * B * oT * oH * oW * N * Cin * ntaps
+
+        def desc(pre):
+            d = L.CConvDesc()
+            d.dtype = d.out_dtype = L.BF16
+            d.mode = 0
+            d.x = L.CTensor(x.data_ptr(), B, T, H, W, Cin, Cin, T * H * W * Cin)
+            d.y = L.CTensor(y.data_ptr(), B, oT, oH, oW, N, N, oT * oH * oW * N)
+            d.oT, d.oH, d.oW = oT, oH, oW
+            d.sT, d.sH, d.sW = s
+            d.omT = d.omH = d.omW = 1
+            d.ntaps, d.taps, d.w, d.Kp = ntaps, taps.data_ptr(), w.data_ptr(), Kp
+            d.pre = L.CAffine(sc.data_ptr(), sh.data_ptr(), 1) if pre else L.CAffine(None, None, 0)
+            return d
+
+        def wdesc(pre):
+            d = L.CWgradDesc()
+            d.dtype, d.mode = L.BF16, 0
+            d.x = L.CTensor(x.data_ptr(), B, T, H, W, Cin, Cin, T * H * W * Cin)
+            d.dy = L.CTensor(y.data_ptr(), B, oT, oH, oW, N, N, oT * oH * oW * N)
+            d.sT, d.sH, d.sW = s
+            d.ntaps, d.taps, d.dw, d.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), Kp
+            d.pre = L.CAffine(sc.data_ptr(), sh.data_ptr(), 1) if pre else L.CAffine(None, None, 0)
+            return d
+
+        times = [[] for _ in variants]
+        for r in range(args.rounds + 1):
+            for vi, (vn, lib, opts, pre) in enumerate(variants):
+                for kname, val in opts.items():
+                    lib.vinet_set_option(kname.encode(), val)
+                d = wdesc(pre) if args.wgrad else desc(pre)
+                fn = lib.vinet_conv3d_wgrad if args.wgrad else lib.vinet_conv3d
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    rc = fn(C.byref(d), stream)
+                    assert rc == 0, lib.vinet_last_error()
+                e1.record()
+                torch.cuda.synchronize()
+                if r > 0:
+                    times[vi].append(e0.elapsed_time(e1) / args.iters)
+        row = "%-26s" % name
+        for t in times:
+            m = statistics.median(t)
+            row += "%12.3f |%7.1f " % (m, flops / m / 1e9)
+        print(row, flush=True)
+
+
+if __name__ == "__main__":
+    main()

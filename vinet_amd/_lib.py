@@ -54,7 +54,7 @@ _PT, _PC, _PW, _PP = C.POINTER(CTensor), C.POINTER(CConvDesc), C.POINTER(CWgradD
 SIGNATURES = {
     "vinet_conv3d": [_PC, _vp],
     "vinet_conv3d_tile_m": [_PC],
-    "vinet_conv3d_config": [_PC, C.POINTER(C.c_int32)],
+    "vinet_conv3d_kernel_name": [_PC, C.c_char_p, _i32],
     "vinet_conv3d_wgrad": [_PW, _vp],
     "vinet_pack_weights": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "vinet_unpack_wgrad": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
@@ -79,6 +79,7 @@ SIGNATURES = {
     "vinet_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "vinet_bilinear_fwd": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "vinet_bilinear_bwd": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "vinet_set_option": [C.c_char_p, _i32],
     "vinet_fill_f32": [_vp, _i64, _f32, _vp],
     "vinet_abi_version": [],
     "vinet_last_error": [],

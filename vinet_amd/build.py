@@ -36,6 +36,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(tag, extra_flags, verbose=True):
+    """side build for A/B experiments: vinet_amd/csrc/obj_<tag>/ -> /tmp/libvinet_hip_<tag>.so"""
+    global OBJ, LIB, FLAGS
+    save = (OBJ, LIB, FLAGS)
+    OBJ, LIB, FLAGS = os.path.join(CSRC, "obj_" + tag), os.path.join(HERE, "libvinet_hip_%s.so" % tag), FLAGS + list(extra_flags)
+    try:
+        return build(force=False, verbose=verbose)
+    finally:
+        OBJ, LIB, FLAGS = save
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()

@@ -92,6 +92,19 @@ VN_DEV int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// Wave-uniform read of a small read-only table through the scalar cache (s_load):
+// a plain global load of a uniform address compiles to a VECTOR load followed by
+// s_waitcnt vmcnt(0), which drains every LDS-DMA / prefetch in flight.
+VN_DEV int4 load_tap(const int4* taps, int i) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VINET_TAP_VECTOR_LOAD)
+  typedef const __attribute__((address_space(4))) int* const_int_ptr;
+  const_int_ptr p = (const_int_ptr)(taps + i);
+  return make_int4(p[0], p[1], p[2], p[3]);
+#else
+  return taps[i];
+#endif
+}
+
 VN_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1,5 +1,6 @@
 // Host side of the convolution entry points + library-wide error state.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "conv_igemm.h"
 
@@ -95,11 +96,30 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C).BM();
 }
 
-extern "C" int vinet_conv3d_config(const VinetConvDesc* d, int32_t out_cfg[4]) {
-  if (!d || !out_cfg) return -1;
+int g_vinet_opt_dma = 1;
+int g_vinet_opt_wgrad_tr = 1;
+
+extern "C" int vinet_set_option(const char* name, int32_t value) {
+  if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
+  if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
+  vinet_set_error("set_option: unknown option %s", name ? name : "(null)");
+  return -1;
+}
+
+static bool use_dma(const VinetConvDesc* d) {
+  // a pending affine is supported when it comes with ReLU (BN+ReLU, the only kind the nets
+  // produce): the NaN-page padding trick needs the max(.,0); Kp <= 1024 for the LDS table
+  const bool pre_ok = !d->pre.scale || (d->pre.relu && d->pre.shift && d->Kp <= 1024);
+  return g_vinet_opt_dma && d->dtype == VINET_BF16 && d->mode == VINET_CONV_GENERIC && pre_ok &&
+         !(d->pre.relu && !d->pre.scale);
+}
+
+extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32_t n) {
+  if (!d || !buf || n <= 0) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C);
-  out_cfg[0] = t.MT; out_cfg[1] = t.NT; out_cfg[2] = t.WM; out_cfg[3] = t.WN;
+  if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
+  else snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", t.MT, t.NT, t.WM, t.WN, d->mode);
   return 0;
 }
 
@@ -108,6 +128,7 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
   ConvTile t;
   int rc = fill_args(d, a, t);
   if (rc) return rc;
+  if (use_dma(d)) return vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);
   if (d->dtype == VINET_BF16) return vinet_launch_conv_bf16(t, d->mode, a, (hipStream_t)stream);
   return vinet_launch_conv_f32(t, d->mode, a, (hipStream_t)stream);
 }

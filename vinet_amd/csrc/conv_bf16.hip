@@ -1,5 +1,5 @@
 // bf16 instantiations of the implicit-GEMM convolution.
-#include "conv_igemm.h"
+#include "conv_dma.h"
 
 #define CASE(MT_, NT_, WM_, WN_)                                                            \
   if (t.MT == MT_ && t.NT == NT_ && t.WM == WM_ && t.WN == WN_)                             \
@@ -10,5 +10,18 @@ int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipSt
   CASE(4, 8, 4, 1) CASE(4, 6, 4, 1) CASE(4, 4, 4, 1) CASE(4, 3, 4, 1) CASE(4, 2, 4, 1) CASE(4, 1, 4, 1)
   CASE(4, 4, 2, 2) CASE(4, 2, 2, 2) CASE(2, 4, 2, 2) CASE(2, 2, 2, 2)
   vinet_set_error("conv bf16: no kernel for tile MT=%d NT=%d WM=%d WN=%d", t.MT, t.NT, t.WM, t.WN);
+  return -1;
+}
+
+#define DMA_CASE(MT_, NT_, WM_, WN_)                                                   \
+  if (t.MT == MT_ && t.NT == NT_ && t.WM == WM_ && t.WN == WN_)                        \
+    return a.in_scale ? launch_conv_dma_cfg<MT_, NT_, WM_, WN_, 3, true>(a, s)          \
+                      : launch_conv_dma_cfg<MT_, NT_, WM_, WN_, 3, false>(a, s);
+
+// LDS-DMA pipelined kernel (conv_dma.h); a pending affine+ReLU is applied at fragment-read time
+int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t s) {
+  DMA_CASE(4, 8, 4, 1) DMA_CASE(4, 6, 4, 1) DMA_CASE(4, 4, 4, 1) DMA_CASE(4, 3, 4, 1) DMA_CASE(4, 2, 4, 1) DMA_CASE(4, 1, 4, 1)
+  DMA_CASE(4, 4, 2, 2) DMA_CASE(4, 2, 2, 2) DMA_CASE(2, 4, 2, 2) DMA_CASE(2, 2, 2, 2)
+  vinet_set_error("conv dma bf16: no kernel for tile MT=%d NT=%d WM=%d WN=%d", t.MT, t.NT, t.WM, t.WN);
   return -1;
 }

@@ -1,0 +1,239 @@
+// LDS-DMA pipelined implicit-GEMM convolution (bf16, gfx950).
+//
+// Same GEMM view, tiling, tap tables, weight packs and epilogue as
+// conv_igemm_kernel, but for inputs that need NO transform on load (every dgrad,
+// the whole decoder, all of inference).  Then operands can go HBM/L2 -> LDS
+// directly with `global_load_lds_dwordx4` (no VGPR round trip), which makes a
+// deep software pipeline cheap:
+//
+//   * STAGES ring slots of [BM + BNP rows][32 k] bf16, rows UNPADDED (64 B): the
+//     DMA writes wave-uniform-base + lane*16, i.e. 16 rows x 4 chunks per
+//     wave-instruction.  Bank conflicts of the ds_read_b128 fragment reads are
+//     removed by an XOR swizzle of the 16-byte chunk index with (row>>2)&3,
+//     applied on the SOURCE address of the DMA and again on the read.
+//   * out-of-range taps / rows / channels read a 64-byte zero page instead of
+//     being skipped, so every wave issues exactly LPS DMAs per stage and the
+//     counted `s_waitcnt vmcnt(LPS*(STAGES-2))` is exact.
+//   * one raw s_barrier per K step: [wait my DMAs of stage i] [barrier]
+//     [issue stage i+STAGES-1 into the slot read last step] [ds_read + MFMA].
+//     STAGES-1 K-steps of loads stay in flight across barriers.
+#pragma once
+#include "conv_igemm.h"
+
+__device__ __attribute__((aligned(64))) uint4 g_vinet_zero_page[4];
+// PRE variant: activations that are out of range must be zero AFTER relu(scale*x+shift).
+// They are fetched from a page of bf16 quiet NaNs: fma(NaN,s,b) = NaN and
+// v_max_f32(NaN, 0) = 0 (IEEE maxNum), so padding needs no per-element mask.
+__device__ __attribute__((aligned(64))) uint4 g_vinet_nan_page[4] = {
+    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu},
+    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}};
+
+VN_DEV uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+template <int MT, int NT, int WARPS_M, int WARPS_N, int STAGES, bool PRE = false>
+struct ConvDmaCfg {
+  static constexpr int BM = 16 * MT * WARPS_M;
+  static constexpr int BN = 16 * NT * WARPS_N;
+  static constexpr int BNP = (BN + 63) / 64 * 64;   // B rows in LDS (whole wave-instructions)
+  static constexpr int A_LOADS = BM / 64;
+  static constexpr int B_LOADS = BNP / 64;
+  static constexpr int LPS = A_LOADS + B_LOADS;      // DMAs per wave per stage
+  static constexpr int STAGE_BYTES = (BM + BNP) * 64;
+  static constexpr int WNC = NT * 16, EROW = WNC + 4;
+  static constexpr int AFF_BYTES = PRE ? 2 * 1024 * 4 : 0;   // scale[Kp], shift[Kp] (Kp <= 1024) behind the ring
+  static constexpr int KLOOP_BYTES = STAGES * STAGE_BYTES + AFF_BYTES;
+  static constexpr int EPI_BYTES = 4 * 16 * EROW * 4 + WARPS_M * BN * 2 * 4;
+  static constexpr int SMEM = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
+};
+
+template <int N> VN_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MT, int NT, int WARPS_M, int WARPS_N, int STAGES, bool PRE>
+__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
+  using Cfg = ConvDmaCfg<MT, NT, WARPS_M, WARPS_N, STAGES, PRE>;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, A_LOADS = Cfg::A_LOADS, B_LOADS = Cfg::B_LOADS;
+  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+  static_assert(STAGES >= 2 && Cfg::LPS * (STAGES - 2) <= 63, "vmcnt immediate range");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = wg % a.tilesN, tile_m = wg / a.tilesN;
+  const char* zero = (const char*)g_vinet_zero_page;
+  const char* apad = PRE ? (const char*)g_vinet_nan_page : zero;   // what out-of-range ACTIVATIONS read
+  float* aff = (float*)(smem + STAGES * Cfg::STAGE_BYTES);         // PRE: scale[0..Kp), shift at +1024
+  if constexpr (PRE) {
+    for (int c = tid; c < a.Kp; c += 256) {
+      const bool in = c < a.Cin;
+      aff[c] = in ? a.in_scale[c] : 0.f;
+      aff[1024 + c] = in ? a.in_shift[c] : 0.f;
+    }
+    __syncthreads();   // plain loads above are complete before any DMA is counted
+  }
+
+  // this lane's DMA role: row (lane>>2) of a 16-row group, LDS slot (lane&3);
+  // it fetches source chunk slot ^ swizzle(row)
+  const int lrow = lane >> 2;
+  const int src_chunk = (lane & 3) ^ ((lrow >> 2) & 3);
+
+  // ---- per-lane A rows (fixed across the K loop) -----------------------------
+  const char* a_ptr[A_LOADS];
+  int a_t[A_LOADS], a_h[A_LOADS], a_w[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int row = i * 64 + wave * 16 + lrow;
+    const int m = tile_m * BM + row;
+    if (m < a.M) {
+      const int wo = m % a.Wo;
+      const int t1 = m / a.Wo;
+      const int ho = t1 % a.Ho;
+      const int t2 = t1 / a.Ho;
+      const int to = t2 % a.To;
+      const int b = t2 / a.To;
+      a_t[i] = to * a.sT; a_h[i] = ho * a.sH; a_w[i] = wo * a.sW;
+      const long off = (long)b * a.sBx + ((long)(a_t[i] * a.Hi + a_h[i]) * a.Wi + a_w[i]) * (long)a.ldx + src_chunk * 8;
+      a_ptr[i] = a.x + off * 2;
+    } else {
+      a_ptr[i] = apad; a_t[i] = -(1 << 28); a_h[i] = 0; a_w[i] = 0;
+    }
+  }
+  // ---- per-lane B rows ----------------------------------------------------------
+  const char* b_ptr[B_LOADS];
+  unsigned b_ok[B_LOADS];
+#pragma unroll
+  for (int j = 0; j < B_LOADS; ++j) {
+    const int n = j * 64 + wave * 16 + lrow;
+    const int nn = tile_n * BN + n;
+    b_ok[j] = (unsigned)(n < BN) & (unsigned)(nn < a.Nw);
+    b_ptr[j] = a.w + ((long)(b_ok[j] ? nn : 0) * (long)a.Kp + src_chunk * 8) * 2;
+  }
+
+  const int cpt = a.Kp / 32;
+  const int nchunks = a.ntaps * cpt;
+  const long slice_bytes = (long)a.Nw * a.Kp * 2;
+
+  // issue state: K chunk `isu` = (tap isu_tap, channel offset isu_c)
+  int isu = 0, isu_tap = 0, isu_c = 0;
+  auto issue = [&](int slot) {
+    char* stage = smem + slot * Cfg::STAGE_BYTES;
+    if (isu < nchunks) {
+      const int4 tp = load_tap(a.taps, isu_tap);
+      const long tap_delta = (((long)(tp.x * a.Hi + tp.y) * a.Wi + tp.z) * (long)a.ldx + isu_c) * 2;
+      // branch-free source selection: every DMA must be ONE unconditional instruction per
+      // wave (a select lowered to divergent branches would issue it twice and break the
+      // vmcnt accounting)
+      const unsigned cin_ok = (unsigned)(isu_c + src_chunk * 8 < a.Cin);
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const int ti = a_t[i] + tp.x, hi = a_h[i] + tp.y, wi = a_w[i] + tp.z;
+        const unsigned ok = cin_ok & (unsigned)((unsigned)ti < (unsigned)a.Ti) & (unsigned)((unsigned)hi < (unsigned)a.Hi) &
+                            (unsigned)((unsigned)wi < (unsigned)a.Wi);
+        const char* src = apad + (((a_ptr[i] + tap_delta) - apad) & -(long)ok);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + (i * 64 + wave * 16) * 64), 16, 0, 0);
+      }
+      const long wdelta = (long)tp.w * slice_bytes + (long)isu_c * 2;
+#pragma unroll
+      for (int j = 0; j < B_LOADS; ++j) {
+        const char* src = zero + (((b_ptr[j] + wdelta) - zero) & -(long)b_ok[j]);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + (BM + j * 64 + wave * 16) * 64), 16, 0, 0);
+      }
+      isu_c += 32;
+      if (isu_c >= a.Kp) { isu_c = 0; ++isu_tap; }
+    } else {
+      // past the end: keep the DMA count per stage exact
+#pragma unroll
+      for (int i = 0; i < A_LOADS + B_LOADS; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)zero,
+                                         (__attribute__((address_space(3))) void*)(stage + (i * 64 + wave * 16) * 64), 16, 0, 0);
+    }
+    ++isu;
+  };
+
+  f32x4_v acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row (lane&15) of a 16-row group, k chunk (lane>>4), swizzled
+  const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) * 16);
+
+  int cmp_c = 0;   // channel offset of the chunk being computed (PRE)
+  auto compute = [&](int slot) {
+    const char* As = smem + slot * Cfg::STAGE_BYTES + (wm * MT * 16) * 64 + frag_off;
+    const char* Bs = smem + slot * Cfg::STAGE_BYTES + (BM + wn * NT * 16) * 64 + frag_off;
+    bf16x8_v af[MT], bfr[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8_v*)(As + i * 16 * 64);
+    if constexpr (PRE) {
+      // this lane's 8 k-elements are channels cmp_c + (lane>>4)*8 .. +7 in every fragment
+      const float* sp = aff + cmp_c + (lane >> 4) * 8;
+      const float4 s0 = *(const float4*)sp, s1 = *(const float4*)(sp + 4);
+      const float4 h0 = *(const float4*)(sp + 1024), h1 = *(const float4*)(sp + 1028);
+      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        union { bf16x8_v v; uint32_t u[4]; } q;
+        q.v = af[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = fmaxf(fmaf(__uint_as_float(q.u[e] << 16), sc[2 * e], sh[2 * e]), 0.f);
+          const float hi = fmaxf(fmaf(__uint_as_float(q.u[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), 0.f);
+          q.u[e] = cvt_pk_bf16(lo, hi);
+        }
+        af[i] = q.v;
+      }
+      cmp_c += 32;
+      if (cmp_c >= a.Kp) cmp_c = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8_v*)(Bs + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- pipeline ------------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue(s);
+  int slot = 0, fill = STAGES - 1;
+  for (int it = 0; it < nchunks; ++it) {
+    wait_vmcnt<Cfg::LPS*(STAGES - 2)>();      // my DMAs of stage `it` have landed
+    __builtin_amdgcn_s_barrier();              // everyone's have; everyone finished reading slot `fill`
+    asm volatile("" ::: "memory");
+    issue(fill);
+    compute(slot);
+    asm volatile("" ::: "memory");
+    slot = slot + 1 == STAGES ? 0 : slot + 1;
+    fill = fill + 1 == STAGES ? 0 : fill + 1;
+  }
+  wait_vmcnt<0>();                             // drain the tail DMAs before LDS is reused
+  __syncthreads();
+  conv_epilogue<MT, NT, WARPS_M, WARPS_N>(a, acc, smem, tile_m, tile_n);
+}
+
+template <int MT, int NT, int WM, int WN, int STAGES, bool PRE>
+static int launch_conv_dma_cfg(const ConvArgs& a, hipStream_t s) {
+  using Cfg = ConvDmaCfg<MT, NT, WM, WN, STAGES, PRE>;
+  auto kern = conv_dma_kernel<MT, NT, WM, WN, STAGES, PRE>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_dma): %s", hipGetErrorString(e)); return (int)e; }
+    attr_done[dev & 63] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(256), Cfg::SMEM, s, a);
+  return vn_launch_status("conv_dma");
+}

@@ -54,7 +54,125 @@ struct ConvCfg {
   static constexpr int SMEM = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
 };
 
-template <typename T> struct MmaAcc { f32x4_v v; };
+// ---- shared epilogue: per-channel affine, BN partial statistics, activation,
+//      LDS-transposed 4-channel vector stores, accumulate, arbitrary placement.
+//      Must be entered after a workgroup barrier (it reuses the K-loop LDS). ------
+template <int MT, int NT, int WARPS_M, int WARPS_N>
+VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem, int tile_m, int tile_n) {
+  constexpr int BM = 16 * MT * WARPS_M, BN = 16 * NT * WARPS_N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  constexpr int WNC = NT * 16, EROW = WNC + 4;
+  float* Ew = (float*)smem + wave * (16 * EROW);
+  float* red = (float*)smem + 4 * 16 * EROW;
+  const int m_wave = tile_m * BM + wm * MT * 16;
+  const int n_wave = tile_n * BN + wn * WNC;
+
+  {
+    float s_sum[NT], s_sq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n_wave + j * 16 + (lane & 15);
+      const bool nok = n < a.Nw;
+      const float sc = (a.out_scale && nok) ? a.out_scale[n] : 1.f;
+      const float sh = (a.out_shift && nok) ? a.out_shift[n] : 0.f;
+      float ss = 0.f, qq = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m_wave + i * 16 + (lane >> 4) * 4 + r;
+          float v = fmaf(acc[i][j][r], sc, sh);
+          if (a.stats && nok && m < a.M) { ss += v; qq += v * v; }
+          if (a.act == VINET_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == VINET_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+          acc[i][j][r] = v;
+        }
+      s_sum[j] = ss; s_sq[j] = qq;
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float ss = s_sum[j], qq = s_sq[j];
+        ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+        qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
+        if (lane < 16) {
+          const int col = wn * WNC + j * 16 + lane;
+          red[(wm * BN + col) * 2 + 0] = ss;
+          red[(wm * BN + col) * 2 + 1] = qq;
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ew[((lane >> 4) * 4 + r) * EROW + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    for (int e = lane; e < 16 * (WNC / 4); e += 64) {
+      const int rr = e / (WNC / 4), cc = (e % (WNC / 4)) * 4;
+      const int m = m_wave + i * 16 + rr;
+      const int n = n_wave + cc;
+      if (m < a.M && n < a.N) {
+        const float4 v = *(const float4*)&Ew[rr * EROW + cc];
+        const int wo = m % a.Wo;
+        const int t1 = m / a.Wo;
+        const int ho = t1 % a.Ho;
+        const int t2 = t1 / a.Ho;
+        const int to = t2 % a.To;
+        const int b = t2 / a.To;
+        const long off = (long)b * a.sBy +
+                         ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) *
+                             (long)a.ldy + n;
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (a.vec_ok) {
+          if (a.out_f32) {
+            float* dst = (float*)a.y + off;
+            if (a.accumulate) { const float4 q = *(const float4*)dst; o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
+            *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+            bf16_t* dst = (bf16_t*)a.y + off;
+            if (a.accumulate) {
+              const uint2 q = *(const uint2*)dst;
+              o[0] += __uint_as_float(q.x << 16); o[1] += __uint_as_float(q.x & 0xffff0000u);
+              o[2] += __uint_as_float(q.y << 16); o[3] += __uint_as_float(q.y & 0xffff0000u);
+            }
+            *(uint2*)dst = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+          }
+        } else {
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            if (n + e2 < a.N) {
+              if (a.out_f32) {
+                float* dst = (float*)a.y + off + e2;
+                *dst = a.accumulate ? *dst + o[e2] : o[e2];
+              } else {
+                bf16_t* dst = (bf16_t*)a.y + off + e2;
+                *dst = f2bf(a.accumulate ? bf2f(*dst) + o[e2] : o[e2]);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (a.stats && tid < BN) {
+    const int n = tile_n * BN + tid;
+    if (n < a.N) {
+      float ss = 0.f, qq = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < WARPS_M; ++w2) { ss += red[(w2 * BN + tid) * 2]; qq += red[(w2 * BN + tid) * 2 + 1]; }
+      a.stats[((long)tile_m * 2 + 0) * a.N + n] = ss;
+      a.stats[((long)tile_m * 2 + 1) * a.N + n] = qq;
+    }
+  }
+}
+
 
 template <typename T, int MT, int NT, int WARPS_M, int WARPS_N, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
@@ -103,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   auto load_tiles = [&](int it) {
     const int tap = it / cpt;
     const int c0 = (it - tap * cpt) * BK;
-    const int4 tp = a.taps[tap];
+    const int4 tp = load_tap(a.taps, tap);
     if constexpr (MODE == VINET_CONV_GENERIC) {
       const int c = c0 + g * EG;
       const bool cin_ok = c < a.Cin;
@@ -242,116 +360,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue -------------------------------------------------------------
-  constexpr int WNC = Cfg::WNC, EROW = Cfg::EROW;
-  float* Ew = (float*)smem + wave * (16 * EROW);
-  float* red = (float*)smem + 4 * 16 * EROW;
-  const int m_wave = tile_m * BM + wm * MT * 16;
-  const int n_wave = tile_n * BN + wn * WNC;
-
-  {
-    float s_sum[NT], s_sq[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n_wave + j * 16 + (lane & 15);
-      const bool nok = n < a.Nw;
-      const float sc = (a.out_scale && nok) ? a.out_scale[n] : 1.f;
-      const float sh = (a.out_shift && nok) ? a.out_shift[n] : 0.f;
-      float ss = 0.f, qq = 0.f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m_wave + i * 16 + (lane >> 4) * 4 + r;
-          float v = fmaf(acc[i][j][r], sc, sh);
-          if (a.stats && nok && m < a.M) { ss += v; qq += v * v; }
-          if (a.act == VINET_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == VINET_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-          acc[i][j][r] = v;
-        }
-      s_sum[j] = ss; s_sq[j] = qq;
-    }
-    if (a.stats) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float ss = s_sum[j], qq = s_sq[j];
-        ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
-        qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
-        if (lane < 16) {
-          const int col = wn * WNC + j * 16 + lane;
-          red[(wm * BN + col) * 2 + 0] = ss;
-          red[(wm * BN + col) * 2 + 1] = qq;
-        }
-      }
-    }
-  }
-
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ew[((lane >> 4) * 4 + r) * EROW + j * 16 + (lane & 15)] = acc[i][j][r];
-    __syncthreads();
-    for (int e = lane; e < 16 * (WNC / 4); e += 64) {
-      const int rr = e / (WNC / 4), cc = (e % (WNC / 4)) * 4;
-      const int m = m_wave + i * 16 + rr;
-      const int n = n_wave + cc;
-      if (m < a.M && n < a.N) {
-        const float4 v = *(const float4*)&Ew[rr * EROW + cc];
-        const int wo = m % a.Wo;
-        const int t1 = m / a.Wo;
-        const int ho = t1 % a.Ho;
-        const int t2 = t1 / a.Ho;
-        const int to = t2 % a.To;
-        const int b = t2 / a.To;
-        const long off = (long)b * a.sBy +
-                         ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) *
-                             (long)a.ldy + n;
-        float o[4] = {v.x, v.y, v.z, v.w};
-        if (a.vec_ok) {
-          if (a.out_f32) {
-            float* dst = (float*)a.y + off;
-            if (a.accumulate) { const float4 q = *(const float4*)dst; o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
-            *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
-            bf16_t* dst = (bf16_t*)a.y + off;
-            if (a.accumulate) {
-              const uint2 q = *(const uint2*)dst;
-              o[0] += __uint_as_float(q.x << 16); o[1] += __uint_as_float(q.x & 0xffff0000u);
-              o[2] += __uint_as_float(q.y << 16); o[3] += __uint_as_float(q.y & 0xffff0000u);
-            }
-            *(uint2*)dst = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-          }
-        } else {
-#pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) {
-            if (n + e2 < a.N) {
-              if (a.out_f32) {
-                float* dst = (float*)a.y + off + e2;
-                *dst = a.accumulate ? *dst + o[e2] : o[e2];
-              } else {
-                bf16_t* dst = (bf16_t*)a.y + off + e2;
-                *dst = f2bf(a.accumulate ? bf2f(*dst) + o[e2] : o[e2]);
-              }
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  if (a.stats && tid < BN) {
-    const int n = tile_n * BN + tid;
-    if (n < a.N) {
-      float ss = 0.f, qq = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < WARPS_M; ++w2) { ss += red[(w2 * BN + tid) * 2]; qq += red[(w2 * BN + tid) * 2 + 1]; }
-      a.stats[((long)tile_m * 2 + 0) * a.N + n] = ss;
-      a.stats[((long)tile_m * 2 + 1) * a.N + n] = qq;
-    }
-  }
+  conv_epilogue<MT, NT, WARPS_M, WARPS_N>(a, acc, smem, tile_m, tile_n);
 }
 
 // ---- host-side dispatch helpers ---------------------------------------------
@@ -362,6 +371,7 @@ struct ConvTile { int MT, NT, WM, WN; int BM() const { return 16 * MT * WM; } in
 ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N);
 int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
+int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t s);
 
 template <typename T, int MT, int NT, int WM, int WN, int MODE>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {

@@ -11,6 +11,8 @@
 // fp32 atomics into the caller-zeroed dw buffer.
 #include "common.h"
 
+extern int g_vinet_opt_wgrad_tr;
+
 struct WgradArgs {
   const char* x;
   const char* dy;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tile_c = blockIdx.x % a.tilesC, tile_n = blockIdx.x / a.tilesC;
-  const int4 tp = a.taps[blockIdx.y];
+  const int4 tp = load_tap(a.taps, blockIdx.y);
   const int chunk0 = blockIdx.z * a.chunks_per_split;
   int chunk1 = chunk0 + a.chunks_per_split;
   if (chunk1 > a.nchunks) chunk1 = a.nchunks;
@@ -270,9 +272,7 @@ extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   if (sk > 4096) sk = 4096;
   a.chunks_per_split = vn_div_up(a.nchunks, sk);
   a.splitK = vn_div_up(a.nchunks, a.chunks_per_split);
-  static int no_tr = -1;
-  if (no_tr < 0) { const char* e = getenv("VINET_WGRAD_NO_TR"); no_tr = (e && e[0] == '1') ? 1 : 0; }
-  a.use_tr = !no_tr;
+  a.use_tr = g_vinet_opt_wgrad_tr;
 
   dim3 grid(a.tilesN * a.tilesC, a.ntaps, a.splitK);
   hipStream_t s = (hipStream_t)stream;

@@ -445,9 +445,9 @@ def _param_grad(p):
 
 
 def _conv_kernel_name(ctx, d):
-    cfg = (C.c_int32 * 4)()
-    ctx.lib.vinet_conv3d_config(C.byref(d), cfg)
-    return "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>" % ("bf16" if d.dtype == BF16 else "float", cfg[0], cfg[1], cfg[2], cfg[3], d.mode)
+    buf = C.create_string_buffer(96)
+    ctx.lib.vinet_conv3d_kernel_name(C.byref(d), buf, 96)
+    return buf.value.decode() or "conv"
 
 
 def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n_pad=None):
