@@ -136,6 +136,7 @@ typedef struct VinetWgradDesc {
 } VinetWgradDesc;
 
 int vinet_conv3d_wgrad(const VinetWgradDesc* desc, void* stream);
+int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* desc, char* buf, int32_t n);
 
 /* fp32 torch-layout master weights [N][Cin][ntaps] -> packed compute weights.
  *  transpose == 0: out[t][n][c]       (Kp = pad32(Cin))   forward / wgrad layout
@@ -254,7 +255,8 @@ int vinet_bilinear_bwd(const void* x1, const void* x2, const void* dout, int32_t
 
 /* misc */
 /* Tuning / A-B switches (process-wide): "dma" (1 = use the LDS-DMA conv kernel where
- * legal, default 1), "wgrad_tr" (1 = hardware transpose reads in wgrad, default 1). */
+ * legal, default 1), "wgrad_tr" (1 = hardware transpose reads in the register-staged wgrad, default 1),
+ * "wgrad_dma" (1 = LDS-DMA multi-tap wgrad kernel where legal, default 1). */
 int vinet_set_option(const char* name, int32_t value);
 int vinet_fill_f32(float* p, int64_t n, float value, void* stream);
 int vinet_abi_version(void);

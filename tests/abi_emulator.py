@@ -140,6 +140,9 @@ class AbiEmulator:
     def vinet_conv3d_kernel_name(self, d, buf, n):
         return 0
 
+    def vinet_conv3d_wgrad_kernel_name(self, d, buf, n):
+        return 0
+
     def _taps(self, d):
         return np.ctypeslib.as_array((C.c_int32 * (4 * d.ntaps)).from_address(d.taps)).reshape(-1, 4)
 

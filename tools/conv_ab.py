@@ -54,6 +54,13 @@ def main():
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     variants = []
+    if args.wgrad:
+        for ln, lib in libs:
+            variants.append((ln + ":wdma", lib, dict(wgrad_dma=1), False))
+            variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1), True))
+            variants.append((ln + ":wold", lib, dict(wgrad_dma=0), False))
+            variants.append((ln + ":wold+pre", lib, dict(wgrad_dma=0), True))
+        libs = []
     for ln, lib in libs:
         variants.append((ln + ":dma", lib, dict(dma=1), False))
         variants.append((ln + ":dma+pre", lib, dict(dma=1), True))

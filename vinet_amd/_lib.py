@@ -56,6 +56,7 @@ SIGNATURES = {
     "vinet_conv3d_tile_m": [_PC],
     "vinet_conv3d_kernel_name": [_PC, C.c_char_p, _i32],
     "vinet_conv3d_wgrad": [_PW, _vp],
+    "vinet_conv3d_wgrad_kernel_name": [_PW, C.c_char_p, _i32],
     "vinet_pack_weights": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "vinet_unpack_wgrad": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "vinet_import_ncdhw": [_vp, _i64, _i64, _i64, _i64, _i64, _i32, _PT, _i32, _vp],

@@ -12,6 +12,9 @@
 #include "common.h"
 
 extern int g_vinet_opt_wgrad_tr;
+extern int g_vinet_opt_wgrad_dma;
+int vinet_launch_wgrad_dma(const VinetWgradDesc* d, hipStream_t s);
+int vinet_wgrad_dma_name(const VinetWgradDesc* d, char* buf, int n);
 
 struct WgradArgs {
   const char* x;
@@ -240,6 +243,19 @@ extern "C" int vinet_selftest_tr16(uint16_t* out_dev, void* stream) {
   return vn_launch_status("tr16_selftest");
 }
 
+static bool wgrad_use_dma(const VinetWgradDesc* d) {
+  const bool pre_ok = !d->pre.scale || (d->pre.relu && d->pre.shift);
+  return g_vinet_opt_wgrad_dma && d->dtype == VINET_BF16 && d->mode == VINET_CONV_GENERIC && pre_ok &&
+         !(d->pre.relu && !d->pre.scale);
+}
+
+extern "C" int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* d, char* buf, int32_t n) {
+  if (!d || !buf || n <= 0) return -1;
+  if (wgrad_use_dma(d)) return vinet_wgrad_dma_name(d, buf, n);
+  snprintf(buf, n, "conv_wgrad_kernel<%s,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", d->mode);
+  return 0;
+}
+
 extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   VN_CHECK_ARG(d != nullptr, "wgrad: null descriptor");
   VN_CHECK_ARG(d->dtype == VINET_F32 || d->dtype == VINET_BF16, "wgrad: bad dtype %d", d->dtype);
@@ -252,6 +268,7 @@ extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   if (d->mode == VINET_CONV_STEM) VN_CHECK_ARG(d->x.C == 4 && d->Kp == 32, "wgrad stem: x.C must be 4, Kp 32");
   else VN_CHECK_ARG(d->Kp >= d->x.C, "wgrad: Kp < Cin");
 
+  if (wgrad_use_dma(d)) return vinet_launch_wgrad_dma(d, (hipStream_t)stream);
   WgradArgs a;
   a.x = (const char*)d->x.ptr; a.dy = (const char*)d->dy.ptr; a.dw = d->dw; a.taps = (const int4*)d->taps;
   a.in_scale = d->pre.scale; a.in_shift = d->pre.shift; a.in_relu = d->pre.relu;

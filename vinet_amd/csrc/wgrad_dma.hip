@@ -1,0 +1,338 @@
+// Weight gradient, LDS-DMA multi-tap kernel (bf16, gfx950).
+//
+//   dw[slice_g][n][c] += sum_m dy[m][n] * pre(x[m (+) tap_g])[c]      for the TG taps of a group
+//
+// One workgroup (4 waves, 2x2) owns a TN x TC tile of (n, c), a group of up to
+// TG taps and a split-K range of voxel chunks (32 voxels each).  Per chunk the
+// dY tile is fetched ONCE and reused for every tap of the group (the 64x64
+// single-tap kernel re-streamed dY and X once per tap: 7x for the stem's
+// 7x1x1 conv); all TG x (TN x TC) accumulators live in registers.
+//
+//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 into a STAGES-slot
+//     ring ([32 voxel rows][TN or TC channels], rows unpadded); the 16-byte
+//     chunk index is XOR-swizzled with the row so the K-major fragment reads
+//     (ds_read_b64_tr_b16, hardware transpose) do not serialise on banks;
+//   * out-of-range sources read a zero page (dY, plain X) or a NaN page (X
+//     with a pending BN+ReLU: max(fma(NaN,s,b),0) == 0), so every wave issues
+//     exactly LPS DMAs per stage and the counted vmcnt wait is exact;
+//   * the pending affine is applied at fragment time: a B fragment holds 8
+//     voxels of ONE channel per lane, so scale/shift are two scalars per lane;
+//   * voxel index -> (b,t,h,w) uses multiply-high fast division.
+#include <type_traits>
+
+#include "common.h"
+
+// (device globals are per translation unit without -fgpu-rdc: own copies of the pad pages)
+__device__ __attribute__((aligned(64))) uint4 g_wg_zero_page[4];
+__device__ __attribute__((aligned(64))) uint4 g_wg_nan_page[4] = {
+    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu},
+    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}};
+
+struct FastDiv { uint32_t magic, shift, d; };
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f; f.d = d;
+  if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
+  uint32_t l = 0; while ((1u << l) < d) ++l;               // ceil(log2 d)
+  f.magic = (uint32_t)((((unsigned long long)1 << (31 + l)) / d) + 1);
+  f.shift = l - 1;
+  return f;
+}
+VN_DEV uint32_t fdiv(uint32_t m, const FastDiv& f) {          // exact for m < 2^31
+  return f.d <= 1 ? m : (__umulhi(m, f.magic) >> f.shift);
+}
+
+struct WgradDmaArgs {
+  const char* x;
+  const char* dy;
+  float* dw;
+  const int4* taps;
+  const float* in_scale;
+  const float* in_shift;
+  int Ti, Hi, Wi, Cin, ldx;
+  long sBx;
+  int To, Ho, Wo, N, ldy;
+  long sBy;
+  int sT, sH, sW;
+  int ntaps, Kp, M;
+  int tilesN, tilesC, splitK, chunks_per_split, nchunks;
+  FastDiv dW, dH, dT;
+};
+
+template <int N_> VN_DEV void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+VN_DEV uint32_t wg_cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+template <int TN, int TC, int TG, int STAGES, bool PRE>
+struct WgCfg {
+  static constexpr int KV = 32;
+  static constexpr int D_BYTES = KV * TN * 2, X_BYTES = KV * TC * 2;
+  static constexpr int STAGE_BYTES = D_BYTES + TG * X_BYTES;
+  static constexpr int D_IPW = (TN / 64);          // DMA instructions per wave for the dY tile (KV*TN*2/1024/4)
+  static constexpr int X_IPW = (TC / 64);
+  static constexpr int LPS = D_IPW + TG * X_IPW;
+  static constexpr int SMEM = STAGES * STAGE_BYTES;
+  static constexpr int MT = TN / 32, NT = TC / 32;  // 16x16 fragments per wave (2x2 waves)
+};
+
+// tile row r (0..31) of a [32][TW channels] bf16 tile, 16-byte chunk ch -> byte offset with swizzle
+template <int TW> VN_DEV int wg_swz(int r) { return TW == 64 ? (((r >> 1) & 1) << 1) : ((r & 3) << 1); }
+
+template <int TN, int TC, int TG, int STAGES, bool PRE>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs a) {
+  using Cfg = WgCfg<TN, TC, TG, STAGES, PRE>;
+  constexpr int MT = Cfg::MT, NT = Cfg::NT, KV = 32;
+  static_assert(Cfg::LPS * (STAGES - 2) <= 63 && STAGES >= 2, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile_c = blockIdx.x % a.tilesC, tile_n = blockIdx.x / a.tilesC;
+  const int tap0 = blockIdx.y * TG;
+  const int chunk0 = blockIdx.z * a.chunks_per_split;
+  int chunk1 = chunk0 + a.chunks_per_split;
+  if (chunk1 > a.nchunks) chunk1 = a.nchunks;
+  const int nloc = chunk1 - chunk0;
+  const int n0 = tile_n * TN, c0 = tile_c * TC;
+  const char* zero = (const char*)g_wg_zero_page;
+  const char* xpad = PRE ? (const char*)g_wg_nan_page : zero;
+
+  // taps of this group (scalar registers); invalid ones are flagged
+  int4 tp[TG];
+  bool tap_ok[TG];
+#pragma unroll
+  for (int g = 0; g < TG; ++g) {
+    tap_ok[g] = tap0 + g < a.ntaps;
+    tp[g] = load_tap(a.taps, tap_ok[g] ? tap0 + g : tap0);
+  }
+
+  // DMA roles.  dY tile: rows of TN*2 bytes; X tiles: rows of TC*2 bytes.
+  constexpr int D_CPR = TN * 2 / 16, D_RPI = 64 / D_CPR;   // chunks per row, rows per wave-instruction
+  constexpr int X_CPR = TC * 2 / 16, X_RPI = 64 / X_CPR;
+  const int d_lr = lane / D_CPR, d_ch = lane % D_CPR;
+  const int x_lr = lane / X_CPR, x_ch = lane % X_CPR;
+
+  int isu = 0;   // local chunk counter being issued
+  auto issue = [&](int slot) {
+    char* stage = smem + slot * Cfg::STAGE_BYTES;
+    const bool live = isu < nloc;
+    const int mbase = (chunk0 + isu) * KV;
+    // ---- dY tile ----
+#pragma unroll
+    for (int j = 0; j < Cfg::D_IPW; ++j) {
+      const int q = wave + 4 * j;                 // wave-instruction index within the tile
+      const int r = q * D_RPI + d_lr;             // tile row = voxel within the chunk
+      const int m = mbase + r;
+      const uint32_t t1 = fdiv((uint32_t)m, a.dW);
+      const int wo = m - (int)t1 * a.Wo;
+      const uint32_t t2 = fdiv(t1, a.dH);
+      const int ho = (int)t1 - (int)t2 * a.Ho;
+      const uint32_t b = fdiv(t2, a.dT);
+      const int to = (int)t2 - (int)b * a.To;
+      const int sch = d_ch ^ wg_swz<TN>(r);
+      const int n = n0 + sch * 8;
+      const unsigned ok = (unsigned)live & (unsigned)(m < a.M) & (unsigned)(n < a.N);
+      const char* p = a.dy + ((long)b * a.sBy + ((long)(to * a.Ho + ho) * a.Wo + wo) * (long)a.ldy + n) * 2;
+      const char* src = zero + ((p - zero) & -(long)ok);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + q * 1024), 16, 0, 0);
+    }
+    // ---- X tiles, one per tap of the group ----
+#pragma unroll
+    for (int j = 0; j < Cfg::X_IPW; ++j) {
+      const int q = wave + 4 * j;
+      const int r = q * X_RPI + x_lr;
+      const int m = mbase + r;
+      const uint32_t t1 = fdiv((uint32_t)m, a.dW);
+      const int wo = m - (int)t1 * a.Wo;
+      const uint32_t t2 = fdiv(t1, a.dH);
+      const int ho = (int)t1 - (int)t2 * a.Ho;
+      const uint32_t b = fdiv(t2, a.dT);
+      const int to = (int)t2 - (int)b * a.To;
+      const int sch = x_ch ^ wg_swz<TC>(r);
+      const int c = c0 + sch * 8;
+      const unsigned rowok = (unsigned)live & (unsigned)(m < a.M) & (unsigned)(c < a.Cin);
+      const long base = (long)b * a.sBx + c;
+#pragma unroll
+      for (int g = 0; g < TG; ++g) {
+        const int ti = to * a.sT + tp[g].x, hi = ho * a.sH + tp[g].y, wi = wo * a.sW + tp[g].z;
+        const unsigned ok = rowok & (unsigned)tap_ok[g] & (unsigned)((unsigned)ti < (unsigned)a.Ti) &
+                            (unsigned)((unsigned)hi < (unsigned)a.Hi) & (unsigned)((unsigned)wi < (unsigned)a.Wi);
+        const char* p = a.x + (base + ((long)(ti * a.Hi + hi) * a.Wi + wi) * (long)a.ldx) * 2;
+        const char* src = xpad + ((p - xpad) & -(long)ok);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + Cfg::D_BYTES + g * Cfg::X_BYTES + q * 1024), 16, 0, 0);
+      }
+    }
+    ++isu;
+  };
+
+  // per-lane scale/shift of the channels its B fragments hold
+  float sc[NT], sh[NT];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int c = c0 + wn * (TC / 2) + j * 16 + (lane & 15);
+      sc[j] = c < a.Cin ? a.in_scale[c] : 0.f;
+      sh[j] = c < a.Cin ? a.in_shift[c] : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // plain loads done before DMAs are counted
+  }
+
+  f32x4_v acc[TG][MT][NT];
+#pragma unroll
+  for (int g = 0; g < TG; ++g)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[g][i][j] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+
+  // K-major fragment (8 voxels x 1 channel per lane) of a [32][TW] tile by two transpose reads
+  auto frag = [&](const char* tile, int col0, auto twc) -> bf16x8_v {
+    constexpr int TW = decltype(twc)::value;
+    union { bf16x8_v v; s16x4_v h[2]; } u;
+    const int p = lane & 15;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int krow = (lane >> 4) * 8 + h * 4 + (p >> 2);
+      const int col = col0 + (p & 3) * 4;                       // element column
+      const int ch = (col >> 3) ^ wg_swz<TW>(krow);             // swizzled 16-byte chunk
+      const char* src = tile + krow * (TW * 2) + ch * 16 + (col & 7) * 2;
+      u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)src);
+    }
+    return u.v;
+  };
+
+  auto compute = [&](int slot) {
+    const char* stage = smem + slot * Cfg::STAGE_BYTES;
+    bf16x8_v af[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = frag(stage, wm * (TN / 2) + i * 16, std::integral_constant<int, TN>());
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {
+      const char* xt = stage + Cfg::D_BYTES + g * Cfg::X_BYTES;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bf16x8_v bf = frag(xt, wn * (TC / 2) + j * 16, std::integral_constant<int, TC>());
+        if constexpr (PRE) {
+          union { bf16x8_v v; uint32_t w[4]; } q;
+          q.v = bf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = fmaxf(fmaf(__uint_as_float(q.w[e] << 16), sc[j], sh[j]), 0.f);
+            const float hi = fmaxf(fmaf(__uint_as_float(q.w[e] & 0xffff0000u), sc[j], sh[j]), 0.f);
+            q.w[e] = wg_cvt_pk_bf16(lo, hi);
+          }
+          bf = q.v;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          acc[g][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[g][i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- pipeline (same scheme as conv_dma_kernel) ----------------------------------
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue(s);
+  int slot = 0, fill = STAGES - 1;
+  for (int it = 0; it < nloc; ++it) {
+    wg_wait_vmcnt<Cfg::LPS*(STAGES - 2)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(fill);
+    compute(slot);
+    asm volatile("" ::: "memory");
+    slot = slot + 1 == STAGES ? 0 : slot + 1;
+    fill = fill + 1 == STAGES ? 0 : fill + 1;
+  }
+  wg_wait_vmcnt<0>();
+
+#pragma unroll
+  for (int g = 0; g < TG; ++g) {
+    if (!tap_ok[g]) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wm * (TN / 2) + i * 16 + (lane >> 4) * 4 + r;
+          const int c = c0 + wn * (TC / 2) + j * 16 + (lane & 15);
+          if (n < a.N && c < a.Kp) {
+            float* dst = a.dw + ((long)tp[g].w * a.N + n) * (long)a.Kp + c;
+            if (a.splitK > 1) atomicAdd(dst, acc[g][i][j][r]);
+            else *dst = acc[g][i][j][r];
+          }
+        }
+  }
+}
+
+template <int TN, int TC, int TG, int STAGES, bool PRE>
+static int launch_wg(WgradDmaArgs& a, hipStream_t s) {
+  using Cfg = WgCfg<TN, TC, TG, STAGES, PRE>;
+  auto kern = conv_wgrad_dma_kernel<TN, TC, TG, STAGES, PRE>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(wgrad_dma): %s", hipGetErrorString(e)); return (int)e; }
+    attr_done[dev & 63] = true;
+  }
+  a.tilesN = vn_div_up(a.N, TN);
+  a.tilesC = vn_div_up(a.Cin, TC);
+  const int groups = vn_div_up(a.ntaps, TG);
+  a.nchunks = vn_div_up(a.M, 32);
+  const long base_blocks = (long)a.tilesN * a.tilesC * groups;
+  long sk = (1024 + base_blocks - 1) / base_blocks;        // ~4 workgroups per CU
+  // every split adds TG*TN*TC fp32 atomics: keep at least 32 chunks (1024 voxels) of work behind them
+  if (sk > a.nchunks / 32) sk = a.nchunks / 32;
+  if (sk < 1) sk = 1;
+  if (sk > 2048) sk = 2048;
+  a.chunks_per_split = vn_div_up(a.nchunks, sk);
+  a.splitK = vn_div_up(a.nchunks, a.chunks_per_split);
+  hipLaunchKernelGGL(kern, dim3(a.tilesN * a.tilesC, groups, a.splitK), dim3(256), Cfg::SMEM, s, a);
+  return vn_launch_status("conv_wgrad_dma");
+}
+
+// pick (tile, taps per group) from the conv geometry
+static const char* wg_pick(int N, int Cin, int ntaps, int* tn, int* tg) {
+  if (ntaps == 1) { *tn = (N >= 256 && Cin >= 256) ? 128 : 64; *tg = 1; }
+  else if (ntaps % 9 == 0) { *tn = 64; *tg = 9; }
+  else if (ntaps == 7) { *tn = 64; *tg = 7; }
+  else if (ntaps % 3 == 0) { *tn = 64; *tg = 3; }
+  else if (ntaps % 2 == 0) { *tn = 64; *tg = 2; }
+  else { *tn = 64; *tg = 1; }
+  return nullptr;
+}
+
+int vinet_wgrad_dma_name(const VinetWgradDesc* d, char* buf, int n) {
+  int tn, tg;
+  wg_pick(d->dy.C, d->x.C, d->ntaps, &tn, &tg);
+  snprintf(buf, n, "conv_wgrad_dma_kernel<%d,%d,%d,%s>", tn, tn, tg, d->pre.scale ? "pre" : "plain");
+  return 0;
+}
+
+int vinet_launch_wgrad_dma(const VinetWgradDesc* d, hipStream_t s) {
+  WgradDmaArgs a;
+  a.x = (const char*)d->x.ptr; a.dy = (const char*)d->dy.ptr; a.dw = d->dw; a.taps = (const int4*)d->taps;
+  a.in_scale = d->pre.scale; a.in_shift = d->pre.shift;
+  a.Ti = d->x.T; a.Hi = d->x.H; a.Wi = d->x.W; a.Cin = d->x.C; a.ldx = d->x.ld; a.sBx = d->x.sB;
+  a.To = d->dy.T; a.Ho = d->dy.H; a.Wo = d->dy.W; a.N = d->dy.C; a.ldy = d->dy.ld; a.sBy = d->dy.sB;
+  a.sT = d->sT; a.sH = d->sH; a.sW = d->sW;
+  a.ntaps = d->ntaps; a.Kp = d->Kp;
+  a.M = (int)((long)d->dy.B * d->dy.T * d->dy.H * d->dy.W);
+  a.dW = make_fastdiv(a.Wo); a.dH = make_fastdiv(a.Ho); a.dT = make_fastdiv(a.To);
+  int tn, tg;
+  wg_pick(a.N, a.Cin, a.ntaps, &tn, &tg);
+  const bool pre = d->pre.scale != nullptr;
+#define WG(TN_, TG_, ST_) \
+  if (tn == TN_ && tg == TG_) return pre ? launch_wg<TN_, TN_, TG_, ST_, true>(a, s) : launch_wg<TN_, TN_, TG_, ST_, false>(a, s);
+  WG(128, 1, 3) WG(64, 1, 3) WG(64, 2, 3) WG(64, 3, 3) WG(64, 7, 2) WG(64, 9, 2)
+#undef WG
+  vinet_set_error("wgrad dma: no kernel for tile %d taps/group %d", tn, tg);
+  return -1;
+}

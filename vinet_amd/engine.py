@@ -33,6 +33,10 @@ EG = {F32: 4, BF16: 8}          # elements per 16 bytes
 
 _DEFAULT_DTYPE = BF16
 _WEIGHTS_EPOCH = 0
+# Weight gradients are off the backward critical path (only the optimizer consumes them):
+# they run on a second HIP stream, concurrently with the dgrad / BN-backward chain.
+WGRAD_SIDE_STREAM = True
+_SIDE_STREAMS = {}
 
 
 def set_default_dtype(name):
@@ -240,9 +244,22 @@ class Ctx:
         if self.tape is not None:
             self.tape.append(fn)
 
+    def side_stream(self):
+        """second stream of this device (None on the CPU test double)"""
+        if not WGRAD_SIDE_STREAM or self.device.type != "cuda":
+            return None
+        st = _SIDE_STREAMS.get(self.device.index)
+        if st is None:
+            st = _SIDE_STREAMS[self.device.index] = torch.cuda.Stream(self.device)
+        return st
+
     def run_backward(self):
+        self.side_used = False
         for fn in reversed(self.tape):
             fn()
+        if getattr(self, "side_used", False):
+            # the optimizer (and every buffer release that follows) is ordered after the side stream
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream())
         self.tape = []
 
 
@@ -450,6 +467,12 @@ def _conv_kernel_name(ctx, d):
     return buf.value.decode() or "conv"
 
 
+def _wgrad_kernel_name(ctx, wd):
+    buf = C.create_string_buffer(96)
+    ctx.lib.vinet_conv3d_wgrad_kernel_name(C.byref(wd), buf, 96)
+    return buf.value.decode() or "wgrad"
+
+
 def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n_pad=None):
     """x -> conv (-> BN) (-> act).  Returns the output Act.
 
@@ -541,6 +564,14 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     return res
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
     out = res.v
     dz = res.grad_view()
@@ -581,28 +612,39 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         # channels modulo N leaves the real sums untouched
         assert Ny % plan.N == 0 and (Ny == plan.N or plan.N == 1)
         ctx.call("vinet_channel_sum", C.byref(dy.ct()), dy.dt, ws.data_ptr(), plan.N, gb.data_ptr(), 1, ctx.stream)
-    # ---- weight gradient ---------------------------------------------------------
+    # ---- weight gradient (side stream) ---------------------------------------------
     if plan.weight.requires_grad:
-        taps, ntaps = plan.fwd_taps(ctx.device)
-        kp = plan.kp(False)
-        nsl = 7 if plan.stem else plan.ntaps
-        dw = ctx.f32(nsl * Ny * kp, zero=True)
-        wd = L.CWgradDesc()
-        wd.dtype, wd.mode = ctx.dt, (L.CONV_STEM if plan.stem else L.CONV_GENERIC)
-        wd.x, wd.dy = x.v.ct(), dy.ct()
-        wd.sT, wd.sH, wd.sW = plan.s
-        wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), kp
-        wd.pre = x.affine()
-        es = ESIZE[ctx.dt]
-        ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
-                 tag="conv_wgrad_kernel<%s,%d> | wgrad %s" % ("bf16" if ctx.dt == BF16 else "float", wd.mode, plan.site(x.v)),
-                 work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
-                           bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
-        if Ny != plan.N:
-            assert plan.ntaps == 1, "channel-padded outputs are only supported for 1x1x1 convs"
-        gw = _param_grad(plan.weight)
-        ctx.call("vinet_unpack_wgrad", dw.data_ptr(), plan.N, plan.Cin, plan.ntaps, 1 if plan.stem else 0, 1,
-                 gw.data_ptr(), ctx.stream)
+        side = ctx.side_stream()
+        main_ptr = ctx.stream
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(ctx.device))   # dy (and everything before it) is ready
+            ctx.side_used = True
+        with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+            if side is not None:
+                ctx.stream = side.cuda_stream
+            try:
+                taps, ntaps = plan.fwd_taps(ctx.device)
+                kp = plan.kp(False)
+                nsl = 7 if plan.stem else plan.ntaps
+                dw = ctx.f32(nsl * Ny * kp, zero=True)
+                wd = L.CWgradDesc()
+                wd.dtype, wd.mode = ctx.dt, (L.CONV_STEM if plan.stem else L.CONV_GENERIC)
+                wd.x, wd.dy = x.v.ct(), dy.ct()
+                wd.sT, wd.sH, wd.sW = plan.s
+                wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), kp
+                wd.pre = x.affine()
+                es = ESIZE[ctx.dt]
+                ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
+                         tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
+                         work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
+                                   bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
+                if Ny != plan.N:
+                    assert plan.ntaps == 1, "channel-padded outputs are only supported for 1x1x1 convs"
+                gw = _param_grad(plan.weight)
+                ctx.call("vinet_unpack_wgrad", dw.data_ptr(), plan.N, plan.Cin, plan.ntaps, 1 if plan.stem else 0, 1,
+                         gw.data_ptr(), ctx.stream)
+            finally:
+                ctx.stream = main_ptr
     # ---- data gradient -------------------------------------------------------------
     if x.needs_grad:
         xv = x.v
@@ -647,7 +689,10 @@ def maxpool_forward(ctx, x, k, s, p, dst=None):
     pd = L.CPoolDesc(xv.dt, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
     rec = ctx.recording and x.needs_grad
     am = torch.empty(out.nvox * out.C, dtype=torch.uint8, device=xv.device) if rec else None
-    ctx.call("vinet_maxpool3d", C.byref(pd), C.byref(xv.ct()), x.affine(), C.byref(out.ct()), _ptr(am), ctx.stream)
+    ptag = "maxpool k%dx%dx%d s%dx%dx%d C%d in%dx%dx%dx%d" % (k + s + (xv.C, xv.B, xv.T, xv.H, xv.W))
+    es = ESIZE[xv.dt]
+    ctx.call("vinet_maxpool3d", C.byref(pd), C.byref(xv.ct()), x.affine(), C.byref(out.ct()), _ptr(am), ctx.stream,
+             tag="maxpool_fwd_kernel | " + ptag, work=dict(flops=0.0, bytes=float((xv.nvox + out.nvox) * xv.C * es)))
     dst.needs_grad = x.needs_grad
     if rec:
         def bwd():
@@ -656,7 +701,8 @@ def maxpool_forward(ctx, x, k, s, p, dst=None):
                 raise RuntimeError("maxpool backward expects a dense output gradient")
             dx = x.grad_view()
             ctx.call("vinet_maxpool3d_bwd", C.byref(pd), C.byref(dy.ct()), am.data_ptr(), C.byref(dx.ct()),
-                     1 if x.is_grad_ready() else 0, ctx.stream)
+                     1 if x.is_grad_ready() else 0, ctx.stream, tag="maxpool_bwd_kernel | " + ptag,
+                     work=dict(flops=0.0, bytes=float((xv.nvox + out.nvox) * xv.C * es + out.nvox * xv.C)))
             x.mark_grad_ready()
         ctx.record(bwd)
     return dst
