@@ -300,26 +300,42 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(TView x, TView dz, 
     if (r < R) {
       float4 mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
       if (MODE == 1) { mu = *(const float4*)(mean + q * 4); is = *(const float4*)(invstd + q * 4); }
-      for (long v = v0 + r; v < v1; v += R) {
-        int b, t, h, w;
-        decode_vox(x, v, b, t, h, w);
-        const float4 xv = ldq<T>((const T*)x.p + vox_off(x, b, t, h, w) + q * 4);
-        if (MODE == 0) {
-          s[0] += xv.x; s[1] += xv.y; s[2] += xv.z; s[3] += xv.w;
-          p[0] += xv.x * xv.x; p[1] += xv.y * xv.y; p[2] += xv.z * xv.z; p[3] += xv.w * xv.w;
-        } else {
-          float4 g = ldq<T>((const T*)dz.p + vox_off(dz, b, t, h, w) + q * 4);
-          if (fwd.relu) {
-            Affine na = fwd; na.relu = 0;
-            const float4 z = affine4(xv, na, q * 4);
-            if (!(z.x > 0.f)) g.x = 0.f;
-            if (!(z.y > 0.f)) g.y = 0.f;
-            if (!(z.z > 0.f)) g.z = 0.f;
-            if (!(z.w > 0.f)) g.w = 0.f;
+      constexpr int U = 4;   // independent voxels per iteration: 2*U loads in flight per lane
+      for (long vb = v0 + r; vb < v1; vb += (long)R * U) {
+        float4 xv[U], gv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long v = vb + (long)u * R;
+          ok[u] = v < v1;
+          xv[u] = make_float4(0, 0, 0, 0); gv[u] = make_float4(0, 0, 0, 0);
+          if (ok[u]) {
+            int b, t, h, w;
+            decode_vox(x, v, b, t, h, w);
+            xv[u] = ldq<T>((const T*)x.p + vox_off(x, b, t, h, w) + q * 4);
+            if (MODE == 1) gv[u] = ldq<T>((const T*)dz.p + vox_off(dz, b, t, h, w) + q * 4);
           }
-          s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
-          p[0] += g.x * (xv.x - mu.x) * is.x; p[1] += g.y * (xv.y - mu.y) * is.y;
-          p[2] += g.z * (xv.z - mu.z) * is.z; p[3] += g.w * (xv.w - mu.w) * is.w;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!ok[u]) continue;
+          if (MODE == 0) {
+            s[0] += xv[u].x; s[1] += xv[u].y; s[2] += xv[u].z; s[3] += xv[u].w;
+            p[0] += xv[u].x * xv[u].x; p[1] += xv[u].y * xv[u].y; p[2] += xv[u].z * xv[u].z; p[3] += xv[u].w * xv[u].w;
+          } else {
+            float4 g = gv[u];
+            if (fwd.relu) {
+              Affine na = fwd; na.relu = 0;
+              const float4 z = affine4(xv[u], na, q * 4);
+              if (!(z.x > 0.f)) g.x = 0.f;
+              if (!(z.y > 0.f)) g.y = 0.f;
+              if (!(z.z > 0.f)) g.z = 0.f;
+              if (!(z.w > 0.f)) g.w = 0.f;
+            }
+            s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+            p[0] += g.x * (xv[u].x - mu.x) * is.x; p[1] += g.y * (xv[u].y - mu.y) * is.y;
+            p[2] += g.z * (xv[u].z - mu.z) * is.z; p[3] += g.w * (xv[u].w - mu.w) * is.w;
+          }
         }
       }
     }
@@ -552,12 +568,81 @@ __global__ void maxpool_fwd_kernel(PoolP p, TView x, Affine pre, TView y, uint8_
   if (argmax) *(uint32_t*)(argmax + vox * y.C + q * 4) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
 }
 
+// kT == 3, sT == 1, pT == 1 (the Inception branch-3 pools, model_utils.py:178): one thread
+// walks T for a fixed output (h,w), keeps the maxima of the last three (kH x kW) planes and
+// so reads kH*kW instead of 3*kH*kW inputs per output.  Same first-max tie rule: planes in
+// t order, (h,w) scan order inside a plane, strict comparisons.
+template <typename T>
+__global__ void maxpool_tslide_kernel(PoolP p, TView x, Affine pre, TView y, uint8_t* __restrict__ argmax, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Q = y.C / 4;
+  const int q = (int)(i % Q);
+  long r = i / Q;
+  const int wo = (int)(r % y.W); r /= y.W;
+  const int ho = (int)(r % y.H);
+  const int b = (int)(r / y.H);
+  float pm[3][4];
+  int pa[3][4];
+  const int khw = p.kH * p.kW;
+  // plane tp feeds outputs tp-1, tp, tp+1; output t is complete once plane t+1 is in
+  for (int tp = 0; tp <= x.T; ++tp) {
+    const int slot = tp % 3;
+    if (tp < x.T) {
+      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int bi[4] = {0, 0, 0, 0};
+      for (int kh = 0; kh < p.kH; ++kh) {
+        const int h = ho * p.sH - p.pH + kh;
+        if ((unsigned)h >= (unsigned)x.H) continue;
+        for (int kw = 0; kw < p.kW; ++kw) {
+          const int w = wo * p.sW - p.pW + kw;
+          if ((unsigned)w >= (unsigned)x.W) continue;
+          float4 v = ldq<T>((const T*)x.p + vox_off(x, b, tp, h, w) + q * 4);
+          v = affine4(v, pre, q * 4);
+          const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (f[e] > best[e] || (f[e] != f[e] && best[e] == best[e])) { best[e] = f[e]; bi[e] = kh * p.kW + kw; }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pm[slot][e] = best[e]; pa[slot][e] = bi[e]; }
+    }
+    const int to = tp - 1;
+    if (to < 0) continue;
+    float o[4];
+    int oi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = -INFINITY; oi[e] = 0; }
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const int t = to - 1 + kt;
+      if (t < 0 || t >= x.T) continue;
+      const int sl = t % 3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (pm[sl][e] > o[e] || (pm[sl][e] != pm[sl][e] && o[e] == o[e])) { o[e] = pm[sl][e]; oi[e] = kt * khw + pa[sl][e]; }
+    }
+    stq<T>((T*)y.p + vox_off(y, b, to, ho, wo) + q * 4, make_float4(o[0], o[1], o[2], o[3]));
+    if (argmax) {
+      const long ovox = (((long)b * y.T + to) * y.H + ho) * y.W + wo;
+      *(uint32_t*)(argmax + ovox * y.C + q * 4) = (uint32_t)oi[0] | ((uint32_t)oi[1] << 8) | ((uint32_t)oi[2] << 16) | ((uint32_t)oi[3] << 24);
+    }
+  }
+}
+
 extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, VinetAffine pre, const VinetTensor* y,
                                uint8_t* argmax, void* stream) {
   VN_CHECK_ARG(d && x && y && quad_ok(*x, esize(d->dtype)) && quad_ok(*y, esize(d->dtype)) && x->C == y->C && x->B == y->B,
                "maxpool3d: bad views");
   VN_CHECK_ARG(d->kT * d->kH * d->kW <= 255 && d->kT > 0 && d->kH > 0 && d->kW > 0, "maxpool3d: window too large");
   const PoolP p = {d->kT, d->kH, d->kW, d->sT, d->sH, d->sW, d->pT, d->pH, d->pW};
+  if (d->kT == 3 && d->sT == 1 && d->pT == 1 && y->T == x->T && x->T >= 2) {
+    const long cols = (long)y->B * y->H * y->W * (y->C / 4);
+    DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_tslide_kernel<T>, dim3(ew_grid(cols)), dim3(256), 0,
+                                               (hipStream_t)stream, p, make_view(*x), make_affine(pre), make_view(*y), argmax, cols);)
+    return vn_launch_status("maxpool3d(tslide)");
+  }
   const long total = view_voxels(*y) * (y->C / 4);
   DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
                                              (hipStream_t)stream, p, make_view(*x), make_affine(pre), make_view(*y), argmax, total);)
@@ -592,12 +677,15 @@ __global__ void maxpool_bwd_kernel(PoolP p, TView dy, const uint8_t* __restrict_
         const uint32_t tap = (uint32_t)((kt * p.kH + kh) * p.kW + kw);
         const long ovox = (((long)b * dy.T + to) * dy.H + ho) * dy.W + wo;
         const uint32_t am = *(const uint32_t*)(argmax + ovox * dy.C + q * 4);
-        if (am == 0xffffffffu) continue;
+        // a window routes its gradient to exactly one of its taps: most candidates do not match,
+        // and then dy is not read at all (zero-byte test on am ^ tap-in-every-byte)
+        const uint32_t xr = am ^ (tap * 0x01010101u);
+        if (!((xr - 0x01010101u) & ~xr & 0x80808080u)) continue;
         const float4 d = ldq<T>((const T*)dy.p + vox_off(dy, b, to, ho, wo) + q * 4);
-        if ((am & 0xff) == tap) g[0] += d.x;
-        if (((am >> 8) & 0xff) == tap) g[1] += d.y;
-        if (((am >> 16) & 0xff) == tap) g[2] += d.z;
-        if (((am >> 24) & 0xff) == tap) g[3] += d.w;
+        if ((xr & 0xffu) == 0) g[0] += d.x;
+        if ((xr & 0xff00u) == 0) g[1] += d.y;
+        if ((xr & 0xff0000u) == 0) g[2] += d.z;
+        if ((xr & 0xff000000u) == 0) g[3] += d.w;
       }
     }
   }

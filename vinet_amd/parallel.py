@@ -19,13 +19,15 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
-    device = torch.device("cuda:%d" % local) if use_cuda else torch.device("cpu")
+    # (local % device_count only matters for functional tests that oversubscribe one GPU)
+    device = torch.device("cuda:%d" % (local % torch.cuda.device_count())) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("VINET_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local, device
 
 
