@@ -130,3 +130,20 @@ def test_avinet_fp32():
     d = MC.close(y, z["y"], 1e-4, "avinet map")
     assert int(y.reshape(-1).argmax()) == meta["argmax"]
     _note("avinet_fp32", dict(max_abs=d, top2_gap=meta["top2_gap"]))
+
+
+def test_graphed_inference_matches_eager():
+    """hipGraph replay of the forward == eager forward, and survives new inputs"""
+    from vinet_amd import model as VM
+    from vinet_amd.graph import GraphedInference
+    E.set_default_dtype("bf16")
+    m = VM.VideoSaliencyModel(num_clips=8).eval()
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 3))
+    m = m.to(DEV)
+    x1 = synth.clip(1, 8, 96, 192, 1).to(DEV).permute(0, 2, 1, 3, 4).contiguous()
+    x2 = synth.clip(1, 8, 96, 192, 2).to(DEV).permute(0, 2, 1, 3, 4).contiguous()
+    with torch.no_grad():
+        e1, e2 = m(x1).clone(), m(x2).clone()
+    g = GraphedInference(m, x1)
+    assert torch.equal(g(x2), e2)
+    assert torch.equal(g(x1), e1)

@@ -49,11 +49,18 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--wgrad", action="store_true")
+    ap.add_argument("--ablate", action="store_true", help="DMA conv kernel: full / fill-only / compute-only")
     args = ap.parse_args()
     libs = [(os.path.basename(p), bind(p)) for p in (args.lib or [L.LIB_PATH])]
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     variants = []
+    if args.ablate:
+        for ln, lib in libs:
+            variants.append((ln + ":full", lib, dict(dma=1, ablate=0), False))
+            variants.append((ln + ":fill-only", lib, dict(dma=1, ablate=1), False))
+            variants.append((ln + ":mfma-only", lib, dict(dma=1, ablate=2), False))
+        libs = []
     if args.wgrad:
         for ln, lib in libs:
             variants.append((ln + ":wdma", lib, dict(wgrad_dma=1), False))

@@ -105,6 +105,43 @@ VN_DEV int4 load_tap(const int4* taps, int i) {
 #endif
 }
 
+// Division by a launch-invariant 31-bit integer as multiply-high + shift (exact for
+// m < 2^31).  Runtime `/` and `%` cost ~40 instructions each on the GPU; the voxel decode
+// m -> (b,t,h,w) needs three of them per row.
+struct FastDiv { uint32_t magic, shift, d; };
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f; f.d = d;
+  if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
+  uint32_t l = 0; while ((1u << l) < d) ++l;               // ceil(log2 d)
+  f.magic = (uint32_t)((((unsigned long long)1 << (31 + l)) / d) + 1);
+  f.shift = l - 1;
+  return f;
+}
+VN_DEV uint32_t fdiv(uint32_t m, const FastDiv& f) { return f.d <= 1 ? m : (__umulhi(m, f.magic) >> f.shift); }
+// m -> (b, to, ho, wo) for an iteration space [B][To][Ho][Wo]
+VN_DEV void decode_m(int m, const FastDiv& dW, const FastDiv& dH, const FastDiv& dT, int& b, int& to, int& ho, int& wo) {
+  const uint32_t t1 = fdiv((uint32_t)m, dW);
+  wo = m - (int)t1 * (int)dW.d;
+  const uint32_t t2 = fdiv(t1, dH);
+  ho = (int)t1 - (int)t2 * (int)dH.d;
+  const uint32_t bb = fdiv(t2, dT);
+  to = (int)t2 - (int)bb * (int)dT.d;
+  b = (int)bb;
+}
+
+// MFMA with the accumulator PINNED in the AGPR file.  With the builtin, hipcc keeps the
+// accumulators of an address-heavy pipelined loop in VGPRs and spills/reloads all of them
+// through AGPRs every iteration (2 x 96 v_accvgpr moves per 24 MFMAs measured); an asm
+// operand with the "a" constraint cannot leave the accumulator file.  Accumulate chains need
+// no wait states; callers must call mfma_drain() before anything else reads the result.
+VN_DEV void mfma_bf16_acc(f32x4_v& acc, const bf16x8_v& a, const bf16x8_v& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// wait states between the last MFMA (8 passes) and a non-MFMA reader of its result
+VN_DEV void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+// wait states between a VALU write of an MFMA A/B operand and the MFMA that reads it
+VN_DEV void valu_to_mfma_pad() { asm volatile("s_nop 1"); }
+
 VN_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -81,6 +81,10 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   a.ntaps = d->ntaps; a.Kp = d->Kp; a.M = (int)M;
   a.Nw = d->n_valid > 0 ? d->n_valid : d->y.C;
   VN_CHECK_ARG(a.Nw <= d->y.C, "conv: n_valid > y.C");
+  a.dW = make_fastdiv(d->oW); a.dH = make_fastdiv(d->oH); a.dT = make_fastdiv(d->oT);
+  a.y_linear = (d->omT == 1 && d->omH == 1 && d->omW == 1 && d->ooT == 0 && d->ooH == 0 && d->ooW == 0 &&
+                d->y.T == d->oT && d->y.H == d->oH && d->y.W == d->oW &&
+                d->y.sB == (int64_t)d->y.T * d->y.H * d->y.W * d->y.ld) ? 1 : 0;
   a.act = d->act; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == VINET_F32;
   const int oeb = a.out_f32 ? 4 : 2;
   a.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && (a.sBy % 4 == 0) && ((((uintptr_t)d->y.ptr) % (4 * oeb)) == 0);

@@ -44,16 +44,22 @@ struct ConvDmaCfg {
   static constexpr int LPS = A_LOADS + B_LOADS;      // DMAs per wave per stage
   static constexpr int STAGE_BYTES = (BM + BNP) * 64;
   static constexpr int WNC = NT * 16, EROW = WNC + 4;
-  static constexpr int AFF_BYTES = PRE ? 2 * 1024 * 4 : 0;   // scale[Kp], shift[Kp] (Kp <= 1024) behind the ring
-  static constexpr int KLOOP_BYTES = STAGES * STAGE_BYTES + AFF_BYTES;
+  static constexpr int KLOOP_BYTES = STAGES * STAGE_BYTES;   // PRE adds scale[Kp], shift[Kp] behind the ring
   static constexpr int EPI_BYTES = 4 * 16 * EROW * 4 + WARPS_M * BN * 2 * 4;
-  static constexpr int SMEM = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
+  static int smem_bytes(int Kp) {
+    const int k = KLOOP_BYTES + (PRE ? 2 * Kp * 4 : 0);
+    return k > EPI_BYTES ? k : EPI_BYTES;
+  }
 };
 
 template <int N> VN_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// __launch_bounds__(256, 2): two waves per SIMD (two workgroups per CU).  With one wave per
+// SIMD the wave's DMA issue (~6 x 120 cycles), address VALU and MFMAs serialise (1900 cycles
+// per K step for 384 cycles of MFMA, s_memtime) and the epilogue's write burst overlaps with
+// nothing; a second resident workgroup fills both gaps.
 template <int MT, int NT, int WARPS_M, int WARPS_N, int STAGES, bool PRE>
-__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   using Cfg = ConvDmaCfg<MT, NT, WARPS_M, WARPS_N, STAGES, PRE>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, A_LOADS = Cfg::A_LOADS, B_LOADS = Cfg::B_LOADS;
   static_assert(WARPS_M * WARPS_N == 4, "4 waves");
@@ -62,16 +68,19 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+#ifdef VINET_CONV_TIMING
+  const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = wg % a.tilesN, tile_m = wg / a.tilesN;
   const char* zero = (const char*)g_vinet_zero_page;
   const char* apad = PRE ? (const char*)g_vinet_nan_page : zero;   // what out-of-range ACTIVATIONS read
-  float* aff = (float*)(smem + STAGES * Cfg::STAGE_BYTES);         // PRE: scale[0..Kp), shift at +1024
+  float* aff = (float*)(smem + STAGES * Cfg::STAGE_BYTES);         // PRE: scale[0..Kp), shift[0..Kp)
   if constexpr (PRE) {
     for (int c = tid; c < a.Kp; c += 256) {
       const bool in = c < a.Cin;
       aff[c] = in ? a.in_scale[c] : 0.f;
-      aff[1024 + c] = in ? a.in_shift[c] : 0.f;
+      aff[a.Kp + c] = in ? a.in_shift[c] : 0.f;
     }
     __syncthreads();   // plain loads above are complete before any DMA is counted
   }
@@ -89,12 +98,8 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     const int row = i * 64 + wave * 16 + lrow;
     const int m = tile_m * BM + row;
     if (m < a.M) {
-      const int wo = m % a.Wo;
-      const int t1 = m / a.Wo;
-      const int ho = t1 % a.Ho;
-      const int t2 = t1 / a.Ho;
-      const int to = t2 % a.To;
-      const int b = t2 / a.To;
+      int b, to, ho, wo;
+      decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
       a_t[i] = to * a.sT; a_h[i] = ho * a.sH; a_w[i] = wo * a.sW;
       const long off = (long)b * a.sBx + ((long)(a_t[i] * a.Hi + a_h[i]) * a.Wi + a_w[i]) * (long)a.ldx + src_chunk * 8;
       a_ptr[i] = a.x + off * 2;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
       // this lane's 8 k-elements are channels cmp_c + (lane>>4)*8 .. +7 in every fragment
       const float* sp = aff + cmp_c + (lane >> 4) * 8;
       const float4 s0 = *(const float4*)sp, s1 = *(const float4*)(sp + 4);
-      const float4 h0 = *(const float4*)(sp + 1024), h1 = *(const float4*)(sp + 1028);
+      const float4 h0 = *(const float4*)(sp + a.Kp), h1 = *(const float4*)(sp + a.Kp + 4);
       const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
       const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
       }
       cmp_c += 32;
       if (cmp_c >= a.Kp) cmp_c = 0;
+      valu_to_mfma_pad();
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8_v*)(Bs + j * 16 * 64);
@@ -200,10 +206,13 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        mfma_bf16_acc(acc[i][j], af[i], bfr[j]);
   };
 
   // ---- pipeline ------------------------------------------------------------------
+#ifdef VINET_CONV_TIMING
+  const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s);
   int slot = 0, fill = STAGES - 1;
@@ -218,8 +227,19 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     fill = fill + 1 == STAGES ? 0 : fill + 1;
   }
   wait_vmcnt<0>();                             // drain the tail DMAs before LDS is reused
+  mfma_drain();                                // accumulators are about to be read by VALU code
   __syncthreads();
+#ifdef VINET_CONV_TIMING
+  const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+#endif
   conv_epilogue<MT, NT, WARPS_M, WARPS_N>(a, acc, smem, tile_m, tile_n);
+#ifdef VINET_CONV_TIMING
+  if (tid == 0 && a.out_shift) {   // tuning build only: out_shift doubles as a [grid][4] float dump
+    const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+    float* dbg = (float*)a.out_shift + (long)blockIdx.x * 4;
+    dbg[0] = (float)(tm1 - tm0); dbg[1] = (float)(tm2 - tm1); dbg[2] = (float)(tm3 - tm2); dbg[3] = (float)nchunks;
+  }
+#endif
 }
 
 template <int MT, int NT, int WM, int WN, int STAGES, bool PRE>
@@ -230,10 +250,10 @@ static int launch_conv_dma_cfg(const ConvArgs& a, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_done[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::smem_bytes(1024));
     if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_dma): %s", hipGetErrorString(e)); return (int)e; }
     attr_done[dev & 63] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(256), Cfg::SMEM, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(256), Cfg::smem_bytes(a.Kp), s, a);
   return vn_launch_status("conv_dma");
 }

@@ -35,6 +35,8 @@ struct ConvArgs {
   int omT, omH, omW, ooT, ooH, ooW;
   int ntaps, Kp, M, tilesM, tilesN, Nw;
   int in_relu, act, accumulate, out_f32, vec_ok;
+  int y_linear;          // output offset of voxel m is simply m*ldy (full-extent, possibly channel-sliced view)
+  FastDiv dW, dH, dT;    // fast division by Wo, Ho, To
 };
 
 template <typename T, int MT, int NT, int WARPS_M, int WARPS_N>
@@ -56,7 +58,16 @@ struct ConvCfg {
 
 // ---- shared epilogue: per-channel affine, BN partial statistics, activation,
 //      LDS-transposed 4-channel vector stores, accumulate, arbitrary placement.
-//      Must be entered after a workgroup barrier (it reuses the K-loop LDS). ------
+//      Must be entered after a workgroup barrier (it reuses the K-loop LDS).
+//      The staging area is PRIVATE to each wave, so the write->read hand-off needs only
+//      wave-level ordering.  (A __syncthreads() here would also wait for the wave's own
+//      global stores -- vmcnt counts stores on gfx950 -- and cost a full write round trip
+//      per row group: 3.9k cycles each, measured with s_memtime.) ------------------------
+VN_DEV void wave_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int MT, int NT, int WARPS_M, int WARPS_N>
 VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem, int tile_m, int tile_n) {
   constexpr int BM = 16 * MT * WARPS_M, BN = 16 * NT * WARPS_N;
@@ -67,6 +78,8 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   float* red = (float*)smem + 4 * 16 * EROW;
   const int m_wave = tile_m * BM + wm * MT * 16;
   const int n_wave = tile_n * BN + wn * WNC;
+  const bool do_stats = a.stats != nullptr;
+  const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;   // branch-free ReLU: max(v, floor)
 
   {
     float s_sum[NT], s_sq[NT];
@@ -82,15 +95,22 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m_wave + i * 16 + (lane >> 4) * 4 + r;
-          float v = fmaf(acc[i][j][r], sc, sh);
-          if (a.stats && nok && m < a.M) { ss += v; qq += v * v; }
-          if (a.act == VINET_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == VINET_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-          acc[i][j][r] = v;
+          const float v = fmaf(acc[i][j][r], sc, sh);
+          const float vs = (nok && m < a.M) ? v : 0.f;
+          ss += vs; qq += vs * vs;
+          acc[i][j][r] = fmaxf(v, relu_floor);
         }
       s_sum[j] = ss; s_sq[j] = qq;
     }
-    if (a.stats) {
+    if (a.act == VINET_ACT_SIGMOID) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = 1.f / (1.f + __expf(-acc[i][j][r]));
+    }
+    if (do_stats) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         float ss = s_sum[j], qq = s_sq[j];
@@ -105,74 +125,94 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     }
   }
 
+  // common case: bf16 output, 4-channel vectors, plain store, output offset linear in m
+  const bool fast = a.vec_ok && !a.out_f32 && !a.accumulate && a.y_linear;
+  constexpr int VPR = WNC / 4;             // 4-channel vectors per tile row
+  constexpr int ITERS = (16 * VPR) / 64;   // store instructions per lane per row group
+  static_assert((16 * VPR) % 64 == 0, "row group must divide over the wave");
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Ew[((lane >> 4) * 4 + r) * EROW + j * 16 + (lane & 15)] = acc[i][j][r];
-    __syncthreads();
-    for (int e = lane; e < 16 * (WNC / 4); e += 64) {
-      const int rr = e / (WNC / 4), cc = (e % (WNC / 4)) * 4;
-      const int m = m_wave + i * 16 + rr;
-      const int n = n_wave + cc;
-      if (m < a.M && n < a.N) {
-        const float4 v = *(const float4*)&Ew[rr * EROW + cc];
-        const int wo = m % a.Wo;
-        const int t1 = m / a.Wo;
-        const int ho = t1 % a.Ho;
-        const int t2 = t1 / a.Ho;
-        const int to = t2 % a.To;
-        const int b = t2 / a.To;
-        const long off = (long)b * a.sBy +
-                         ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) *
-                             (long)a.ldy + n;
-        float o[4] = {v.x, v.y, v.z, v.w};
-        if (a.vec_ok) {
-          if (a.out_f32) {
-            float* dst = (float*)a.y + off;
-            if (a.accumulate) { const float4 q = *(const float4*)dst; o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
-            *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
-            bf16_t* dst = (bf16_t*)a.y + off;
-            if (a.accumulate) {
-              const uint2 q = *(const uint2*)dst;
-              o[0] += __uint_as_float(q.x << 16); o[1] += __uint_as_float(q.x & 0xffff0000u);
-              o[2] += __uint_as_float(q.y << 16); o[3] += __uint_as_float(q.y & 0xffff0000u);
-            }
-            *(uint2*)dst = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-          }
-        } else {
+    wave_lds_fence();
+    if (fast) {
 #pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) {
-            if (n + e2 < a.N) {
-              if (a.out_f32) {
-                float* dst = (float*)a.y + off + e2;
-                *dst = a.accumulate ? *dst + o[e2] : o[e2];
-              } else {
-                bf16_t* dst = (bf16_t*)a.y + off + e2;
-                *dst = f2bf(a.accumulate ? bf2f(*dst) + o[e2] : o[e2]);
+      for (int k = 0; k < ITERS; ++k) {
+        const int e = lane + 64 * k;
+        const int rr = e / VPR, cc = (e % VPR) * 4;
+        const int m = m_wave + i * 16 + rr;
+        const int n = n_wave + cc;
+        const float4 v = *(const float4*)&Ew[rr * EROW + cc];
+        if (m < a.M && n < a.N)
+          *(uint2*)((bf16_t*)a.y + (long)m * a.ldy + n) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+      }
+    } else {
+      for (int e = lane; e < 16 * VPR; e += 64) {
+        const int rr = e / VPR, cc = (e % VPR) * 4;
+        const int m = m_wave + i * 16 + rr;
+        const int n = n_wave + cc;
+        if (m < a.M && n < a.N) {
+          const float4 v = *(const float4*)&Ew[rr * EROW + cc];
+          long off;
+          if (a.y_linear) {
+            off = (long)m * a.ldy + n;
+          } else {
+            int b, to, ho, wo;
+            decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
+            off = (long)b * a.sBy +
+                  ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) * (long)a.ldy + n;
+          }
+          float o[4] = {v.x, v.y, v.z, v.w};
+          if (a.vec_ok) {
+            if (a.out_f32) {
+              float* dst = (float*)a.y + off;
+              if (a.accumulate) { const float4 q = *(const float4*)dst; o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
+              *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+              bf16_t* dst = (bf16_t*)a.y + off;
+              if (a.accumulate) {
+                const uint2 q = *(const uint2*)dst;
+                o[0] += __uint_as_float(q.x << 16); o[1] += __uint_as_float(q.x & 0xffff0000u);
+                o[2] += __uint_as_float(q.y << 16); o[3] += __uint_as_float(q.y & 0xffff0000u);
+              }
+              *(uint2*)dst = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            }
+          } else {
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+              if (n + e2 < a.N) {
+                if (a.out_f32) {
+                  float* dst = (float*)a.y + off + e2;
+                  *dst = a.accumulate ? *dst + o[e2] : o[e2];
+                } else {
+                  bf16_t* dst = (bf16_t*)a.y + off + e2;
+                  *dst = f2bf(a.accumulate ? bf2f(*dst) + o[e2] : o[e2]);
+                }
               }
             }
           }
         }
       }
     }
-    __syncthreads();
+    wave_lds_fence();   // all lanes have read this row group before the next one overwrites it
   }
 
-  if (a.stats && tid < BN) {
-    const int n = tile_n * BN + tid;
-    if (n < a.N) {
-      float ss = 0.f, qq = 0.f;
+  if (do_stats) {
+    __syncthreads();    // cross-wave hand-off of the per-wave column sums
+    if (tid < BN) {
+      const int n = tile_n * BN + tid;
+      if (n < a.N) {
+        float ss = 0.f, qq = 0.f;
 #pragma unroll
-      for (int w2 = 0; w2 < WARPS_M; ++w2) { ss += red[(w2 * BN + tid) * 2]; qq += red[(w2 * BN + tid) * 2 + 1]; }
-      a.stats[((long)tile_m * 2 + 0) * a.N + n] = ss;
-      a.stats[((long)tile_m * 2 + 1) * a.N + n] = qq;
+        for (int w2 = 0; w2 < WARPS_M; ++w2) { ss += red[(w2 * BN + tid) * 2]; qq += red[(w2 * BN + tid) * 2 + 1]; }
+        a.stats[((long)tile_m * 2 + 0) * a.N + n] = ss;
+        a.stats[((long)tile_m * 2 + 1) * a.N + n] = qq;
+      }
     }
   }
 }
-
 
 template <typename T, int MT, int NT, int WARPS_M, int WARPS_N, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
@@ -199,12 +239,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int row = (i * 256 + tid) / G;
     const int m = tile_m * BM + row;
     if (m < a.M) {
-      const int wo = m % a.Wo;
-      const int t1 = m / a.Wo;
-      const int ho = t1 % a.Ho;
-      const int t2 = t1 / a.Ho;
-      const int to = t2 % a.To;
-      const int b = t2 / a.To;
+      int b, to, ho, wo;
+      decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
       a_base[i] = (long)b * a.sBx;
       a_t[i] = to * a.sT; a_h[i] = ho * a.sH; a_w[i] = wo * a.sW;
     } else {

@@ -28,19 +28,6 @@ __device__ __attribute__((aligned(64))) uint4 g_wg_nan_page[4] = {
     {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu},
     {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}};
 
-struct FastDiv { uint32_t magic, shift, d; };
-static inline FastDiv make_fastdiv(uint32_t d) {
-  FastDiv f; f.d = d;
-  if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
-  uint32_t l = 0; while ((1u << l) < d) ++l;               // ceil(log2 d)
-  f.magic = (uint32_t)((((unsigned long long)1 << (31 + l)) / d) + 1);
-  f.shift = l - 1;
-  return f;
-}
-VN_DEV uint32_t fdiv(uint32_t m, const FastDiv& f) {          // exact for m < 2^31
-  return f.d <= 1 ? m : (__umulhi(m, f.magic) >> f.shift);
-}
-
 struct WgradDmaArgs {
   const char* x;
   const char* dy;
@@ -226,10 +213,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
             q.w[e] = wg_cvt_pk_bf16(lo, hi);
           }
           bf = q.v;
+          valu_to_mfma_pad();
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-          acc[g][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[g][i][j], 0, 0, 0);
+          mfma_bf16_acc(acc[g][i][j], af[i], bf);
       }
     }
   };
@@ -249,6 +237,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
     fill = fill + 1 == STAGES ? 0 : fill + 1;
   }
   wg_wait_vmcnt<0>();
+  mfma_drain();
 
 #pragma unroll
   for (int g = 0; g < TG; ++g) {
