@@ -59,15 +59,45 @@ template <typename T> VN_DEV void store1(T* p, float v);
 template <> VN_DEV void store1<float>(float* p, float v) { *p = v; }
 template <> VN_DEV void store1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
+// Division by a launch-invariant 31-bit integer as multiply-high + shift (exact for
+// m < 2^31).  Runtime `/` and `%` cost ~40 instructions each on the GPU; the voxel decode
+// m -> (b,t,h,w) needs three of them per row.
+struct FastDiv { uint32_t magic, shift, d; };
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f; f.d = d;
+  if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
+  uint32_t l = 0; while ((1u << l) < d) ++l;               // ceil(log2 d)
+  f.magic = (uint32_t)((((unsigned long long)1 << (31 + l)) / d) + 1);
+  f.shift = l - 1;
+  return f;
+}
+VN_DEV uint32_t fdiv(uint32_t m, const FastDiv& f) { return f.d <= 1 ? m : (__umulhi(m, f.magic) >> f.shift); }
+// m -> (b, to, ho, wo) for an iteration space [B][To][Ho][Wo]
+VN_DEV void decode_m(int m, const FastDiv& dW, const FastDiv& dH, const FastDiv& dT, int& b, int& to, int& ho, int& wo) {
+  const uint32_t t1 = fdiv((uint32_t)m, dW);
+  wo = m - (int)t1 * (int)dW.d;
+  const uint32_t t2 = fdiv(t1, dH);
+  ho = (int)t1 - (int)t2 * (int)dH.d;
+  const uint32_t bb = fdiv(t2, dT);
+  to = (int)t2 - (int)bb * (int)dT.d;
+  b = (int)bb;
+}
+
 // Device-side tensor view (mirror of VinetTensor with typed helpers).
 struct TView {
   char* p;
   int B, T, H, W, C, ld;
   long sB;
+  int linear;            // voxel v lives at element offset v*ld (full-extent view, possibly a channel slice)
+  FastDiv dW, dH, dT;    // voxel index -> (b,t,h,w) without runtime division
+  FastDiv dQ;            // flat (voxel, 4-channel group) index -> voxel
 };
 static inline TView make_view(const VinetTensor& t) {
   TView v;
   v.p = (char*)t.ptr; v.B = t.B; v.T = t.T; v.H = t.H; v.W = t.W; v.C = t.C; v.ld = t.ld; v.sB = t.sB;
+  v.linear = (t.sB == (int64_t)t.T * t.H * t.W * t.ld) ? 1 : 0;
+  v.dW = make_fastdiv((uint32_t)t.W); v.dH = make_fastdiv((uint32_t)t.H); v.dT = make_fastdiv((uint32_t)t.T);
+  v.dQ = make_fastdiv((uint32_t)(t.C / 4 > 0 ? t.C / 4 : 1));
   return v;
 }
 // element offset of voxel (b,t,h,w), channel 0
@@ -103,30 +133,6 @@ VN_DEV int4 load_tap(const int4* taps, int i) {
 #else
   return taps[i];
 #endif
-}
-
-// Division by a launch-invariant 31-bit integer as multiply-high + shift (exact for
-// m < 2^31).  Runtime `/` and `%` cost ~40 instructions each on the GPU; the voxel decode
-// m -> (b,t,h,w) needs three of them per row.
-struct FastDiv { uint32_t magic, shift, d; };
-static inline FastDiv make_fastdiv(uint32_t d) {
-  FastDiv f; f.d = d;
-  if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
-  uint32_t l = 0; while ((1u << l) < d) ++l;               // ceil(log2 d)
-  f.magic = (uint32_t)((((unsigned long long)1 << (31 + l)) / d) + 1);
-  f.shift = l - 1;
-  return f;
-}
-VN_DEV uint32_t fdiv(uint32_t m, const FastDiv& f) { return f.d <= 1 ? m : (__umulhi(m, f.magic) >> f.shift); }
-// m -> (b, to, ho, wo) for an iteration space [B][To][Ho][Wo]
-VN_DEV void decode_m(int m, const FastDiv& dW, const FastDiv& dH, const FastDiv& dT, int& b, int& to, int& ho, int& wo) {
-  const uint32_t t1 = fdiv((uint32_t)m, dW);
-  wo = m - (int)t1 * (int)dW.d;
-  const uint32_t t2 = fdiv(t1, dH);
-  ho = (int)t1 - (int)t2 * (int)dH.d;
-  const uint32_t bb = fdiv(t2, dT);
-  to = (int)t2 - (int)bb * (int)dT.d;
-  b = (int)bb;
 }
 
 // MFMA with the accumulator PINNED in the AGPR file.  With the builtin, hipcc keeps the

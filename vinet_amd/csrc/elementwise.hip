@@ -28,9 +28,14 @@ VN_DEV float4 affine4(float4 v, const Affine& a, int c) {
 }
 
 VN_DEV void decode_vox(const TView& v, long vox, int& b, int& t, int& h, int& w) {
-  w = (int)(vox % v.W); vox /= v.W;
-  h = (int)(vox % v.H); vox /= v.H;
-  t = (int)(vox % v.T); b = (int)(vox / v.T);
+  decode_m((int)vox, v.dW, v.dH, v.dT, b, t, h, w);
+}
+// element offset of voxel `vox` (same iteration space as `v`): no decode for linear views
+VN_DEV long vox_lin(const TView& v, long vox) {
+  if (v.linear) return vox * (long)v.ld;
+  int b, t, h, w;
+  decode_m((int)vox, v.dW, v.dH, v.dT, b, t, h, w);
+  return vox_off(v, b, t, h, w);
 }
 static inline long view_voxels(const VinetTensor& t) { return (long)t.B * t.T * t.H * t.W; }
 static inline bool quad_ok(const VinetTensor& t, int esz) {
@@ -41,7 +46,10 @@ static inline int esize(int dtype) { return dtype == VINET_F32 ? 4 : 2; }
 static inline bool same_dims(const VinetTensor& a, const VinetTensor& b) {
   return a.B == b.B && a.T == b.T && a.H == b.H && a.W == b.W && a.C == b.C;
 }
-static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : g); }
+static inline int ew_grid(long n) {   // one thread per item; indices are 32-bit (fast division)
+  if (n >= (1L << 31)) { vinet_set_error("elementwise launch too large (%ld items)", n); return 0; }
+  long g = (n + 255) / 256; return (int)(g < 1 ? 1 : g);
+}
 
 #define DISPATCH_T(dt, T, ...)                         \
   if ((dt) == VINET_F32) { using T = float; __VA_ARGS__ } \
@@ -118,12 +126,9 @@ extern "C" int vinet_unpack_wgrad(const float* dw, int32_t N, int32_t Cin, int32
 template <typename T>
 __global__ void import_ncdhw_kernel(const float* __restrict__ src, long sb, long sc, long st, long sh, long sw, int C,
                                     TView dst, long nvox) {
-  const int Q = dst.C / 4;
-  const long total = nvox * Q;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const long vox = i % nvox;       // voxels fastest: coalesced planar reads
-  const int q = (int)(i / nvox);
+  const long vox = (long)blockIdx.x * blockDim.x + threadIdx.x;   // voxels fastest: coalesced planar reads
+  if (vox >= nvox) return;
+  const int q = blockIdx.y;
   int b, t, h, w;
   decode_vox(dst, vox, b, t, h, w);
   const float* s = src + b * sb + t * st + h * sh + w * sw;
@@ -137,8 +142,7 @@ extern "C" int vinet_import_ncdhw(const float* src, int64_t sb, int64_t sc, int6
                                   int32_t C, const VinetTensor* dst, int32_t dst_dtype, void* stream) {
   VN_CHECK_ARG(src && dst && quad_ok(*dst, esize(dst_dtype)) && C > 0 && C <= dst->C, "import_ncdhw: bad arguments");
   const long nvox = view_voxels(*dst);
-  const long total = nvox * (dst->C / 4);
-  DISPATCH_T(dst_dtype, T, hipLaunchKernelGGL(import_ncdhw_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+  DISPATCH_T(dst_dtype, T, hipLaunchKernelGGL(import_ncdhw_kernel<T>, dim3(ew_grid(nvox), dst->C / 4), dim3(256), 0,
                                               (hipStream_t)stream, src, sb, sc, st, sh, sw, C, make_view(*dst), nvox);)
   return vn_launch_status("import_ncdhw");
 }
@@ -146,12 +150,9 @@ extern "C" int vinet_import_ncdhw(const float* src, int64_t sb, int64_t sc, int6
 template <typename T>
 __global__ void export_ncdhw_kernel(TView src, Affine pre, float* __restrict__ dst, long sb, long sc, long st, long sh,
                                     long sw, int accumulate, long nvox) {
-  const int Q = src.C / 4;
-  const long total = nvox * Q;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const long vox = i % nvox;
-  const int q = (int)(i / nvox);
+  const long vox = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vox >= nvox) return;
+  const int q = blockIdx.y;
   int b, t, h, w;
   decode_vox(src, vox, b, t, h, w);
   float4 v = ldq<T>((const T*)src.p + vox_off(src, b, t, h, w) + q * 4);
@@ -166,8 +167,7 @@ extern "C" int vinet_export_ncdhw(const VinetTensor* src, int32_t src_dtype, Vin
                                   int64_t sc, int64_t st, int64_t sh, int64_t sw, int32_t accumulate, void* stream) {
   VN_CHECK_ARG(src && dst && quad_ok(*src, esize(src_dtype)), "export_ncdhw: bad arguments");
   const long nvox = view_voxels(*src);
-  const long total = nvox * (src->C / 4);
-  DISPATCH_T(src_dtype, T, hipLaunchKernelGGL(export_ncdhw_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
+  DISPATCH_T(src_dtype, T, hipLaunchKernelGGL(export_ncdhw_kernel<T>, dim3(ew_grid(nvox), src->C / 4), dim3(256), 0,
                                               (hipStream_t)stream, make_view(*src), make_affine(pre), dst, sb, sc, st,
                                               sh, sw, accumulate, nvox);)
   return vn_launch_status("export_ncdhw");
@@ -177,14 +177,12 @@ template <typename TI, typename TO>
 __global__ void copy_affine_kernel(TView src, Affine pre, TView dst, int accumulate, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int Q = src.C / 4;
-  const int q = (int)(i % Q);
-  const long vox = i / Q;
-  int b, t, h, w;
-  decode_vox(src, vox, b, t, h, w);
-  float4 v = ldq<TI>((const TI*)src.p + vox_off(src, b, t, h, w) + q * 4);
+  const uint32_t vox_u = fdiv((uint32_t)i, src.dQ);
+  const int q = (int)((uint32_t)i - vox_u * (uint32_t)(src.C / 4));
+  const long vox = (long)vox_u;
+  float4 v = ldq<TI>((const TI*)src.p + vox_lin(src, vox) + q * 4);
   v = affine4(v, pre, q * 4);
-  TO* d = (TO*)dst.p + vox_off(dst, b, t, h, w) + q * 4;
+  TO* d = (TO*)dst.p + vox_lin(dst, vox) + q * 4;
   if (accumulate) { const float4 o = ldq<TO>(d); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
   stq<TO>(d, v);
 }
@@ -310,10 +308,8 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(TView x, TView dz, 
           ok[u] = v < v1;
           xv[u] = make_float4(0, 0, 0, 0); gv[u] = make_float4(0, 0, 0, 0);
           if (ok[u]) {
-            int b, t, h, w;
-            decode_vox(x, v, b, t, h, w);
-            xv[u] = ldq<T>((const T*)x.p + vox_off(x, b, t, h, w) + q * 4);
-            if (MODE == 1) gv[u] = ldq<T>((const T*)dz.p + vox_off(dz, b, t, h, w) + q * 4);
+            xv[u] = ldq<T>((const T*)x.p + vox_lin(x, v) + q * 4);
+            if (MODE == 1) gv[u] = ldq<T>((const T*)dz.p + vox_lin(dz, v) + q * 4);
           }
         }
 #pragma unroll
@@ -419,13 +415,11 @@ __global__ void bn_bwd_apply_kernel(TView dz, TView x, Affine fwd, const float* 
                                     const float* c1, const float* c2, TView dx, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int Q = x.C / 4;
-  const int q = (int)(i % Q);
-  const long vox = i / Q;
-  int b, t, h, w;
-  decode_vox(x, vox, b, t, h, w);
-  const float4 xv = ldq<T>((const T*)x.p + vox_off(x, b, t, h, w) + q * 4);
-  float4 g = ldq<T>((const T*)dz.p + vox_off(dz, b, t, h, w) + q * 4);
+  const uint32_t vox_u = fdiv((uint32_t)i, x.dQ);
+  const int q = (int)((uint32_t)i - vox_u * (uint32_t)(x.C / 4));
+  const long vox = (long)vox_u;
+  const float4 xv = ldq<T>((const T*)x.p + vox_lin(x, vox) + q * 4);
+  float4 g = ldq<T>((const T*)dz.p + vox_lin(dz, vox) + q * 4);
   const float4 sc = *(const float4*)(fwd.scale + q * 4);
   if (fwd.relu) {
     const float4 sh = *(const float4*)(fwd.shift + q * 4);
@@ -441,7 +435,7 @@ __global__ void bn_bwd_apply_kernel(TView dz, TView x, Affine fwd, const float* 
   o.y = sc.y * (g.y - a1.y - (xv.y - mu.y) * is.y * a2.y);
   o.z = sc.z * (g.z - a1.z - (xv.z - mu.z) * is.z * a2.z);
   o.w = sc.w * (g.w - a1.w - (xv.w - mu.w) * is.w * a2.w);
-  stq<T>((T*)dx.p + vox_off(dx, b, t, h, w) + q * 4, o);
+  stq<T>((T*)dx.p + vox_lin(dx, vox) + q * 4, o);
 }
 
 extern "C" int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,
@@ -461,13 +455,11 @@ template <typename TG, typename TZ, typename TO>
 __global__ void act_bwd_kernel(TView dz, TView z, int act, TView dy, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int Q = z.C / 4;
-  const int q = (int)(i % Q);
-  const long vox = i / Q;
-  int b, t, h, w;
-  decode_vox(z, vox, b, t, h, w);
-  const float4 zv = ldq<TZ>((const TZ*)z.p + vox_off(z, b, t, h, w) + q * 4);
-  float4 g = ldq<TG>((const TG*)dz.p + vox_off(dz, b, t, h, w) + q * 4);
+  const uint32_t vox_u = fdiv((uint32_t)i, z.dQ);
+  const int q = (int)((uint32_t)i - vox_u * (uint32_t)(z.C / 4));
+  const long vox = (long)vox_u;
+  const float4 zv = ldq<TZ>((const TZ*)z.p + vox_lin(z, vox) + q * 4);
+  float4 g = ldq<TG>((const TG*)dz.p + vox_lin(dz, vox) + q * 4);
   if (act == VINET_ACT_RELU) {
     if (!(zv.x > 0.f)) g.x = 0.f;
     if (!(zv.y > 0.f)) g.y = 0.f;
@@ -476,7 +468,7 @@ __global__ void act_bwd_kernel(TView dz, TView z, int act, TView dy, long total)
   } else if (act == VINET_ACT_SIGMOID) {
     g.x *= zv.x * (1.f - zv.x); g.y *= zv.y * (1.f - zv.y); g.z *= zv.z * (1.f - zv.z); g.w *= zv.w * (1.f - zv.w);
   }
-  stq<TO>((TO*)dy.p + vox_off(dy, b, t, h, w) + q * 4, g);
+  stq<TO>((TO*)dy.p + vox_lin(dy, vox) + q * 4, g);
 }
 
 extern "C" int vinet_act_bwd(const VinetTensor* dz, int32_t dz_dtype, const VinetTensor* z, int32_t z_dtype,
@@ -532,15 +524,19 @@ extern "C" int vinet_channel_sum(const VinetTensor* x, int32_t dtype, float* wor
 // ============================================================================
 // MaxPool3d
 // ============================================================================
-struct PoolP { int kT, kH, kW, sT, sH, sW, pT, pH, pW; };
+struct PoolP { int kT, kH, kW, sT, sH, sW, pT, pH, pW; FastDiv dsT, dsH, dsW; };
+static inline PoolP make_poolp(const VinetPoolDesc* d) {
+  PoolP p = {d->kT, d->kH, d->kW, d->sT, d->sH, d->sW, d->pT, d->pH, d->pW, make_fastdiv((uint32_t)d->sT), make_fastdiv((uint32_t)d->sH), make_fastdiv((uint32_t)d->sW)};
+  return p;
+}
 
 template <typename T>
 __global__ void maxpool_fwd_kernel(PoolP p, TView x, Affine pre, TView y, uint8_t* __restrict__ argmax, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int Q = y.C / 4;
-  const int q = (int)(i % Q);
-  const long vox = i / Q;
+  const uint32_t vox_u = fdiv((uint32_t)i, y.dQ);
+  const int q = (int)((uint32_t)i - vox_u * (uint32_t)(y.C / 4));
+  const long vox = (long)vox_u;
   int b, to, ho, wo;
   decode_vox(y, vox, b, to, ho, wo);
   float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -576,12 +572,13 @@ template <typename T>
 __global__ void maxpool_tslide_kernel(PoolP p, TView x, Affine pre, TView y, uint8_t* __restrict__ argmax, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int Q = y.C / 4;
-  const int q = (int)(i % Q);
-  long r = i / Q;
-  const int wo = (int)(r % y.W); r /= y.W;
-  const int ho = (int)(r % y.H);
-  const int b = (int)(r / y.H);
+  const uint32_t col = fdiv((uint32_t)i, y.dQ);
+  const int q = (int)((uint32_t)i - col * (uint32_t)(y.C / 4));
+  const uint32_t r1 = fdiv(col, y.dW);
+  const int wo = (int)(col - r1 * (uint32_t)y.W);
+  const uint32_t r2 = fdiv(r1, y.dH);
+  const int ho = (int)(r1 - r2 * (uint32_t)y.H);
+  const int b = (int)r2;
   float pm[3][4];
   int pa[3][4];
   const int khw = p.kH * p.kW;
@@ -636,7 +633,7 @@ extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, Vin
   VN_CHECK_ARG(d && x && y && quad_ok(*x, esize(d->dtype)) && quad_ok(*y, esize(d->dtype)) && x->C == y->C && x->B == y->B,
                "maxpool3d: bad views");
   VN_CHECK_ARG(d->kT * d->kH * d->kW <= 255 && d->kT > 0 && d->kH > 0 && d->kW > 0, "maxpool3d: window too large");
-  const PoolP p = {d->kT, d->kH, d->kW, d->sT, d->sH, d->sW, d->pT, d->pH, d->pW};
+  const PoolP p = make_poolp(d);
   if (d->kT == 3 && d->sT == 1 && d->pT == 1 && y->T == x->T && x->T >= 2) {
     const long cols = (long)y->B * y->H * y->W * (y->C / 4);
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_tslide_kernel<T>, dim3(ew_grid(cols)), dim3(256), 0,
@@ -655,16 +652,18 @@ __global__ void maxpool_bwd_kernel(PoolP p, TView dy, const uint8_t* __restrict_
                                    long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int Q = dx.C / 4;
-  const int q = (int)(i % Q);
-  const long vox = i / Q;
+  const uint32_t vox_u = fdiv((uint32_t)i, dx.dQ);
+  const int q = (int)((uint32_t)i - vox_u * (uint32_t)(dx.C / 4));
+  const long vox = (long)vox_u;
   int b, t, h, w;
   decode_vox(dx, vox, b, t, h, w);
   float g[4] = {0, 0, 0, 0};
   // windows: o*s - pad <= pos <= o*s - pad + k - 1
-  const int to1 = min((t + p.pT) / p.sT, dy.T - 1), ho1 = min((h + p.pH) / p.sH, dy.H - 1), wo1 = min((w + p.pW) / p.sW, dy.W - 1);
-  const int to0 = max(0, (t + p.pT - p.kT + p.sT) / p.sT), ho0 = max(0, (h + p.pH - p.kH + p.sH) / p.sH),
-            wo0 = max(0, (w + p.pW - p.kW + p.sW) / p.sW);
+  // (all numerators are >= 0 after the max: fast unsigned division)
+  const int to1 = min((int)fdiv((uint32_t)(t + p.pT), p.dsT), dy.T - 1), ho1 = min((int)fdiv((uint32_t)(h + p.pH), p.dsH), dy.H - 1),
+            wo1 = min((int)fdiv((uint32_t)(w + p.pW), p.dsW), dy.W - 1);
+  const int to0 = (int)fdiv((uint32_t)max(0, t + p.pT - p.kT + p.sT), p.dsT), ho0 = (int)fdiv((uint32_t)max(0, h + p.pH - p.kH + p.sH), p.dsH),
+            wo0 = (int)fdiv((uint32_t)max(0, w + p.pW - p.kW + p.sW), p.dsW);
   for (int to = to0; to <= to1; ++to) {
     const int kt = t + p.pT - to * p.sT;
     if (kt < 0 || kt >= p.kT) continue;
@@ -698,7 +697,7 @@ extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy
                                    const VinetTensor* dx, int32_t accumulate, void* stream) {
   VN_CHECK_ARG(d && dy && dx && argmax && quad_ok(*dy, esize(d->dtype)) && quad_ok(*dx, esize(d->dtype)) &&
                    dx->C == dy->C && dx->B == dy->B, "maxpool3d_bwd: bad views");
-  const PoolP p = {d->kT, d->kH, d->kW, d->sT, d->sH, d->sW, d->pT, d->pH, d->pW};
+  const PoolP p = make_poolp(d);
   const long total = view_voxels(*dx) * (dx->C / 4);
   DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
                                              (hipStream_t)stream, p, make_view(*dy), argmax, make_view(*dx), accumulate, total);)
@@ -712,9 +711,9 @@ template <typename T>
 __global__ void upsample2x_kernel(TView x, TView y, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int Q = y.C / 4;
-  const int q = (int)(i % Q);
-  const long vox = i / Q;
+  const uint32_t vox_u = fdiv((uint32_t)i, y.dQ);
+  const int q = (int)((uint32_t)i - vox_u * (uint32_t)(y.C / 4));
+  const long vox = (long)vox_u;
   int b, t, ho, wo;
   decode_vox(y, vox, b, t, ho, wo);
   // src = max((o + .5)/2 - .5, 0); i0 = floor(src); l1 = src - i0; i1 = i0 + (i0 < n-1)
@@ -755,9 +754,9 @@ template <typename T>
 __global__ void upsample2x_bwd_kernel(TView dy, TView dx, int accumulate, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int Q = dx.C / 4;
-  const int q = (int)(i % Q);
-  const long vox = i / Q;
+  const uint32_t vox_u = fdiv((uint32_t)i, dx.dQ);
+  const int q = (int)((uint32_t)i - vox_u * (uint32_t)(dx.C / 4));
+  const long vox = (long)vox_u;
   int b, t, h, w;
   decode_vox(dx, vox, b, t, h, w);
   int oh[4], ow[4];
