@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
     ap.add_argument("--clip", type=int, default=32)
     ap.add_argument("--height", type=int, default=224)
     ap.add_argument("--width", type=int, default=384)

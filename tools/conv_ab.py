@@ -63,10 +63,11 @@ def main():
         libs = []
     if args.wgrad:
         for ln, lib in libs:
-            variants.append((ln + ":wdma", lib, dict(wgrad_dma=1), False))
-            variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1), True))
-            variants.append((ln + ":wold", lib, dict(wgrad_dma=0), False))
-            variants.append((ln + ":wold+pre", lib, dict(wgrad_dma=0), True))
+            variants.append((ln + ":wdma", lib, dict(wgrad_dma=1, wgrad_tg=0), False))
+            variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0), True))
+            variants.append((ln + ":tg3", lib, dict(wgrad_dma=1, wgrad_tg=3), False))
+            variants.append((ln + ":tg3+pre", lib, dict(wgrad_dma=1, wgrad_tg=3), True))
+            variants.append((ln + ":tg1", lib, dict(wgrad_dma=1, wgrad_tg=1), False))
         libs = []
     for ln, lib in libs:
         variants.append((ln + ":dma", lib, dict(dma=1), False))

@@ -103,11 +103,13 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
 int g_vinet_opt_dma = 1;
 int g_vinet_opt_wgrad_tr = 1;
 int g_vinet_opt_wgrad_dma = 1;
+int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad (0 = heuristic)
 
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
   if (name && !strcmp(name, "wgrad_dma")) { g_vinet_opt_wgrad_dma = value; return 0; }
+  if (name && !strcmp(name, "wgrad_tg")) { g_vinet_opt_wgrad_tg = value; return 0; }
   vinet_set_error("set_option: unknown option %s", name ? name : "(null)");
   return -1;
 }

@@ -13,6 +13,7 @@
 
 extern int g_vinet_opt_wgrad_tr;
 extern int g_vinet_opt_wgrad_dma;
+extern int g_vinet_opt_wgrad_tg;
 int vinet_launch_wgrad_dma(const VinetWgradDesc* d, hipStream_t s);
 int vinet_wgrad_dma_name(const VinetWgradDesc* d, char* buf, int n);
 
@@ -32,6 +33,7 @@ struct WgradArgs {
   int ntaps, Kp, M;
   int tilesN, tilesC, splitK, chunks_per_split, nchunks;
   int use_tr;
+  FastDiv dW, dH, dT;
 };
 
 template <typename T, int MODE>
@@ -64,12 +66,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       const int m = chunk * KV + row;
       uint4 vd = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
       if (m < a.M) {
-        const int wo = m % a.Wo;
-        const int t1 = m / a.Wo;
-        const int ho = t1 % a.Ho;
-        const int t2 = t1 / a.Ho;
-        const int to = t2 % a.To;
-        const int b = t2 / a.To;
+        int b, to, ho, wo;
+        decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
         const int n = n0 + gg * EG;
         if (n < a.N) {
           const long off = (long)b * a.sBy + ((long)(to * a.Ho + ho) * a.Wo + wo) * (long)a.ldy + n;
@@ -290,6 +288,7 @@ extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   a.chunks_per_split = vn_div_up(a.nchunks, sk);
   a.splitK = vn_div_up(a.nchunks, a.chunks_per_split);
   a.use_tr = g_vinet_opt_wgrad_tr;
+  a.dW = make_fastdiv(a.Wo); a.dH = make_fastdiv(a.Ho); a.dT = make_fastdiv(a.To);
 
   dim3 grid(a.tilesN * a.tilesC, a.ntaps, a.splitK);
   hipStream_t s = (hipStream_t)stream;

@@ -22,6 +22,8 @@
 
 #include "common.h"
 
+extern int g_vinet_opt_wgrad_tg;
+
 // (device globals are per translation unit without -fgpu-rdc: own copies of the pad pages)
 __device__ __attribute__((aligned(64))) uint4 g_wg_zero_page[4];
 __device__ __attribute__((aligned(64))) uint4 g_wg_nan_page[4] = {
@@ -288,19 +290,26 @@ static int launch_wg(WgradDmaArgs& a, hipStream_t s) {
 }
 
 // pick (tile, taps per group) from the conv geometry
-static const char* wg_pick(int N, int Cin, int ntaps, int* tn, int* tg) {
-  if (ntaps == 1) { *tn = (N >= 256 && Cin >= 256) ? 128 : 64; *tg = 1; }
-  else if (ntaps % 9 == 0) { *tn = 64; *tg = 9; }
-  else if (ntaps == 7) { *tn = 64; *tg = 7; }
-  else if (ntaps % 3 == 0) { *tn = 64; *tg = 3; }
-  else if (ntaps % 2 == 0) { *tn = 64; *tg = 2; }
-  else { *tn = 64; *tg = 1; }
+extern int g_vinet_opt_wgrad_tg;
+// Taps per group, from in-process A/B on ViNet layer shapes (tools/conv_ab.py --wgrad):
+// occupancy beats dY reuse -- 3 taps per group (3 workgroups/CU) is as fast or faster than 9
+// (1 workgroup/CU, LDS-limited) except on the very large-M 3x3 layers, and small-M layers
+// want single-tap groups (more workgroups to fill 256 CUs).  64x64 tiles throughout.
+static const char* wg_pick(int N, int Cin, int ntaps, long M, int* tn, int* tg) {
+  *tn = 64;
+  if (g_vinet_opt_wgrad_tg > 0 && ntaps % g_vinet_opt_wgrad_tg == 0) { *tg = g_vinet_opt_wgrad_tg; return nullptr; }
+  if (ntaps == 1 || M < 16384) *tg = 1;
+  else if (ntaps == 7) *tg = 7;
+  else if (ntaps % 9 == 0 && M >= 500000) *tg = 9;
+  else if (ntaps % 3 == 0) *tg = 3;
+  else if (ntaps % 2 == 0) *tg = 2;
+  else *tg = 1;
   return nullptr;
 }
 
 int vinet_wgrad_dma_name(const VinetWgradDesc* d, char* buf, int n) {
   int tn, tg;
-  wg_pick(d->dy.C, d->x.C, d->ntaps, &tn, &tg);
+  wg_pick(d->dy.C, d->x.C, d->ntaps, (long)d->dy.B * d->dy.T * d->dy.H * d->dy.W, &tn, &tg);
   snprintf(buf, n, "conv_wgrad_dma_kernel<%d,%d,%d,%s>", tn, tn, tg, d->pre.scale ? "pre" : "plain");
   return 0;
 }
@@ -316,7 +325,7 @@ int vinet_launch_wgrad_dma(const VinetWgradDesc* d, hipStream_t s) {
   a.M = (int)((long)d->dy.B * d->dy.T * d->dy.H * d->dy.W);
   a.dW = make_fastdiv(a.Wo); a.dH = make_fastdiv(a.Ho); a.dT = make_fastdiv(a.To);
   int tn, tg;
-  wg_pick(a.N, a.Cin, a.ntaps, &tn, &tg);
+  wg_pick(a.N, a.Cin, a.ntaps, a.M, &tn, &tg);
   const bool pre = d->pre.scale != nullptr;
 #define WG(TN_, TG_, ST_) \
   if (tn == TN_ && tg == TG_) return pre ? launch_wg<TN_, TN_, TG_, ST_, true>(a, s) : launch_wg<TN_, TN_, TG_, ST_, false>(a, s);
