@@ -157,6 +157,14 @@ int vinet_unpack_wgrad(const float* dw, int32_t N, int32_t Cin, int32_t ntaps, i
  * ---------------------------------------------------------------------- */
 int vinet_import_ncdhw(const float* src, int64_t sb, int64_t sc, int64_t st, int64_t sh, int64_t sw, int32_t C,
                        const VinetTensor* dst, int32_t dst_dtype, void* stream);
+/* Same, into a zero-padded buffer: dst voxel (h, w) <- src(h - pad_top, w - pad_left), zeros
+ * elsewhere (src is [.., Hs, Ws]).  Used for the RGB stem: with 3 rows / 3 pixels of padding the
+ * 1x7x7 stride-2 conv (model_utils.py:144 via model.py:693) reads, for every output and kernel
+ * row, 8 pixels x 4 channels = 64 contiguous, 16-byte aligned, always in-bounds bytes, i.e. it is
+ * a generic 7-tap conv over the overlapped view [B][T][Hs+6][(Ws+8)/2][C=32], ld = 8. */
+int vinet_import_ncdhw_pad(const float* src, int64_t sb, int64_t sc, int64_t st, int64_t sh, int64_t sw, int32_t C,
+                           int32_t Hs, int32_t Ws, int32_t pad_top, int32_t pad_left, const VinetTensor* dst,
+                           int32_t dst_dtype, void* stream);
 /* dst[b,c,t,h,w] (fp32, strides given) = pre(src); accumulate adds. */
 int vinet_export_ncdhw(const VinetTensor* src, int32_t src_dtype, VinetAffine pre, float* dst, int64_t sb, int64_t sc,
                        int64_t st, int64_t sh, int64_t sw, int32_t accumulate, void* stream);

@@ -266,6 +266,16 @@ class AbiEmulator:
         wr(dst, dst_dtype, v)
         return 0
 
+    def vinet_import_ncdhw_pad(self, src, sb, sc, st, sh, sw, Cc, Hs, Ws, pad_top, pad_left, dst, dst_dtype, stream):
+        dst = _deref(dst)
+        span = (dst.B - 1) * sb + (Cc - 1) * sc + (dst.T - 1) * st + (Hs - 1) * sh + (Ws - 1) * sw + 1
+        raw = _f32(src, span)
+        s = np.lib.stride_tricks.as_strided(raw, (dst.B, dst.T, Hs, Ws, Cc), (sb * 4, st * 4, sh * 4, sw * 4, sc * 4))
+        v = np.zeros((dst.B, dst.T, dst.H, dst.W, dst.C), np.float32)
+        v[:, :, pad_top:pad_top + Hs, pad_left:pad_left + Ws, :Cc] = s
+        wr(dst, dst_dtype, v)
+        return 0
+
     def vinet_export_ncdhw(self, src, src_dtype, pre, dst, sb, sc, st, sh, sw, accumulate, stream):
         src = _deref(src)
         v = affine(rd(src, src_dtype), pre, src.C)

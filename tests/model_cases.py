@@ -2,6 +2,7 @@
 tests/abi_emulator.py) and the GPU parity tests (real libvinet_hip.so).  Every
 case compares vinet_amd against golden vectors captured from the reference."""
 import json
+import os
 
 import numpy as np
 import torch
@@ -182,7 +183,11 @@ def train_step_case(dev, make_optimizer=None):
         e_ref = float((ref32[k] - t).norm() / (t.norm() + 1e-30))
         e_me = float((p.grad.double().cpu() - t).norm() / (t.norm() + 1e-30))
         table.append((e_me, e_ref, k))
-        assert e_me <= 3.0 * e_ref + 2e-4, "%s: rel err %.3e vs reference-fp32 %.3e" % (k, e_me, e_ref)
+        # floor 2e-3: a forward that differs from torch's by fp32 round-off (1e-7 at the stem, 1e-5 after
+        # the 12-sample BNs) flips a ~1e-5 fraction of ReLU gates, and the gradient's L2 error goes with
+        # the square root of that fraction; a 2e-6 perturbation of the oracle's own input moves these
+        # gradients by 1e-4..6e-4.  A wrong tap / pad / stride shows up at >= 1e-1.
+        assert e_me <= 3.0 * e_ref + 2e-3, "%s: rel err %.3e vs reference-fp32 %.3e" % (k, e_me, e_ref)
         worst = max(worst, e_me)
     table.sort(reverse=True)
     train_step_case.last_table = table[:8]

@@ -227,6 +227,75 @@ def test_conv3d_stem_mode(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("hw", [(18, 22), (17, 23), (32, 48)])
+def test_stem_folded(dt, hw):
+    """padded import + overlapped [.., (W+8)/2, C=32] ld=8 view: the stem as a generic 7-tap conv,
+    forward and weight gradient, vs the emulator and (fp32) torch's conv3d"""
+    B, T, N = 2, 3, 64
+    H, W = hw
+    Hp, Wp = H + 6, W + 8 + (W & 1)
+    oH, oW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    src = Pair(_rand("sfx", (B, 3, T, H, W), 1))
+    n = B * T * Hp * Wp * 4
+    buf = Pair(torch.full((n + 64,), 7.0).to(E.TORCH_DT[dt]))
+    yp, ymk = view_pair(B, T, oH, oW, N, dt, "sfy", 2)
+    wm = _rand("sfw", (N, 3, 49), 3, 1.0 / math.sqrt(147))
+    wpk = torch.zeros(7, N, 32)
+    for kh in range(7):
+        for kw in range(7):
+            wpk[kh, :, kw * 4:kw * 4 + 3] = wm[:, :, kh * 7 + kw]
+    wp = Pair(wpk.to(E.TORCH_DT[dt]))
+    taps = Pair(torch.tensor([(0, kh, 0, kh) for kh in range(7)], dtype=torch.int32))
+    sB = T * Hp * Wp * 4
+
+    def b(side):
+        return buf.cpu if side == "cpu" else buf.gpu
+
+    def mk_imp(side):
+        t = src.cpu if side == "cpu" else src.gpu
+        sb, sc, st, sh, sw = t.stride()
+        dst = E.View(b(side), 0, B, T, Hp, Wp, 4, 4, sB, dt)
+        return [t.data_ptr(), sb, sc, st, sh, sw, 3, H, W, 3, 3, C.byref(dst.ct()), dt, _stream() if side == "gpu" else 0]
+
+    run_both("vinet_import_ncdhw_pad", mk_imp)
+    _cmp(buf.get("gpu")[:n], buf.get("cpu")[:n], 0.0, "padded import")
+
+    def mk(side):
+        d = L.CConvDesc()
+        d.dtype, d.out_dtype, d.mode = dt, dt, 0
+        d.x = E.View(b(side), 0, B, T, Hp, Wp // 2, 32, 8, sB, dt).ct()
+        d.y = ymk(side).ct()
+        d.oT, d.oH, d.oW = T, oH, oW
+        d.sT, d.sH, d.sW = 1, 2, 1
+        d.omT = d.omH = d.omW = 1
+        d.ntaps, d.taps, d.w, d.Kp = 7, taps.ptr(side), wp.ptr(side), 32
+        d.pre = L.CAffine(None, None, 0)
+        return [C.byref(d), _stream() if side == "gpu" else 0]
+
+    run_both("vinet_conv3d", mk)
+    _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "folded stem conv")
+    if dt == E.F32:
+        ref = torch.nn.functional.conv3d(src.cpu, wm.view(N, 3, 1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3))
+        _cmp(yp.get("gpu").view(B, T, oH, oW, N).permute(0, 4, 1, 2, 3), ref, 2e-5, "folded stem vs torch")
+
+    dp, dmk = view_pair(B, T, oH, oW, N, dt, "sfd", 4)
+    dw = Pair(torch.zeros(7 * N * 32))
+
+    def mkw(side):
+        d = L.CWgradDesc()
+        d.dtype, d.mode = dt, 0
+        d.x = E.View(b(side), 0, B, T, Hp, Wp // 2, 32, 8, sB, dt).ct()
+        d.dy = dmk(side).ct()
+        d.sT, d.sH, d.sW = 1, 2, 1
+        d.ntaps, d.taps, d.dw, d.Kp = 7, taps.ptr(side), dw.ptr(side), 32
+        d.pre = L.CAffine(None, None, 0)
+        return [C.byref(d), _stream() if side == "gpu" else 0]
+
+    run_both("vinet_conv3d_wgrad", mkw)
+    _cmp(dw.get("gpu"), dw.get("cpu"), 3e-5 if dt == E.F32 else 2e-2, "folded stem wgrad")
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_conv3d_phase_output_mapping(dt):
     """dgrad-style launch: iteration space Q, output written at o*om+oo into a larger tensor"""
     B, Q, N, Cin = 1, (3, 4, 5), 32, 64

@@ -60,6 +60,7 @@ SIGNATURES = {
     "vinet_pack_weights": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "vinet_unpack_wgrad": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "vinet_import_ncdhw": [_vp, _i64, _i64, _i64, _i64, _i64, _i32, _PT, _i32, _vp],
+    "vinet_import_ncdhw_pad": [_vp, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _PT, _i32, _vp],
     "vinet_export_ncdhw": [_PT, _i32, CAffine, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "vinet_copy_affine": [_PT, _i32, CAffine, _PT, _i32, _i32, _vp],
     "vinet_bn_finalize": [_vp, _i32, _i32, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

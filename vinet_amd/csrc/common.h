@@ -178,7 +178,9 @@ static inline int vn_launch_status(const char* what) {
   return 0;
 }
 static inline int vn_div_up(long a, long b) { return (int)((a + b - 1) / b); }
-static inline bool vn_tensor_ok(const VinetTensor& t, int eg) {
-  return t.ptr && t.B > 0 && t.T > 0 && t.H > 0 && t.W > 0 && t.C > 0 && t.ld >= t.C && (t.ld % eg) == 0 &&
+// `overlap`: a read-only conv input may be an OVERLAPPED view (ld < C): consecutive W positions share
+// channels.  The folded RGB stem uses it (position = 2 pixels, "channels" = 8 pixels x 4).
+static inline bool vn_tensor_ok(const VinetTensor& t, int eg, bool overlap = false) {
+  return t.ptr && t.B > 0 && t.T > 0 && t.H > 0 && t.W > 0 && t.C > 0 && (overlap || t.ld >= t.C) && t.ld > 0 && (t.ld % eg) == 0 &&
          (t.C % eg) == 0 && (((uintptr_t)t.ptr) & 15) == 0 && (t.sB % eg) == 0;
 }

@@ -54,7 +54,7 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   VN_CHECK_ARG(d->out_dtype == VINET_F32 || d->out_dtype == VINET_BF16, "conv: bad out_dtype %d", d->out_dtype);
   VN_CHECK_ARG(d->mode == VINET_CONV_GENERIC || d->mode == VINET_CONV_STEM, "conv: bad mode %d", d->mode);
   const int eg = d->dtype == VINET_F32 ? 4 : 8;
-  VN_CHECK_ARG(vn_tensor_ok(d->x, d->mode == VINET_CONV_STEM ? 4 : eg),
+  VN_CHECK_ARG(vn_tensor_ok(d->x, d->mode == VINET_CONV_STEM ? 4 : eg, true),
                "conv: bad x view (C=%d ld=%d must be multiples of %d, 16-byte aligned)", d->x.C, d->x.ld, eg);
   VN_CHECK_ARG(d->y.ptr && d->y.C > 0 && d->y.ld >= d->y.C, "conv: bad y view");
   VN_CHECK_ARG(d->x.B == d->y.B, "conv: batch mismatch %d vs %d", d->x.B, d->y.B);

@@ -258,7 +258,7 @@ extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   VN_CHECK_ARG(d != nullptr, "wgrad: null descriptor");
   VN_CHECK_ARG(d->dtype == VINET_F32 || d->dtype == VINET_BF16, "wgrad: bad dtype %d", d->dtype);
   const int eg = d->dtype == VINET_F32 ? 4 : 8;
-  VN_CHECK_ARG(vn_tensor_ok(d->x, d->mode == VINET_CONV_STEM ? 4 : eg), "wgrad: bad x view");
+  VN_CHECK_ARG(vn_tensor_ok(d->x, d->mode == VINET_CONV_STEM ? 4 : eg, true), "wgrad: bad x view");
   VN_CHECK_ARG(vn_tensor_ok(d->dy, eg), "wgrad: bad dy view");
   VN_CHECK_ARG(d->x.B == d->dy.B, "wgrad: batch mismatch");
   VN_CHECK_ARG(d->ntaps > 0 && d->taps && d->dw, "wgrad: taps/dw missing");

@@ -147,6 +147,38 @@ extern "C" int vinet_import_ncdhw(const float* src, int64_t sb, int64_t sc, int6
   return vn_launch_status("import_ncdhw");
 }
 
+// import into a zero-padded buffer: dst voxel (h, w) <- src(h - pad_top, w - pad_left), zero outside
+template <typename T>
+__global__ void import_pad_kernel(const float* __restrict__ src, long sb, long sc, long st, long sh, long sw, int C,
+                                  int Hs, int Ws, int pad_top, int pad_left, TView dst, long nvox) {
+  const long vox = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vox >= nvox) return;
+  const int q = blockIdx.y;
+  int b, t, h, w;
+  decode_vox(dst, vox, b, t, h, w);
+  const int hs = h - pad_top, ws = w - pad_left;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((unsigned)hs < (unsigned)Hs && (unsigned)ws < (unsigned)Ws) {
+    const float* s = src + b * sb + t * st + hs * sh + ws * sw;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int c = q * 4 + e; if (c < C) v[e] = s[c * sc]; }
+  }
+  stq<T>((T*)dst.p + vox_off(dst, b, t, h, w) + q * 4, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+extern "C" int vinet_import_ncdhw_pad(const float* src, int64_t sb, int64_t sc, int64_t st, int64_t sh, int64_t sw,
+                                      int32_t C, int32_t Hs, int32_t Ws, int32_t pad_top, int32_t pad_left,
+                                      const VinetTensor* dst, int32_t dst_dtype, void* stream) {
+  VN_CHECK_ARG(src && dst && quad_ok(*dst, esize(dst_dtype)) && C > 0 && C <= dst->C && Hs > 0 && Ws > 0 &&
+                   pad_top >= 0 && pad_left >= 0 && pad_top + Hs <= dst->H && pad_left + Ws <= dst->W,
+               "import_ncdhw_pad: bad arguments");
+  const long nvox = view_voxels(*dst);
+  DISPATCH_T(dst_dtype, T, hipLaunchKernelGGL(import_pad_kernel<T>, dim3(ew_grid(nvox), dst->C / 4), dim3(256), 0,
+                                              (hipStream_t)stream, src, sb, sc, st, sh, sw, C, Hs, Ws, pad_top, pad_left,
+                                              make_view(*dst), nvox);)
+  return vn_launch_status("import_ncdhw_pad");
+}
+
 template <typename T>
 __global__ void export_ncdhw_kernel(TView src, Affine pre, float* __restrict__ dst, long sb, long sc, long st, long sh,
                                     long sw, int accumulate, long nvox) {

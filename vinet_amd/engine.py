@@ -21,6 +21,7 @@ Concepts
 import ctypes as C
 import itertools
 import math
+import os
 
 import torch
 
@@ -35,6 +36,7 @@ _DEFAULT_DTYPE = BF16
 _WEIGHTS_EPOCH = 0
 # Weight gradients are off the backward critical path (only the optimizer consumes them):
 # they run on a second HIP stream, concurrently with the dgrad / BN-backward chain.
+STEM_FOLD = os.environ.get("VINET_STEM_FOLD", "1") != "0"   # padded/folded stem input (A/B switch)
 WGRAD_SIDE_STREAM = True
 _SIDE_STREAMS = {}
 
@@ -155,12 +157,13 @@ class View:
 
 class Act:
     """activation = view + pending affine/relu + gradient bookkeeping."""
-    __slots__ = ("v", "scale", "shift", "relu", "_grad", "grad_ready", "needs_grad", "parent", "pc0", "pt0")
+    __slots__ = ("v", "scale", "shift", "relu", "_grad", "grad_ready", "needs_grad", "parent", "pc0", "pt0", "fold")
 
     def __init__(self, v, scale=None, shift=None, relu=False, needs_grad=False):
         self.v, self.scale, self.shift, self.relu = v, scale, shift, relu
         self._grad, self.grad_ready, self.needs_grad = None, False, needs_grad
         self.parent, self.pc0, self.pt0 = None, 0, 0
+        self.fold = None
 
     @property
     def plain(self):
@@ -276,6 +279,23 @@ def import_ncdhw(ctx, t, cpad=None, needs_grad=False):
     sb, sc, st, sh, sw = t.stride()
     ctx.call("vinet_import_ncdhw", t.data_ptr(), sb, sc, st, sh, sw, Cc, C.byref(v.ct()), ctx.dt, ctx.stream)
     a = Act(v, needs_grad=needs_grad)
+    return a
+
+
+def import_video_folded(ctx, t):
+    """RGB clip [B,3,T,H,W] (any strides, no gradient needed) -> Act over the *overlapped* view
+    [B][T][H+6][(W+8)/2][C=32], ld = 8, of a zero-padded 4-channel buffer: the form in which the
+    1x7x7 stride-2 stem is a generic 7-tap conv for the LDS-DMA kernels (see vinet_import_ncdhw_pad)."""
+    assert t.dim() == 5 and t.dtype == torch.float32 and t.shape[1] == 3
+    B, Cc, T, H, W = t.shape
+    Hp, Wp = H + 6, W + 8 + (W & 1)
+    n = B * T * Hp * Wp * 4
+    buf = torch.empty(n + 64, dtype=TORCH_DT[ctx.dt], device=t.device)   # slack: the last positions' rows overhang
+    padded = View(buf, 0, B, T, Hp, Wp, 4, 4, T * Hp * Wp * 4, ctx.dt)
+    sb, sc, st, sh, sw = t.stride()
+    ctx.call("vinet_import_ncdhw_pad", t.data_ptr(), sb, sc, st, sh, sw, Cc, H, W, 3, 3, C.byref(padded.ct()), ctx.dt, ctx.stream)
+    a = Act(View(buf, 0, B, T, Hp, Wp // 2, 32, 8, T * Hp * Wp * 4, ctx.dt))
+    a.fold = (H, W)     # original extent: output is ((H-1)//2+1, (W-1)//2+1)
     return a
 
 
@@ -398,6 +418,11 @@ class ConvPlan:
             self._taps[k] = t
         return t
 
+    def folded_taps(self, device):
+        """stem over the folded view: one tap per kernel row, no padding (the buffer is padded)"""
+        rows = [(0, kh, 0, kh) for kh in range(self.k[1])]
+        return self._dev_taps("fold", rows, device), len(rows)
+
     def fwd_taps(self, device):
         kT, kH, kW = self.k
         pT, pH, pW = self.p
@@ -485,7 +510,11 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     """
     lib_dt = ctx.dt
     xv = x.v
-    oT, oH, oW = plan.out_dims(xv.T, xv.H, xv.W)
+    folded = plan.stem and x.fold is not None
+    if folded:
+        oT, oH, oW = xv.T, (x.fold[0] - 1) // 2 + 1, (x.fold[1] - 1) // 2 + 1
+    else:
+        oT, oH, oW = plan.out_dims(xv.T, xv.H, xv.W)
     Ny = plan.N if n_pad is None else n_pad
     odt = lib_dt if out_dt is None else out_dt
     if dst is None:
@@ -493,14 +522,14 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     out = dst.v
     scale_out, shift_out = dst.scale, dst.shift
     assert (out.B, out.T, out.H, out.W, out.C) == (xv.B, oT, oH, oW, Ny), "conv output view mismatch"
-    taps, ntaps = plan.fwd_taps(ctx.device)
+    taps, ntaps = plan.folded_taps(ctx.device) if folded else plan.fwd_taps(ctx.device)
     w = plan.packed(ctx, False)
 
     d = L.CConvDesc()
-    d.dtype, d.out_dtype, d.mode = lib_dt, out.dt, (L.CONV_STEM if plan.stem else L.CONV_GENERIC)
+    d.dtype, d.out_dtype, d.mode = lib_dt, out.dt, (L.CONV_STEM if (plan.stem and not folded) else L.CONV_GENERIC)
     d.x, d.y = xv.ct(), out.ct()
     d.oT, d.oH, d.oW = oT, oH, oW
-    d.sT, d.sH, d.sW = plan.s
+    d.sT, d.sH, d.sW = (1, 2, 1) if folded else plan.s
     d.omT = d.omH = d.omW = 1
     d.ooT = d.ooH = d.ooW = 0
     d.ntaps, d.taps, d.w, d.Kp = ntaps, taps.data_ptr(), w.data_ptr(), plan.kp(False)
@@ -623,14 +652,15 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             if side is not None:
                 ctx.stream = side.cuda_stream
             try:
-                taps, ntaps = plan.fwd_taps(ctx.device)
+                folded = plan.stem and x.fold is not None
+                taps, ntaps = plan.folded_taps(ctx.device) if folded else plan.fwd_taps(ctx.device)
                 kp = plan.kp(False)
                 nsl = 7 if plan.stem else plan.ntaps
                 dw = ctx.f32(nsl * Ny * kp, zero=True)
                 wd = L.CWgradDesc()
-                wd.dtype, wd.mode = ctx.dt, (L.CONV_STEM if plan.stem else L.CONV_GENERIC)
+                wd.dtype, wd.mode = ctx.dt, (L.CONV_STEM if (plan.stem and not folded) else L.CONV_GENERIC)
                 wd.x, wd.dy = x.v.ct(), dy.ct()
-                wd.sT, wd.sH, wd.sW = plan.s
+                wd.sT, wd.sH, wd.sW = (1, 2, 1) if folded else plan.s
                 wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), kp
                 wd.pre = x.affine()
                 es = ESIZE[ctx.dt]

@@ -160,7 +160,8 @@ class _MapBody:
         acts = []
         for i, (t, r) in enumerate(zip(inputs, req)):
             if self.video and i == 0:
-                acts.append(E.import_ncdhw(ectx, t, 4, needs_grad=r))
+                # the clip needs no gradient in training or inference: folded, padded stem input
+                acts.append(E.import_video_folded(ectx, t) if (not r and E.STEM_FOLD) else E.import_ncdhw(ectx, t, 4, needs_grad=r))
             elif self.audio and i == len(inputs) - 1:
                 # [B,1,L,1] waveform -> [B, T=L, 1, 1, Cpad]
                 acts.append(E.import_ncdhw(ectx, t.unsqueeze(-1), None, needs_grad=r))
