@@ -135,7 +135,15 @@ class AbiEmulator:
     # -- conv ----------------------------------------------------------------
     def vinet_conv3d_tile_m(self, d):
         d = _deref(d)
-        return _tile_m(d.dtype, d.mode, d.x.B * d.oT * d.oH * d.oW, d.y.C)
+        M, N = d.x.B * d.oT * d.oH * d.oW, d.y.C
+        # conv_api.hip::use_pp -- the 256x256x64 kernel takes large plain bf16 convs
+        if d.dtype == BF16 and d.mode == 0 and not d.pre.scale and not d.pre.relu and d.ntaps <= 64:
+            nkt = d.ntaps * ((d.Kp + 63) // 64)
+            bn = 192 if ((N + 191) // 192 * 192) * 20 <= ((N + 255) // 256 * 256) * 17 else 256
+            tiles = ((M + 255) // 256) * ((N + bn - 1) // bn)
+            if N >= 160 and nkt >= 16 and tiles >= 128:
+                return 256
+        return _tile_m(d.dtype, d.mode, M, N)
 
     def vinet_conv3d_kernel_name(self, d, buf, n):
         return 0

@@ -140,6 +140,36 @@ def _fwd_taps(k, p):
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv3d(case, dt):
+    _run_conv_case(case, dt)
+
+
+# the 256x256x64 ping-pong kernel, forced on shapes it would not normally be chosen for as well:
+# partial tiles in M and N, N > 256, odd and even K-tile counts, Kp % 64 == 32, 45 taps, strides,
+# T-sliced inputs, channel-sliced outputs, statistics, accumulate, fp32 head
+PP_CASES = [c for c in CONV_CASES if not c[7].get("pre")] + [
+    ("pp_multi_tile", (2, 4, 14, 24), 192, 480, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(stats=True)),
+    ("pp_kp96_odd", (1, 3, 9, 10), 96, 272, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(act=1)),
+    ("pp_45taps", (1, 10, 6, 8), 64, 320, (5, 3, 3), (5, 1, 1), (0, 1, 1), dict(stats=True, act=1)),
+    ("pp_one_ktile", (1, 2, 20, 20), 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), {}),
+    ("pp_stride2", (1, 9, 12, 12), 128, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1), {}),
+]
+
+
+@pytest.mark.parametrize("shape", [3, 4], ids=["bn256", "bn192"])
+@pytest.mark.parametrize("case", PP_CASES, ids=[c[0] for c in PP_CASES])
+def test_conv3d_pingpong(case, shape):
+    lib = _lib()
+    assert lib.vinet_set_option(b"pp", shape) == 0     # 3 / 4: force the 256- / 192-wide shape
+    try:
+        d0 = _run_conv_case(case, E.BF16, forced=True)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0
+        assert buf.value == (b"conv_pp_kernel<256>" if shape == 3 else b"conv_pp_kernel<192>")
+    finally:
+        lib.vinet_set_option(b"pp", 1)
+
+
+def _run_conv_case(case, dt, forced=False):
     name, (B, T, H, W), Cin, N, k, s, p, ex = case
     oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
     xp, xmk = view_pair(B, T, H, W, Cin, dt, "x" + name, 1, t_total=ex.get("in_ttotal"), t_off=ex.get("in_toff", 0))
@@ -182,11 +212,12 @@ def test_conv3d(case, dt):
     if ex.get("stats"):
         d0 = mk("gpu")[0]._obj
         bm = _lib().vinet_conv3d_tile_m(C.byref(d0))
-        assert bm == AbiEmulator().vinet_conv3d_tile_m(d0)
+        assert forced or bm == AbiEmulator().vinet_conv3d_tile_m(d0)
         r = (M + bm - 1) // bm
         sg = stats.get("gpu")[:r * 2 * N].view(r, 2, N).double().sum(0)
         sc = stats.get("cpu")[:r * 2 * N].view(r, 2, N).double().sum(0)
         _cmp(sg, sc, 1e-4 if dt == E.F32 else 2e-2, "conv stats " + name)
+    return mk("gpu")[0]._obj
 
 
 @pytest.mark.parametrize("dt", DTS)

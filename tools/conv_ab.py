@@ -31,6 +31,14 @@ SITES = [
     ("dec2 832->480 3x3x3/3", 8, 12, 14, 24, 832, 480, (3, 3, 3), (3, 1, 1), (0, 1, 1)),
     ("dec3 480->192 5x3x3/5", 8, 20, 28, 48, 480, 192, (5, 3, 3), (5, 1, 1), (0, 1, 1)),
     ("dec4 192->64 5x3x3/5", 8, 20, 56, 96, 192, 64, (5, 3, 3), (5, 1, 1), (0, 1, 1)),
+    # dgrad phases of the T-strided decoder convs: stride-1 1x3x3 correlations, channels swapped
+    ("dg dec1 832->1024", 8, 4, 7, 12, 832, 1024, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dg dec2 480->832 /ph", 8, 4, 14, 24, 480, 832, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dg dec3 192->480 /ph", 8, 4, 28, 48, 192, 480, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dg dec4 64->192 /ph", 8, 4, 56, 96, 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dg 3c s 192->128", 8, 16, 28, 48, 192, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dg 4x s 320->160", 8, 8, 14, 24, 320, 160, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dg 4x t 320->320", 8, 8, 14, 24, 320, 320, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
 ]
 
 
@@ -49,18 +57,12 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--wgrad", action="store_true")
-    ap.add_argument("--ablate", action="store_true", help="DMA conv kernel: full / fill-only / compute-only")
+    ap.add_argument("--batch", type=int, default=8)
     args = ap.parse_args()
     libs = [(os.path.basename(p), bind(p)) for p in (args.lib or [L.LIB_PATH])]
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     variants = []
-    if args.ablate:
-        for ln, lib in libs:
-            variants.append((ln + ":full", lib, dict(dma=1, ablate=0), False))
-            variants.append((ln + ":fill-only", lib, dict(dma=1, ablate=1), False))
-            variants.append((ln + ":mfma-only", lib, dict(dma=1, ablate=2), False))
-        libs = []
     if args.wgrad:
         for ln, lib in libs:
             variants.append((ln + ":wdma", lib, dict(wgrad_dma=1, wgrad_tg=0), False))
@@ -70,12 +72,14 @@ def main():
             variants.append((ln + ":tg1", lib, dict(wgrad_dma=1, wgrad_tg=1), False))
         libs = []
     for ln, lib in libs:
-        variants.append((ln + ":dma", lib, dict(dma=1), False))
-        variants.append((ln + ":dma+pre", lib, dict(dma=1), True))
-        variants.append((ln + ":igemm", lib, dict(dma=0), False))
-        variants.append((ln + ":igemm+pre", lib, dict(dma=0), True))
-    print("%-26s" % "site" + "".join("%22s" % v[0][-21:] for v in variants) + "   (ms | TF/s)")
+        variants.append((ln + ":pp256", lib, dict(dma=1, pp=3), False))
+        variants.append((ln + ":pp192", lib, dict(dma=1, pp=4), False))
+        variants.append((ln + ":dma", lib, dict(dma=1, pp=0), False))
+        variants.append((ln + ":dma+pre", lib, dict(dma=1, pp=0), True))
+
+    print("%-26s" % "site" + "".join("%22s" % (v[0][-21:].replace("libvinet_hip", "")) for v in variants) + "   (ms | TF/s)")
     for (name, B, T, H, W, Cin, N, k, s, p) in SITES:
+        B = args.batch
         oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
         x = torch.randn(B * T * H * W * Cin, device=dev).bfloat16()
         y = torch.empty(B * oT * oH * oW * N, device=dev, dtype=torch.bfloat16)

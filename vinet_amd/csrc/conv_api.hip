@@ -94,8 +94,11 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   return 0;
 }
 
+static bool use_pp(const VinetConvDesc* d);
+
 extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   if (!d) return -1;
+  if (use_pp(d)) return 256;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C).BM();
 }
@@ -103,10 +106,12 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
 int g_vinet_opt_dma = 1;
 int g_vinet_opt_wgrad_tr = 1;
 int g_vinet_opt_wgrad_dma = 1;
+int g_vinet_opt_pp = 1;         // 256x256x64 ping-pong kernel for large plain convs
 int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad (0 = heuristic)
 
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
+  if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
   if (name && !strcmp(name, "wgrad_dma")) { g_vinet_opt_wgrad_dma = value; return 0; }
   if (name && !strcmp(name, "wgrad_tg")) { g_vinet_opt_wgrad_tg = value; return 0; }
@@ -122,11 +127,35 @@ static bool use_dma(const VinetConvDesc* d) {
          !(d->pre.relu && !d->pre.scale);
 }
 
+// tile width of the ping-pong kernel: 256 or 192, whichever pads N less (ties: 256)
+static int pp_bn(int N) {
+  if (g_vinet_opt_pp == 3) return 256;   // tuning: force shapes
+  if (g_vinet_opt_pp == 4) return 192;
+  // measured (tools/conv_ab.py): the 192 shape does 12 MFMAs per phase against the same staging
+  // work, so it only wins when it saves at least ~15% of the padded columns
+  const int p256 = (N + 255) / 256 * 256, p192 = (N + 191) / 192 * 192;
+  return p192 * 20 <= p256 * 17 ? 192 : 256;
+}
+
+// conv_pp.h: plain bf16 inputs, enough K tiles to amortise the 6-half-tile prologue, enough
+// output channels to use a 256-wide tile, enough tiles to occupy the chip
+static bool use_pp(const VinetConvDesc* d) {
+  if (!g_vinet_opt_pp || !use_dma(d) || d->pre.scale || d->ntaps > 64) return false;
+  const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  const int N = d->y.C;
+  const long nkt = (long)d->ntaps * ((d->Kp + 63) / 64);
+  const int bn = pp_bn(N);
+  const long tiles = ((M + 255) / 256) * ((N + bn - 1) / bn);
+  if (g_vinet_opt_pp >= 2) return true;   // tuning: force
+  return N >= 160 && nkt >= 16 && tiles >= 128;
+}
+
 extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32_t n) {
   if (!d || !buf || n <= 0) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C);
-  if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
+  if (use_pp(d)) snprintf(buf, n, "conv_pp_kernel<%d>", pp_bn(d->y.C));
+  else if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
   else snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", t.MT, t.NT, t.WM, t.WN, d->mode);
   return 0;
 }
@@ -136,6 +165,12 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
   ConvTile t;
   int rc = fill_args(d, a, t);
   if (rc) return rc;
+  if (use_pp(d)) {
+    const int bn = pp_bn(a.N);
+    a.tilesM = vn_div_up(a.M, 256);
+    a.tilesN = vn_div_up(a.N, bn);
+    return vinet_launch_conv_pp_bf16(bn, a, (hipStream_t)stream);
+  }
   if (use_dma(d)) return vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);
   if (d->dtype == VINET_BF16) return vinet_launch_conv_bf16(t, d->mode, a, (hipStream_t)stream);
   return vinet_launch_conv_f32(t, d->mode, a, (hipStream_t)stream);

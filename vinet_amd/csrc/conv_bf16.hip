@@ -1,5 +1,6 @@
 // bf16 instantiations of the implicit-GEMM convolution.
 #include "conv_dma.h"
+#include "conv_pp.h"
 
 #define CASE(MT_, NT_, WM_, WN_)                                                            \
   if (t.MT == MT_ && t.NT == NT_ && t.WM == WM_ && t.WN == WN_)                             \
@@ -24,4 +25,9 @@ int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t
   DMA_CASE(4, 4, 2, 2) DMA_CASE(4, 2, 2, 2) DMA_CASE(2, 4, 2, 2) DMA_CASE(2, 2, 2, 2)
   vinet_set_error("conv dma bf16: no kernel for tile MT=%d NT=%d WM=%d WN=%d", t.MT, t.NT, t.WM, t.WN);
   return -1;
+}
+
+// 256x256x64 ping-pong kernel (conv_pp.h): plain inputs only
+int vinet_launch_conv_pp_bf16(int bn, const ConvArgs& a, hipStream_t s) {
+  return bn == 192 ? launch_conv_pp_cfg<4, 2, 192>(a, s) : launch_conv_pp_cfg<2, 4, 256>(a, s);
 }

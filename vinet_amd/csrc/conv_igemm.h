@@ -75,55 +75,26 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   constexpr int WNC = NT * 16, EROW = WNC + 4;
   float* Ew = (float*)smem + wave * (16 * EROW);
-  float* red = (float*)smem + 4 * 16 * EROW;
+  float* red = (float*)smem + (WARPS_M * WARPS_N) * 16 * EROW;
   const int m_wave = tile_m * BM + wm * MT * 16;
   const int n_wave = tile_n * BN + wn * WNC;
   const bool do_stats = a.stats != nullptr;
   const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;   // branch-free ReLU: max(v, floor)
 
-  {
-    float s_sum[NT], s_sq[NT];
+  // per-column epilogue constants and running BN partial sums (accumulated row group by row
+  // group below, so only ONE 16-row group of the accumulator is live in VGPRs at a time:
+  // a 128-register accumulator tile leaves no room for a whole-tile first pass)
+  float sc[NT], sh[NT], s_sum[NT], s_sq[NT];
+  bool nok[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n_wave + j * 16 + (lane & 15);
-      const bool nok = n < a.Nw;
-      const float sc = (a.out_scale && nok) ? a.out_scale[n] : 1.f;
-      const float sh = (a.out_shift && nok) ? a.out_shift[n] : 0.f;
-      float ss = 0.f, qq = 0.f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m_wave + i * 16 + (lane >> 4) * 4 + r;
-          const float v = fmaf(acc[i][j][r], sc, sh);
-          const float vs = (nok && m < a.M) ? v : 0.f;
-          ss += vs; qq += vs * vs;
-          acc[i][j][r] = fmaxf(v, relu_floor);
-        }
-      s_sum[j] = ss; s_sq[j] = qq;
-    }
-    if (a.act == VINET_ACT_SIGMOID) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] = 1.f / (1.f + __expf(-acc[i][j][r]));
-    }
-    if (do_stats) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float ss = s_sum[j], qq = s_sq[j];
-        ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
-        qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
-        if (lane < 16) {
-          const int col = wn * WNC + j * 16 + lane;
-          red[(wm * BN + col) * 2 + 0] = ss;
-          red[(wm * BN + col) * 2 + 1] = qq;
-        }
-      }
-    }
+  for (int j = 0; j < NT; ++j) {
+    const int n = n_wave + j * 16 + (lane & 15);
+    nok[j] = n < a.Nw;
+    sc[j] = (a.out_scale && nok[j]) ? a.out_scale[n] : 1.f;
+    sh[j] = (a.out_shift && nok[j]) ? a.out_shift[n] : 0.f;
+    s_sum[j] = 0.f; s_sq[j] = 0.f;
   }
+  const bool sigm = a.act == VINET_ACT_SIGMOID;
 
   // common case: bf16 output, 4-channel vectors, plain store, output offset linear in m
   const bool fast = a.vec_ok && !a.out_f32 && !a.accumulate && a.y_linear;
@@ -135,7 +106,15 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Ew[((lane >> 4) * 4 + r) * EROW + j * 16 + (lane & 15)] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) {
+        const int m = m_wave + i * 16 + (lane >> 4) * 4 + r;
+        const float v = fmaf(acc[i][j][r], sc[j], sh[j]);
+        const float vs = (nok[j] && m < a.M) ? v : 0.f;
+        s_sum[j] += vs; s_sq[j] += vs * vs;
+        float o = fmaxf(v, relu_floor);
+        if (sigm) o = 1.f / (1.f + __expf(-o));
+        Ew[((lane >> 4) * 4 + r) * EROW + j * 16 + (lane & 15)] = o;
+      }
     wave_lds_fence();
     if (fast) {
 #pragma unroll
@@ -200,6 +179,17 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   }
 
   if (do_stats) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float ss = s_sum[j], qq = s_sq[j];
+      ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+      qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
+      if (lane < 16) {
+        const int col = wn * WNC + j * 16 + lane;
+        red[(wm * BN + col) * 2 + 0] = ss;
+        red[(wm * BN + col) * 2 + 1] = qq;
+      }
+    }
     __syncthreads();    // cross-wave hand-off of the per-wave column sums
     if (tid < BN) {
       const int n = tile_n * BN + tid;
@@ -408,6 +398,7 @@ ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N);
 int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t s);
+int vinet_launch_conv_pp_bf16(int bn, const ConvArgs& a, hipStream_t s);
 
 template <typename T, int MT, int NT, int WM, int WN, int MODE>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
