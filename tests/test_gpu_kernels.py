@@ -366,6 +366,33 @@ WGRAD_CASES = [
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
 def test_conv3d_wgrad(case, dt):
+    _run_wgrad_case(case, dt)
+
+
+# the 256x256x64 ping-pong wgrad, forced: partial row tiles (N < 256, N > 256), partial segment tiles,
+# Cin not a multiple of 64, pending affine, T stride, odd K-tile counts, split-K
+WGRAD_PP_CASES = WGRAD_CASES + [
+    ("pp_n320_c192", (2, 4, 10, 12), 192, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1), True),
+    ("pp_c480_t5", (1, 10, 6, 8), 480, 192, (5, 3, 3), (5, 1, 1), (0, 1, 1), False),
+    ("pp_c96_3t", (2, 5, 9, 9), 96, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), True),
+    ("pp_bigm", (4, 8, 28, 48), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), True),
+]
+
+
+@pytest.mark.parametrize("shape", [3, 4], ids=["tn256", "tn192"])
+@pytest.mark.parametrize("case", WGRAD_PP_CASES, ids=[c[0] for c in WGRAD_PP_CASES])
+def test_conv3d_wgrad_pingpong(case, shape):
+    lib = _lib()
+    assert lib.vinet_set_option(b"wgrad_pp", shape) == 0      # 3 / 4: force the 256- / 192-row tile
+    try:
+        d0 = _run_wgrad_case(case, E.BF16)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_wgrad_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_wgrad_pp_kernel")
+    finally:
+        lib.vinet_set_option(b"wgrad_pp", 1)
+
+
+def _run_wgrad_case(case, dt):
     name, (B, T, H, W), Cin, N, k, s, p, pre = case
     oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
     xp, xmk = view_pair(B, T, H, W, Cin, dt, "wx" + name, 1)
@@ -387,6 +414,7 @@ def test_conv3d_wgrad(case, dt):
 
     run_both("vinet_conv3d_wgrad", mk)
     _cmp(dw.get("gpu"), dw.get("cpu"), 3e-5 if dt == E.F32 else 2e-2, "wgrad " + name)
+    return mk("gpu")[0]._obj
 
 
 @pytest.mark.parametrize("dt", DTS)

@@ -65,11 +65,11 @@ def main():
     variants = []
     if args.wgrad:
         for ln, lib in libs:
-            variants.append((ln + ":wdma", lib, dict(wgrad_dma=1, wgrad_tg=0), False))
-            variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0), True))
-            variants.append((ln + ":tg3", lib, dict(wgrad_dma=1, wgrad_tg=3), False))
-            variants.append((ln + ":tg3+pre", lib, dict(wgrad_dma=1, wgrad_tg=3), True))
-            variants.append((ln + ":tg1", lib, dict(wgrad_dma=1, wgrad_tg=1), False))
+            variants.append((ln + ":wpp256", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=3), False))
+            variants.append((ln + ":wpp192", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=4), False))
+            variants.append((ln + ":wpp192+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=4), True))
+            variants.append((ln + ":wdma", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0), False))
+            variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0), True))
         libs = []
     for ln, lib in libs:
         variants.append((ln + ":pp256", lib, dict(dma=1, pp=3), False))

@@ -16,6 +16,8 @@ extern int g_vinet_opt_wgrad_dma;
 extern int g_vinet_opt_wgrad_tg;
 int vinet_launch_wgrad_dma(const VinetWgradDesc* d, hipStream_t s);
 int vinet_wgrad_dma_name(const VinetWgradDesc* d, char* buf, int n);
+bool vinet_wgrad_use_pp(const VinetWgradDesc* d);
+int vinet_launch_wgrad_pp(const VinetWgradDesc* d, hipStream_t s);
 
 struct WgradArgs {
   const char* x;
@@ -249,6 +251,7 @@ static bool wgrad_use_dma(const VinetWgradDesc* d) {
 
 extern "C" int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* d, char* buf, int32_t n) {
   if (!d || !buf || n <= 0) return -1;
+  if (wgrad_use_dma(d) && vinet_wgrad_use_pp(d)) { snprintf(buf, n, "conv_wgrad_pp_kernel<%s>", d->pre.scale ? "pre" : "plain"); return 0; }
   if (wgrad_use_dma(d)) return vinet_wgrad_dma_name(d, buf, n);
   snprintf(buf, n, "conv_wgrad_kernel<%s,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", d->mode);
   return 0;
@@ -266,6 +269,7 @@ extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   if (d->mode == VINET_CONV_STEM) VN_CHECK_ARG(d->x.C == 4 && d->Kp == 32, "wgrad stem: x.C must be 4, Kp 32");
   else VN_CHECK_ARG(d->Kp >= d->x.C, "wgrad: Kp < Cin");
 
+  if (wgrad_use_dma(d) && vinet_wgrad_use_pp(d)) return vinet_launch_wgrad_pp(d, (hipStream_t)stream);
   if (wgrad_use_dma(d)) return vinet_launch_wgrad_dma(d, (hipStream_t)stream);
   WgradArgs a;
   a.x = (const char*)d->x.ptr; a.dy = (const char*)d->dy.ptr; a.dw = d->dw; a.taps = (const int4*)d->taps;

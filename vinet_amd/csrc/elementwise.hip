@@ -725,11 +725,78 @@ __global__ void maxpool_bwd_kernel(PoolP p, TView dy, const uint8_t* __restrict_
   stq<T>(dst, make_float4(g[0], g[1], g[2], g[3]));
 }
 
+// 3x3x3 / stride 1 / pad 1 (the Inception branch-3 pools, model_utils.py:178): every input voxel
+// is covered by up to 27 windows.  One thread owns 8 channels of one voxel, issues all 27
+// argmax loads (8 codes = 8 bytes each) before looking at any of them, and reads dy only for
+// the windows that route a gradient here.  The generic kernel walks the same 27 windows as a
+// dependent load -> compare -> branch chain and is latency bound (0.5 TB/s).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s1_kernel(TView dy, const uint8_t* __restrict__ argmax, TView dx,
+                                                               int accumulate, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = dx.C >> 3;
+  const uint32_t vox_u = (uint32_t)(i / G);          // G is small and launch-invariant; one division per thread
+  const int g = (int)(i - (long)vox_u * G);
+  int b, t, h, w;
+  decode_vox(dx, (long)vox_u, b, t, h, w);
+  const int T_ = dx.T, H = dx.H, W = dx.W;
+  const long am_c = (long)vox_u * dx.C + g * 8;
+  const long dy_c = vox_off(dy, b, t, h, w) + g * 8;
+  unsigned long long am[27];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        // window (t+1-kt, h+1-kh, w+1-kw) holds this voxel as its tap (kt,kh,kw)
+        const int dt = 1 - kt, dh = 1 - kh, dw = 1 - kw;
+        const bool ok = (unsigned)(t + dt) < (unsigned)T_ && (unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W;
+        const long d = ((long)(dt * H + dh) * W + dw) * (long)dx.C;
+        am[(kt * 3 + kh) * 3 + kw] = ok ? *(const unsigned long long*)(argmax + am_c + d) : ~0ull;
+      }
+  float gr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tap = (kt * 3 + kh) * 3 + kw;
+        const unsigned long long xr = am[tap] ^ (0x0101010101010101ull * (unsigned long long)tap);
+        if (!((xr - 0x0101010101010101ull) & ~xr & 0x8080808080808080ull)) continue;   // no zero byte: no match
+        const int dt = 1 - kt, dh = 1 - kh, dw = 1 - kw;
+        const T* src = (const T*)dy.p + dy_c + ((long)(dt * H + dh) * W + dw) * (long)dy.ld;
+        const float4 d0 = ldq<T>(src), d1 = ldq<T>(src + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (((xr >> (8 * e)) & 0xffull) == 0) gr[e] += dv[e];
+      }
+  T* dst = (T*)dx.p + vox_off(dx, b, t, h, w) + g * 8;
+  if (accumulate) {
+    const float4 o0 = ldq<T>(dst), o1 = ldq<T>(dst + 4);
+    gr[0] += o0.x; gr[1] += o0.y; gr[2] += o0.z; gr[3] += o0.w; gr[4] += o1.x; gr[5] += o1.y; gr[6] += o1.z; gr[7] += o1.w;
+  }
+  stq<T>(dst, make_float4(gr[0], gr[1], gr[2], gr[3]));
+  stq<T>(dst + 4, make_float4(gr[4], gr[5], gr[6], gr[7]));
+}
+
 extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy, const uint8_t* argmax,
                                    const VinetTensor* dx, int32_t accumulate, void* stream) {
   VN_CHECK_ARG(d && dy && dx && argmax && quad_ok(*dy, esize(d->dtype)) && quad_ok(*dx, esize(d->dtype)) &&
                    dx->C == dy->C && dx->B == dy->B, "maxpool3d_bwd: bad views");
   const PoolP p = make_poolp(d);
+  const bool k3s1 = d->kT == 3 && d->kH == 3 && d->kW == 3 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 1 && d->pH == 1 &&
+                    d->pW == 1 && dy->T == dx->T && dy->H == dx->H && dy->W == dx->W;
+  if (k3s1 && dx->C % 8 == 0 && dx->ld % 8 == 0 && dy->ld % 8 == 0 && dx->sB % 8 == 0 && dy->sB % 8 == 0 &&
+      ((uintptr_t)dx->ptr % 16) == 0 && ((uintptr_t)dy->ptr % 16) == 0 && ((uintptr_t)argmax % 8) == 0) {
+    const long total8 = view_voxels(*dx) * (dx->C / 8);
+    DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_k3s1_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
+                                               make_view(*dy), argmax, make_view(*dx), accumulate, total8);)
+    return vn_launch_status("maxpool3d_bwd(k3s1)");
+  }
   const long total = view_voxels(*dx) * (dx->C / 4);
   DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
                                              (hipStream_t)stream, p, make_view(*dy), argmax, make_view(*dx), accumulate, total);)
