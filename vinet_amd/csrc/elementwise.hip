@@ -17,6 +17,24 @@ template <typename T> VN_DEV void stq(T* p, float4 v);
 template <> VN_DEV void stq<float>(float* p, float4 v) { *(float4*)p = v; }
 template <> VN_DEV void stq<bf16_t>(bf16_t* p, float4 v) { *(uint2*)p = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w)); }
 
+// ---- 8-channel typed access (16 bytes bf16 / 32 bytes fp32): the wide form the streaming kernels use
+//      whenever the channel count and alignment allow it --------------------------------------------
+template <typename T> VN_DEV void ld8(const T* p, float* f);
+template <> VN_DEV void ld8<float>(const float* p, float* f) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <> VN_DEV void ld8<bf16_t>(const bf16_t* p, float* f) { unpack16<bf16_t>(*(const uint4*)p, f); }
+template <typename T> VN_DEV void st8(T* p, const float* f);
+template <> VN_DEV void st8<float>(float* p, const float* f) {
+  *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+  *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+template <> VN_DEV void st8<bf16_t>(bf16_t* p, const float* f) { *(uint4*)p = pack16<bf16_t>(f); }
+static inline bool oct_ok(const VinetTensor& t) {
+  return t.ptr && t.C > 0 && (t.C % 8) == 0 && (t.ld % 8) == 0 && t.ld >= t.C && (t.sB % 8) == 0 && (((uintptr_t)t.ptr) % 16) == 0;
+}
+
 VN_DEV float4 affine4(float4 v, const Affine& a, int c) {
   if (a.scale) {
     const float4 s = *(const float4*)(a.scale + c);
@@ -305,6 +323,82 @@ extern "C" int vinet_bn_fold(const float* gamma, const float* beta, const float*
 // Per-channel reductions over voxels.  Thread (q, r): channel quad q, voxel lane
 // r; a block covers `vb` consecutive voxels and writes one partial row.
 // MODE 0: (sum x, sum x^2) of x;  MODE 1: (sum dz*mask, sum dz*mask*xhat).
+
+// 8-channel form of channel_reduce_kernel: same partials contract ([rows][2][C], block b owns voxels
+// [b*vb, (b+1)*vb)), twice the bytes per load instruction.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void channel_reduce8_kernel(TView x, TView dz, Affine fwd, const float* mean,
+                                                              const float* invstd, long nvox, long vb,
+                                                              float* __restrict__ partials) {
+  const int G = x.C / 8;
+  const int Gb = G < 256 ? G : 256;
+  const int R = 256 / Gb;
+  const int r = threadIdx.x / Gb;
+  const int g0 = threadIdx.x % Gb;
+  __shared__ float red[256 * 16];
+  const long v0 = (long)blockIdx.x * vb;
+  long v1 = v0 + vb; if (v1 > nvox) v1 = nvox;
+  for (int g = g0; g < G; g += Gb) {
+    float s[8], p[8], mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; p[e] = 0.f; mu[e] = 0.f; is[e] = 1.f; sc[e] = 1.f; sh[e] = 0.f; }
+    if (r < R) {
+      if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = mean[g * 8 + e]; is[e] = invstd[g * 8 + e]; }
+        if (fwd.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { sc[e] = fwd.scale ? fwd.scale[g * 8 + e] : 1.f; sh[e] = fwd.shift ? fwd.shift[g * 8 + e] : 0.f; }
+        }
+      }
+      constexpr int U = 4;
+      for (long vq = v0 + r; vq < v1; vq += (long)R * U) {
+        float xv[U][8], gv[U][8];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long v = vq + (long)u * R;
+          ok[u] = v < v1;
+          if (ok[u]) {
+            ld8<T>((const T*)x.p + vox_lin(x, v) + g * 8, xv[u]);
+            if (MODE == 1) ld8<T>((const T*)dz.p + vox_lin(dz, v) + g * 8, gv[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!ok[u]) continue;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (MODE == 0) {
+              s[e] += xv[u][e]; p[e] += xv[u][e] * xv[u][e];
+            } else {
+              float gg = gv[u][e];
+              if (fwd.relu && !(fmaf(xv[u][e], sc[e], sh[e]) > 0.f)) gg = 0.f;
+              s[e] += gg;
+              p[e] += gg * (xv[u][e] - mu[e]) * is[e];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (r < R) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = s[e]; red[threadIdx.x * 16 + 8 + e] = p[e]; }
+    }
+    __syncthreads();
+    if (r == 0) {
+      for (int rr = 1; rr < R; ++rr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += red[(rr * Gb + g0) * 16 + e]; p[e] += red[(rr * Gb + g0) * 16 + 8 + e]; }
+      float* o = partials + (long)blockIdx.x * 2 * x.C + g * 8;
+      *(float4*)o = make_float4(s[0], s[1], s[2], s[3]);
+      *(float4*)(o + 4) = make_float4(s[4], s[5], s[6], s[7]);
+      *(float4*)(o + x.C) = make_float4(p[0], p[1], p[2], p[3]);
+      *(float4*)(o + x.C + 4) = make_float4(p[4], p[5], p[6], p[7]);
+    }
+  }
+}
 static inline int stats_rows_for(long nvox) {
   long rows = (nvox + 63) / 64;
   if (rows > 1024) rows = 1024;
@@ -391,6 +485,11 @@ static int launch_channel_reduce(const VinetTensor* x, const VinetTensor* dz, in
   const int rows = stats_rows_for(nvox);
   const long vb = (nvox + rows - 1) / rows;
   const TView xv = make_view(*x), dv = dz ? make_view(*dz) : xv;
+  if (oct_ok(*x) && (!dz || oct_ok(*dz))) {
+    DISPATCH_T(dtype, T, hipLaunchKernelGGL((channel_reduce8_kernel<T, MODE>), dim3(rows), dim3(256), 0,
+                                            (hipStream_t)stream, xv, dv, make_affine(fwd), mean, invstd, nvox, vb, partials);)
+    return vn_launch_status("channel_reduce8");
+  }
   DISPATCH_T(dtype, T, hipLaunchKernelGGL((channel_reduce_kernel<T, MODE>), dim3(rows), dim3(256), 0,
                                           (hipStream_t)stream, xv, dv, make_affine(fwd), mean, invstd, nvox, vb, partials);)
   return vn_launch_status("channel_reduce");
@@ -470,12 +569,74 @@ __global__ void bn_bwd_apply_kernel(TView dz, TView x, Affine fwd, const float* 
   stq<T>((T*)dx.p + vox_lin(dx, vox) + q * 4, o);
 }
 
+// 8-channel, voxel-looping form: the six per-channel parameter vectors are folded into four
+// coefficients held in registers (dx = A*g + B*x + D with the ReLU gate from sc*x + sh), so a
+// lane issues two 16-byte loads and one 16-byte store per voxel and nothing else.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(TView dz, TView x, Affine fwd, const float* mean, const float* invstd,
+                                                            const float* c1, const float* c2, TView dx, long nvox, long vb) {
+  const int G = x.C / 8;
+  const int Gb = G < 256 ? G : 256;
+  const int R = 256 / Gb;
+  const int r = threadIdx.x / Gb;
+  const int g0 = threadIdx.x % Gb;
+  if (r >= R) return;
+  const long v0 = (long)blockIdx.x * vb;
+  long v1 = v0 + vb; if (v1 > nvox) v1 = nvox;
+  for (int g = g0; g < G; g += Gb) {
+    float A[8], Bc[8], D[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = g * 8 + e;
+      const float sc = fwd.scale[c], k = sc * invstd[c] * c2[c];
+      A[e] = sc; Bc[e] = -k; D[e] = fmaf(k, mean[c], -sc * c1[c]);
+      sh[e] = fwd.shift[c];
+    }
+    constexpr int U = 4;
+    for (long vq = v0 + r; vq < v1; vq += (long)R * U) {
+      float xv[U][8], gv[U][8];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long v = vq + (long)u * R;
+        ok[u] = v < v1;
+        if (ok[u]) {
+          ld8<T>((const T*)x.p + vox_lin(x, v) + g * 8, xv[u]);
+          ld8<T>((const T*)dz.p + vox_lin(dz, v) + g * 8, gv[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float gg = gv[u][e];
+          if (fwd.relu && !(fmaf(xv[u][e], A[e], sh[e]) > 0.f)) gg = 0.f;
+          o[e] = fmaf(A[e], gg, fmaf(Bc[e], xv[u][e], D[e]));
+        }
+        st8<T>((T*)dx.p + vox_lin(dx, vq + (long)u * R) + g * 8, o);
+      }
+    }
+  }
+}
+
 extern "C" int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,
                                   const float* mean, const float* invstd, const float* c1, const float* c2,
                                   const VinetTensor* dx, void* stream) {
   VN_CHECK_ARG(dz && x_raw && dx && fwd.scale && fwd.shift && mean && invstd && c1 && c2, "bn_bwd_apply: null argument");
   VN_CHECK_ARG(quad_ok(*dz, esize(dtype)) && quad_ok(*x_raw, esize(dtype)) && quad_ok(*dx, esize(dtype)) &&
                    same_dims(*dz, *x_raw) && same_dims(*dz, *dx), "bn_bwd_apply: bad views");
+  if (oct_ok(*dz) && oct_ok(*x_raw) && oct_ok(*dx)) {
+    const long nvox = view_voxels(*dz);
+    const int G = dz->C / 8, R = 256 / (G < 256 ? G : 256);
+    long vb = R * 16;                                  // 4 rounds of 4 voxels per lane
+    while ((nvox + vb - 1) / vb > 16384) vb *= 2;
+    DISPATCH_T(dtype, T, hipLaunchKernelGGL(bn_bwd_apply8_kernel<T>, dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0,
+                                            (hipStream_t)stream, make_view(*dz), make_view(*x_raw), make_affine(fwd), mean,
+                                            invstd, c1, c2, make_view(*dx), nvox, vb);)
+    return vn_launch_status("bn_bwd_apply8");
+  }
   const long total = view_voxels(*dz) * (dz->C / 4);
   DISPATCH_T(dtype, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
                                           (hipStream_t)stream, make_view(*dz), make_view(*x_raw), make_affine(fwd), mean,
@@ -660,6 +821,59 @@ __global__ void maxpool_tslide_kernel(PoolP p, TView x, Affine pre, TView y, uin
   }
 }
 
+// 8 channels per lane forms of the two forward kernels above (same scan order and tie rule)
+VN_DEV void affine8(float* v, const Affine& a, int c) {
+  if (a.scale) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], a.scale[c + e], a.shift[c + e]);
+  }
+  if (a.relu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd8_kernel(PoolP p, TView x, Affine pre, TView y, uint8_t* __restrict__ argmax, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = y.C >> 3;
+  const uint32_t vox_u = (uint32_t)(i / G);
+  const int g = (int)(i - (long)vox_u * G);
+  int b, to, ho, wo;
+  decode_vox(y, (long)vox_u, b, to, ho, wo);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = pre.scale ? pre.scale[g * 8 + e] : 1.f; sh[e] = pre.scale ? pre.shift[g * 8 + e] : 0.f; }
+  float best[8];
+  unsigned long long bi = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+  for (int kt = 0; kt < p.kT; ++kt) {
+    const int t = to * p.sT - p.pT + kt;
+    if ((unsigned)t >= (unsigned)x.T) continue;
+    for (int kh = 0; kh < p.kH; ++kh) {
+      const int h = ho * p.sH - p.pH + kh;
+      if ((unsigned)h >= (unsigned)x.H) continue;
+      for (int kw = 0; kw < p.kW; ++kw) {
+        const int w = wo * p.sW - p.pW + kw;
+        if ((unsigned)w >= (unsigned)x.W) continue;
+        float f[8];
+        ld8<T>((const T*)x.p + vox_off(x, b, t, h, w) + g * 8, f);
+        const unsigned long long tap = (unsigned long long)((kt * p.kH + kh) * p.kW + kw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = fmaf(f[e], sc[e], sh[e]);
+          if (pre.relu) v = fmaxf(v, 0.f);
+          if (v > best[e] || (v != v && best[e] == best[e])) { best[e] = v; bi = (bi & ~(0xffull << (8 * e))) | (tap << (8 * e)); }
+        }
+      }
+    }
+  }
+  st8<T>((T*)y.p + vox_off(y, b, to, ho, wo) + g * 8, best);
+  if (argmax) *(unsigned long long*)(argmax + (long)vox_u * y.C + g * 8) = bi;
+}
+
 extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, VinetAffine pre, const VinetTensor* y,
                                uint8_t* argmax, void* stream) {
   VN_CHECK_ARG(d && x && y && quad_ok(*x, esize(d->dtype)) && quad_ok(*y, esize(d->dtype)) && x->C == y->C && x->B == y->B,
@@ -671,6 +885,12 @@ extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, Vin
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_tslide_kernel<T>, dim3(ew_grid(cols)), dim3(256), 0,
                                                (hipStream_t)stream, p, make_view(*x), make_affine(pre), make_view(*y), argmax, cols);)
     return vn_launch_status("maxpool3d(tslide)");
+  }
+  if (oct_ok(*x) && oct_ok(*y) && (!argmax || ((uintptr_t)argmax % 8) == 0)) {
+    const long total8 = view_voxels(*y) * (y->C / 8);
+    DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_fwd8_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0,
+                                               (hipStream_t)stream, p, make_view(*x), make_affine(pre), make_view(*y), argmax, total8);)
+    return vn_launch_status("maxpool3d(8)");
   }
   const long total = view_voxels(*y) * (y->C / 4);
   DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
@@ -783,6 +1003,54 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s1_kernel(TView dy, const u
   stq<T>(dst + 4, make_float4(gr[4], gr[5], gr[6], gr[7]));
 }
 
+// generic backward, 8 channels per lane (same gather as maxpool_bwd_kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd8_kernel(PoolP p, TView dy, const uint8_t* __restrict__ argmax, TView dx, int accumulate,
+                                                           long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = dx.C >> 3;
+  const uint32_t vox_u = (uint32_t)(i / G);
+  const int g = (int)(i - (long)vox_u * G);
+  int b, t, h, w;
+  decode_vox(dx, (long)vox_u, b, t, h, w);
+  float gr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int to1 = min((int)fdiv((uint32_t)(t + p.pT), p.dsT), dy.T - 1), ho1 = min((int)fdiv((uint32_t)(h + p.pH), p.dsH), dy.H - 1),
+            wo1 = min((int)fdiv((uint32_t)(w + p.pW), p.dsW), dy.W - 1);
+  const int to0 = (int)fdiv((uint32_t)max(0, t + p.pT - p.kT + p.sT), p.dsT), ho0 = (int)fdiv((uint32_t)max(0, h + p.pH - p.kH + p.sH), p.dsH),
+            wo0 = (int)fdiv((uint32_t)max(0, w + p.pW - p.kW + p.sW), p.dsW);
+  for (int to = to0; to <= to1; ++to) {
+    const int kt = t + p.pT - to * p.sT;
+    if (kt < 0 || kt >= p.kT) continue;
+    for (int ho = ho0; ho <= ho1; ++ho) {
+      const int kh = h + p.pH - ho * p.sH;
+      if (kh < 0 || kh >= p.kH) continue;
+      for (int wo = wo0; wo <= wo1; ++wo) {
+        const int kw = w + p.pW - wo * p.sW;
+        if (kw < 0 || kw >= p.kW) continue;
+        const unsigned long long tap = (unsigned long long)((kt * p.kH + kh) * p.kW + kw);
+        const long ovox = (((long)b * dy.T + to) * dy.H + ho) * dy.W + wo;
+        const unsigned long long am = *(const unsigned long long*)(argmax + ovox * dy.C + g * 8);
+        const unsigned long long xr = am ^ (tap * 0x0101010101010101ull);
+        if (!((xr - 0x0101010101010101ull) & ~xr & 0x8080808080808080ull)) continue;
+        float dv[8];
+        ld8<T>((const T*)dy.p + vox_off(dy, b, to, ho, wo) + g * 8, dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (((xr >> (8 * e)) & 0xffull) == 0) gr[e] += dv[e];
+      }
+    }
+  }
+  T* dst = (T*)dx.p + vox_off(dx, b, t, h, w) + g * 8;
+  if (accumulate) {
+    float o[8];
+    ld8<T>(dst, o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gr[e] += o[e];
+  }
+  st8<T>(dst, gr);
+}
+
 extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy, const uint8_t* argmax,
                                    const VinetTensor* dx, int32_t accumulate, void* stream) {
   VN_CHECK_ARG(d && dy && dx && argmax && quad_ok(*dy, esize(d->dtype)) && quad_ok(*dx, esize(d->dtype)) &&
@@ -796,6 +1064,12 @@ extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_k3s1_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
                                                make_view(*dy), argmax, make_view(*dx), accumulate, total8);)
     return vn_launch_status("maxpool3d_bwd(k3s1)");
+  }
+  if (oct_ok(*dx) && oct_ok(*dy) && ((uintptr_t)argmax % 8) == 0) {
+    const long total8 = view_voxels(*dx) * (dx->C / 8);
+    DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd8_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
+                                               p, make_view(*dy), argmax, make_view(*dx), accumulate, total8);)
+    return vn_launch_status("maxpool3d_bwd8");
   }
   const long total = view_voxels(*dx) * (dx->C / 4);
   DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,

@@ -399,7 +399,8 @@ bool vinet_wgrad_use_pp(const VinetWgradDesc* d) {
   const int tn = wpp_tn(N);
   const int npad = (N + tn - 1) / tn * tn, spad = (nseg + 3) / 4 * 4;
   const long max_blocks = (long)(npad / tn) * (spad / 4) * (M / 64 / 32);
-  return dy_linear && M >= 32768 && max_blocks >= 256 && (double)N * nseg >= 0.6 * (double)npad * spad;
+  const double need = d->pre.scale ? 0.7 : 0.6;   // the fragment-time affine costs the kernel ~25%
+  return dy_linear && M >= 32768 && max_blocks >= 256 && (double)N * nseg >= need * (double)npad * spad;
 }
 
 int vinet_launch_wgrad_pp(const VinetWgradDesc* d, hipStream_t s) {
@@ -430,7 +431,7 @@ int vinet_launch_wgrad_pp(const VinetWgradDesc* d, hipStream_t s) {
   {
     long max_sk = a.nkt / 32;
     if (max_sk < 1) max_sk = 1;
-    if (max_sk > 64) max_sk = 64;
+    if (max_sk > 1024) max_sk = 1024;
     double best = -1.0;
     for (long k = 1; k <= max_sk; ++k) {
       const long blocks = base_blocks * k;
