@@ -241,9 +241,23 @@ def main():
         else:
             roof = dict(bound="hbm", achieved=byts / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof.update(traffic=None, kernel=dom, launches=domstat["count"], avg_us=avg_s * 1e6,
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (profiles/pmc_traffic.json; separate --pmc runs, gfx950 FETCH_SIZE correction applied); None if the
+        # dominant kernel was not in that profile
+        traffic, pmc = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)["kernels"].get(dom.replace(" ", ""))
+            if pmc is not None and B == 32 and args.mode == "train":
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
+        roof.update(traffic=traffic, kernel=dom, launches=domstat["count"], avg_us=avg_s * 1e6,
                     algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=byts,
                     also={"TFLOP/s": flops / avg_s / 1e12, "GB/s": byts / avg_s / 1e9})
+        if traffic is not None:
+            roof["traffic_source"] = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes); (2*FETCH+WRITE)*1024 B, L2-miss traffic incl. Infinity-Cache hits"
+            roof["mfma_busy_frac_pmc"] = pmc.get("mfma_busy_frac")
         per_gpu = value / world
         out = {
             "metric": "clips/sec training (32x224x384 bf16)" if args.mode == "train" else "inference clips/sec (one output frame per clip)",

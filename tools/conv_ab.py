@@ -65,17 +65,19 @@ def main():
     variants = []
     if args.wgrad:
         for ln, lib in libs:
-            variants.append((ln + ":wpp256", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=3), False))
-            variants.append((ln + ":wpp192", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=4), False))
-            variants.append((ln + ":wpp192+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=4), True))
-            variants.append((ln + ":wdma", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0), False))
-            variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0), True))
+            variants.append((ln + ":wpp256", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=3, tperm=1), False))
+            variants.append((ln + ":wpp192", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=4, tperm=1), False))
+            variants.append((ln + ":wpp192+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=4, tperm=1), True))
+            variants.append((ln + ":wdma", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), False))
+            variants.append((ln + ":wdma-noperm", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=0), False))
+            variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), True))
         libs = []
     for ln, lib in libs:
-        variants.append((ln + ":pp256", lib, dict(dma=1, pp=3), False))
-        variants.append((ln + ":pp192", lib, dict(dma=1, pp=4), False))
-        variants.append((ln + ":dma", lib, dict(dma=1, pp=0), False))
-        variants.append((ln + ":dma+pre", lib, dict(dma=1, pp=0), True))
+        variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=1), False))
+        variants.append((ln + ":pp192", lib, dict(dma=1, pp=4, tperm=1), False))
+        variants.append((ln + ":dma", lib, dict(dma=1, pp=0, tperm=1), False))
+        variants.append((ln + ":dma-noperm", lib, dict(dma=1, pp=0, tperm=0), False))
+        variants.append((ln + ":dma+pre", lib, dict(dma=1, pp=0, tperm=1), True))
 
     print("%-26s" % "site" + "".join("%22s" % (v[0][-21:].replace("libvinet_hip", "")) for v in variants) + "   (ms | TF/s)")
     for (name, B, T, H, W, Cin, N, k, s, p) in SITES:

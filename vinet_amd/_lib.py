@@ -115,6 +115,11 @@ def load(path=LIB_PATH):
         fn.restype = _RESTYPE.get(name, C.c_int)
     if lib.vinet_abi_version() != ABI_VERSION:
         raise VinetLibraryError("libvinet_hip.so ABI %d != expected %d" % (lib.vinet_abi_version(), ABI_VERSION))
+    # tuning switches, e.g. VINET_OPT="tperm=0,pp=0" (names: vinet_set_option in include/vinet_hip.h)
+    for item in filter(None, os.environ.get("VINET_OPT", "").split(",")):
+        k, _, v = item.partition("=")
+        if lib.vinet_set_option(k.strip().encode(), int(v)) != 0:
+            raise VinetLibraryError("VINET_OPT: " + lib.vinet_last_error().decode())
     _LIB = lib
     return lib
 

@@ -5,6 +5,7 @@
 #include "conv_igemm.h"
 
 static thread_local char g_err[512] = "";
+extern int g_vinet_opt_tperm;
 
 void vinet_set_error(const char* fmt, ...) {
   va_list ap;
@@ -89,6 +90,15 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   const int oeb = a.out_f32 ? 4 : 2;
   a.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && (a.sBy % 4 == 0) && ((((uintptr_t)d->y.ptr) % (4 * oeb)) == 0);
   t = vinet_pick_conv_tile(d->dtype, d->mode, M, a.N);
+  a.perm_P = a.perm_T = 0;
+  a.dPT = a.dPermT = make_fastdiv(1);
+  if (g_vinet_opt_tperm && d->dtype == VINET_BF16 && d->mode == VINET_CONV_GENERIC && t.BM() == 256 && d->oT > 1 &&
+      ((long)d->oH * d->oW) % 256 == 0) {
+    a.perm_P = (int)(((long)d->oH * d->oW) / 256);
+    a.perm_T = d->oT;
+    a.dPT = make_fastdiv((uint32_t)(a.perm_P * a.perm_T));
+    a.dPermT = make_fastdiv((uint32_t)a.perm_T);
+  }
   a.tilesM = vn_div_up(M, t.BM());
   a.tilesN = vn_div_up(a.N, t.BN());
   return 0;
@@ -104,6 +114,7 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
 }
 
 int g_vinet_opt_dma = 1;
+int g_vinet_opt_tperm = 0;      // t-fastest M-tile order (L2 reuse across temporal taps): measured neutral on the whole step, off
 int g_vinet_opt_wgrad_tr = 1;
 int g_vinet_opt_wgrad_dma = 1;
 int g_vinet_opt_pp = 1;         // 256x256x64 ping-pong kernel for large plain convs
@@ -112,6 +123,7 @@ int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad
 
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
+  if (name && !strcmp(name, "tperm")) { g_vinet_opt_tperm = value; return 0; }
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }

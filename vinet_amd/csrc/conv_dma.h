@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = wg % a.tilesN, tile_m = wg / a.tilesN;
+  const int tile_n = wg % a.tilesN, tile_m = conv_tile_perm(a, wg / a.tilesN);
   const char* zero = (const char*)g_vinet_zero_page;
   const char* apad = PRE ? (const char*)g_vinet_nan_page : zero;   // what out-of-range ACTIVATIONS read
   float* aff = (float*)(smem + STAGES * Cfg::STAGE_BYTES);         // PRE: scale[0..Kp), shift[0..Kp)

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
   const int wr = wave / WN, wc = wave % WN;
   const int grp = wave >> 2;                       // 0: upper rows, 1: lower rows (runs one barrier behind)
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = wg % a.tilesN, tile_m = wg / a.tilesN;
+  const int tile_n = wg % a.tilesN, tile_m = conv_tile_perm(a, wg / a.tilesN);
   const char* zero = (const char*)g_vinet_zero_page;
 
   const int cpt = (a.Kp + 63) >> 6;            // K tiles per tap

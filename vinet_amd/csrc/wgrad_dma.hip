@@ -23,6 +23,7 @@
 #include "common.h"
 
 extern int g_vinet_opt_wgrad_tg;
+extern int g_vinet_opt_tperm;
 
 // (device globals are per translation unit without -fgpu-rdc: own copies of the pad pages)
 __device__ __attribute__((aligned(64))) uint4 g_wg_zero_page[4];
@@ -45,7 +46,20 @@ struct WgradDmaArgs {
   int ntaps, Kp, M;
   int tilesN, tilesC, splitK, chunks_per_split, nchunks;
   FastDiv dW, dH, dT;
+  int perm_P, perm_T;        // voxel-chunk order with t fastest (see ConvArgs::perm_P); 0 = identity
+  FastDiv dPT, dPermT;
 };
+
+// logical chunk index -> chunk position in memory order: (b, spatial chunk c, t) with t fastest, so the
+// temporal taps of consecutive K steps re-read the same (h,w) rows of neighbouring frames from L1/L2
+VN_DEV int wg_chunk_perm(const WgradDmaArgs& a, int i) {
+  if (a.perm_P == 0) return i;
+  const uint32_t b = fdiv((uint32_t)i, a.dPT);
+  const uint32_t rem = (uint32_t)i - b * (uint32_t)(a.perm_P * a.perm_T);
+  const uint32_t c = fdiv(rem, a.dPermT);
+  const uint32_t t = rem - c * (uint32_t)a.perm_T;
+  return (int)((b * (uint32_t)a.perm_T + t) * (uint32_t)a.perm_P + c);
+}
 
 template <int N_> VN_DEV void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 VN_DEV uint32_t wg_cvt_pk_bf16(float lo, float hi) {
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
   auto issue = [&](int slot) {
     char* stage = smem + slot * Cfg::STAGE_BYTES;
     const bool live = isu < nloc;
-    const int mbase = (chunk0 + isu) * KV;
+    const int mbase = wg_chunk_perm(a, live ? chunk0 + isu : 0) * KV;
     // ---- dY tile ----
 #pragma unroll
     for (int j = 0; j < Cfg::D_IPW; ++j) {
@@ -324,6 +338,14 @@ int vinet_launch_wgrad_dma(const VinetWgradDesc* d, hipStream_t s) {
   a.ntaps = d->ntaps; a.Kp = d->Kp;
   a.M = (int)((long)d->dy.B * d->dy.T * d->dy.H * d->dy.W);
   a.dW = make_fastdiv(a.Wo); a.dH = make_fastdiv(a.Ho); a.dT = make_fastdiv(a.To);
+  a.perm_P = a.perm_T = 0;
+  a.dPT = a.dPermT = make_fastdiv(1);
+  if (g_vinet_opt_tperm && a.To > 1 && ((long)a.Ho * a.Wo) % 32 == 0) {
+    a.perm_P = (int)(((long)a.Ho * a.Wo) / 32);
+    a.perm_T = a.To;
+    a.dPT = make_fastdiv((uint32_t)(a.perm_P * a.perm_T));
+    a.dPermT = make_fastdiv((uint32_t)a.perm_T);
+  }
   int tn, tg;
   wg_pick(a.N, a.Cin, a.ntaps, a.M, &tn, &tg);
   const bool pre = d->pre.scale != nullptr;

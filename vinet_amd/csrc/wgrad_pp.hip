@@ -44,6 +44,8 @@ struct WgradPPArgs {
   int tilesN, tilesS, nseg, cpt;     // column tiles of 4 segments; segments = ntaps * cpt, cpt = ceil(Cin/64)
   int nkt, kt_per_split, splitK;
   FastDiv dW, dH, dT, dCpt;
+  int perm_P, perm_T;        // K-tile order with t fastest (see ConvArgs::perm_P); 0 = identity
+  FastDiv dPT, dPermT;
 #ifdef VINET_CONV_TIMING
   float* dbg;   // tuning build: [grid][2 groups][4] mean cycles per phase part
 #endif
@@ -71,7 +73,7 @@ VN_DEV uint32_t wpp_cvt_pk_bf16(float lo, float hi) {
 // (bit q*2+j: x row q is in range for the tap of half j; bit 4+q: the row exists).  dy is addressed as
 // m * ldy (linear views only), so it needs no per-row state.
 struct WppCursor {
-  int kt;
+  int kt, mb;                // logical K tile, first voxel of the tile in memory order
   long xo[2];
   unsigned bits;
 };
@@ -147,10 +149,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(const WgradPPArgs
 
   auto set_cursor = [&](WppCursor& c, int kt) {
     c.kt = kt;
+    {
+      int pk = kt < kt1 ? kt : 0;
+      if (a.perm_P != 0) {
+        const uint32_t b = fdiv((uint32_t)pk, a.dPT);
+        const uint32_t rem = (uint32_t)pk - b * (uint32_t)(a.perm_P * a.perm_T);
+        const uint32_t cc = fdiv(rem, a.dPermT);
+        pk = (int)((b * (uint32_t)a.perm_T + (rem - cc * (uint32_t)a.perm_T)) * (uint32_t)a.perm_P + cc);
+      }
+      c.mb = pk * 64;
+    }
     c.bits = 0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int m = kt * 64 + q * 32 + prow;
+      const int m = c.mb + q * 32 + prow;
       const bool live = (kt < kt1) & (m < a.M);
       int b, to, ho, wo;
       decode_m(live ? m : 0, a.dW, a.dH, a.dT, b, to, ho, wo);
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(const WgradPPArgs
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const unsigned ok = ((c.bits >> (4 + q)) & 1u) & a_nok[h];
-      const char* p = a.dy + (long)(c.kt * 64 + q * 32 + prow) * ldy2 + a_noff[h];
+      const char* p = a.dy + (long)(c.mb + q * 32 + prow) * ldy2 + a_noff[h];
       dma(zero + ((p - zero) & -(long)ok), dst + q * 8192);
     }
   };
@@ -375,6 +387,7 @@ static int launch_wpp(const WgradPPArgs& a, hipStream_t s) {
 }
 
 extern int g_vinet_opt_wgrad_pp;
+extern int g_vinet_opt_tperm;
 #ifdef VINET_CONV_TIMING
 static float* g_wpp_dbg = nullptr;
 extern "C" void vinet_debug_wgrad_ptr(float* p) { g_wpp_dbg = p; }
@@ -416,6 +429,14 @@ int vinet_launch_wgrad_pp(const VinetWgradDesc* d, hipStream_t s) {
 #ifdef VINET_CONV_TIMING
   a.dbg = g_wpp_dbg;
 #endif
+  a.perm_P = a.perm_T = 0;
+  a.dPT = a.dPermT = make_fastdiv(1);
+  if (g_vinet_opt_tperm && a.To > 1 && ((long)a.Ho * a.Wo) % 64 == 0) {
+    a.perm_P = (int)(((long)a.Ho * a.Wo) / 64);
+    a.perm_T = a.To;
+    a.dPT = make_fastdiv((uint32_t)(a.perm_P * a.perm_T));
+    a.dPermT = make_fastdiv((uint32_t)a.perm_T);
+  }
   a.cpt = (a.Cin + 63) / 64;
   a.dCpt = make_fastdiv(a.cpt);
   a.nseg = a.ntaps * a.cpt;
