@@ -562,6 +562,17 @@ POOLS = [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), (
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_maxpool_k3s1_twalk_backward(dt):
+    """the T-walking 3x3x3/s1 backward (chosen for large tensors only) forced on the small test shape"""
+    lib = _lib()
+    assert lib.vinet_set_option(b"pool_twalk", 2) == 0
+    try:
+        test_maxpool(dt, ((3, 3, 3), (1, 1, 1), (1, 1, 1)))
+    finally:
+        lib.vinet_set_option(b"pool_twalk", 1)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("ksp", POOLS, ids=[str(p[0]) + str(p[1]) for p in POOLS])
 def test_maxpool(dt, ksp):
     k, s, p = ksp

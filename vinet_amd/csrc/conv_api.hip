@@ -114,6 +114,7 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
 }
 
 int g_vinet_opt_dma = 1;
+int g_vinet_opt_pool_twalk = 1; // T-walking 3x3x3/s1 max-pool backward
 int g_vinet_opt_tperm = 0;      // t-fastest M-tile order (L2 reuse across temporal taps): measured neutral on the whole step, off
 int g_vinet_opt_wgrad_tr = 1;
 int g_vinet_opt_wgrad_dma = 1;
@@ -123,6 +124,7 @@ int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad
 
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
+  if (name && !strcmp(name, "pool_twalk")) { g_vinet_opt_pool_twalk = value; return 0; }
   if (name && !strcmp(name, "tperm")) { g_vinet_opt_tperm = value; return 0; }
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }

@@ -5,6 +5,8 @@
 // so every wave touches whole contiguous rows.
 #include "common.h"
 
+extern int g_vinet_opt_pool_twalk;
+
 // ---- 4-channel ("quad") typed access -----------------------------------------
 template <typename T> VN_DEV float4 ldq(const T* p);
 template <> VN_DEV float4 ldq<float>(const float* p) { return *(const float4*)p; }
@@ -874,12 +876,90 @@ __global__ __launch_bounds__(256) void maxpool_fwd8_kernel(PoolP p, TView x, Aff
   if (argmax) *(unsigned long long*)(argmax + (long)vox_u * y.C + g * 8) = bi;
 }
 
+// 8-channel T-walking forward for kT == 3, sT == 1, pT == 1 (any in-plane window): one lane owns an output
+// column (b, ho, wo, 8 channels), computes each input plane's (kH x kW) window maximum ONCE and keeps the
+// last three in named registers (explicit rotation: a runtime-indexed ring would live in scratch).  Tie rule
+// as everywhere: planes in t order, (h, w) scan order inside a plane, strict comparisons.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_tslide8_kernel(PoolP p, TView x, Affine pre, TView y, uint8_t* __restrict__ argmax, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = y.C >> 3;
+  const uint32_t col = (uint32_t)(i / G);
+  const int g = (int)(i - (long)col * G);
+  const uint32_t r1 = fdiv(col, y.dW);
+  const int wo = (int)(col - r1 * (uint32_t)y.W);
+  const uint32_t r2 = fdiv(r1, y.dH);
+  const int ho = (int)(r1 - r2 * (uint32_t)y.H);
+  const int b = (int)r2;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = pre.scale ? pre.scale[g * 8 + e] : 1.f; sh[e] = pre.scale ? pre.shift[g * 8 + e] : 0.f; }
+  const int khw = p.kH * p.kW;
+  float m_a[8], m_b[8], m_c[8];                 // plane maxima of planes tp-2, tp-1, tp
+  unsigned long long i_a = 0, i_b = 0, i_c = 0;   // ... and their in-plane argmax codes (8 x 8 bit)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { m_a[e] = -INFINITY; m_b[e] = -INFINITY; m_c[e] = -INFINITY; }
+  for (int tp = 0; tp <= x.T; ++tp) {
+    // rotate: (a, b, c) <- (b, c, new plane tp)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m_a[e] = m_b[e]; m_b[e] = m_c[e]; m_c[e] = -INFINITY; }
+    i_a = i_b; i_b = i_c; i_c = 0;
+    if (tp < x.T) {
+      for (int kh = 0; kh < p.kH; ++kh) {
+        const int h = ho * p.sH - p.pH + kh;
+        if ((unsigned)h >= (unsigned)x.H) continue;
+        for (int kw = 0; kw < p.kW; ++kw) {
+          const int w = wo * p.sW - p.pW + kw;
+          if ((unsigned)w >= (unsigned)x.W) continue;
+          float f[8];
+          ld8<T>((const T*)x.p + vox_off(x, b, tp, h, w) + g * 8, f);
+          const unsigned long long code = (unsigned long long)(kh * p.kW + kw);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = fmaf(f[e], sc[e], sh[e]);
+            if (pre.relu) v = fmaxf(v, 0.f);
+            if (v > m_c[e] || (v != v && m_c[e] == m_c[e])) { m_c[e] = v; i_c = (i_c & ~(0xffull << (8 * e))) | (code << (8 * e)); }
+          }
+        }
+      }
+    }
+    const int to = tp - 1;       // complete once plane tp = to + 1 is in: window planes (a, b, c) = (to-1, to, to+1)
+    if (to < 0) continue;
+    float o[8];
+    unsigned long long oi = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float best = -INFINITY;
+      unsigned long long bi = 0;
+      // kt = 0: plane to-1 (exists iff to >= 1; otherwise m_a is -inf and never wins against a real plane)
+      if (to >= 1 && (m_a[e] > best || (m_a[e] != m_a[e] && best == best))) { best = m_a[e]; bi = (i_a >> (8 * e)) & 0xffull; }
+      if (m_b[e] > best || (m_b[e] != m_b[e] && best == best)) { best = m_b[e]; bi = (unsigned long long)khw + ((i_b >> (8 * e)) & 0xffull); }
+      if (to + 1 < x.T && (m_c[e] > best || (m_c[e] != m_c[e] && best == best))) { best = m_c[e]; bi = 2ull * khw + ((i_c >> (8 * e)) & 0xffull); }
+      o[e] = best;
+      oi |= bi << (8 * e);
+    }
+    st8<T>((T*)y.p + vox_off(y, b, to, ho, wo) + g * 8, o);
+    if (argmax) {
+      const long ovox = (((long)b * y.T + to) * y.H + ho) * y.W + wo;
+      *(unsigned long long*)(argmax + ovox * y.C + g * 8) = oi;
+    }
+  }
+}
+
 extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, VinetAffine pre, const VinetTensor* y,
                                uint8_t* argmax, void* stream) {
   VN_CHECK_ARG(d && x && y && quad_ok(*x, esize(d->dtype)) && quad_ok(*y, esize(d->dtype)) && x->C == y->C && x->B == y->B,
                "maxpool3d: bad views");
   VN_CHECK_ARG(d->kT * d->kH * d->kW <= 255 && d->kT > 0 && d->kH > 0 && d->kW > 0, "maxpool3d: window too large");
   const PoolP p = make_poolp(d);
+  if (d->kT == 3 && d->sT == 1 && d->pT == 1 && y->T == x->T && x->T >= 2 && oct_ok(*x) && oct_ok(*y) &&
+      (!argmax || ((uintptr_t)argmax % 8) == 0)) {
+    const long cols8 = (long)y->B * y->H * y->W * (y->C / 8);
+    DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_tslide8_kernel<T>, dim3(ew_grid(cols8)), dim3(256), 0,
+                                               (hipStream_t)stream, p, make_view(*x), make_affine(pre), make_view(*y), argmax, cols8);)
+    return vn_launch_status("maxpool3d(tslide8)");
+  }
   if (d->kT == 3 && d->sT == 1 && d->pT == 1 && y->T == x->T && x->T >= 2) {
     const long cols = (long)y->B * y->H * y->W * (y->C / 4);
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_tslide_kernel<T>, dim3(ew_grid(cols)), dim3(256), 0,
@@ -1051,6 +1131,76 @@ __global__ __launch_bounds__(256) void maxpool_bwd8_kernel(PoolP p, TView dy, co
   st8<T>(dst, gr);
 }
 
+// 3x3x3 / s1 / p1 backward, T-walking form: one lane owns an input column (b, h, w, 8 channels) and walks the
+// output planes; the argmax word of each of the 9 in-plane neighbour windows is read ONCE per plane and tested
+// against the three temporal taps it could route to, accumulating into three named accumulators (inputs
+// to-1, to, to+1).  9 argmax reads per voxel instead of 27.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s1_twalk_kernel(TView dy, const uint8_t* __restrict__ argmax, TView dx,
+                                                                     int accumulate, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = dx.C >> 3;
+  const uint32_t col = (uint32_t)(i / G);
+  const int g = (int)(i - (long)col * G);
+  const uint32_t r1 = fdiv(col, dx.dW);
+  const int w = (int)(col - r1 * (uint32_t)dx.W);
+  const uint32_t r2 = fdiv(r1, dx.dH);
+  const int h = (int)(r1 - r2 * (uint32_t)dx.H);
+  const int b = (int)r2;
+  const int T_ = dx.T, H = dx.H, W = dx.W;
+  float g_m[8], g_0[8], g_p[8];      // gradients of inputs to-1, to, to+1 while output plane `to` is processed
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { g_m[e] = 0.f; g_0[e] = 0.f; g_p[e] = 0.f; }
+  for (int to = 0; to <= T_; ++to) {
+    if (to < T_) {
+      unsigned long long am[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ho = h + 1 - kh, wo = w + 1 - kw;     // the window that holds (h, w) as its in-plane tap (kh, kw)
+          const bool ok = (unsigned)ho < (unsigned)H && (unsigned)wo < (unsigned)W;
+          const long ovox = (((long)b * T_ + to) * H + (ok ? ho : 0)) * W + (ok ? wo : 0);
+          am[kh * 3 + kw] = ok ? *(const unsigned long long*)(argmax + ovox * dx.C + g * 8) : ~0ull;
+        }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const unsigned long long s = (unsigned long long)(kh * 3 + kw) * 0x0101010101010101ull;
+          // codes kt*9 + s for kt = 0 (input to-1), 1 (input to), 2 (input to+1)
+          const unsigned long long x0 = am[kh * 3 + kw] ^ s, x1 = am[kh * 3 + kw] ^ (s + 9ull * 0x0101010101010101ull),
+                                   x2 = am[kh * 3 + kw] ^ (s + 18ull * 0x0101010101010101ull);
+          const unsigned long long z0 = (x0 - 0x0101010101010101ull) & ~x0, z1 = (x1 - 0x0101010101010101ull) & ~x1,
+                                   z2 = (x2 - 0x0101010101010101ull) & ~x2;
+          if (!((z0 | z1 | z2) & 0x8080808080808080ull)) continue;
+          float dv[8];
+          ld8<T>((const T*)dy.p + vox_off(dy, b, to, h + 1 - kh, w + 1 - kw) + g * 8, dv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (((x0 >> (8 * e)) & 0xffull) == 0) g_m[e] += dv[e];
+            if (((x1 >> (8 * e)) & 0xffull) == 0) g_0[e] += dv[e];
+            if (((x2 >> (8 * e)) & 0xffull) == 0) g_p[e] += dv[e];
+          }
+        }
+    }
+    const int t = to - 1;          // input plane to-1 has now seen all of its windows (planes to-2, to-1, to)
+    if (t >= 0) {
+      T* dst = (T*)dx.p + vox_off(dx, b, t, h, w) + g * 8;
+      if (accumulate) {
+        float o[8];
+        ld8<T>(dst, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g_m[e] += o[e];
+      }
+      st8<T>(dst, g_m);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { g_m[e] = g_0[e]; g_0[e] = g_p[e]; g_p[e] = 0.f; }
+  }
+}
+
 extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy, const uint8_t* argmax,
                                    const VinetTensor* dx, int32_t accumulate, void* stream) {
   VN_CHECK_ARG(d && dy && dx && argmax && quad_ok(*dy, esize(d->dtype)) && quad_ok(*dx, esize(d->dtype)) &&
@@ -1060,6 +1210,12 @@ extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy
                     d->pW == 1 && dy->T == dx->T && dy->H == dx->H && dy->W == dx->W;
   if (k3s1 && dx->C % 8 == 0 && dx->ld % 8 == 0 && dy->ld % 8 == 0 && dx->sB % 8 == 0 && dy->sB % 8 == 0 &&
       ((uintptr_t)dx->ptr % 16) == 0 && ((uintptr_t)dy->ptr % 16) == 0 && ((uintptr_t)argmax % 8) == 0) {
+    const long cols8 = (long)dx->B * dx->H * dx->W * (dx->C / 8);
+    if (g_vinet_opt_pool_twalk >= 2 || (g_vinet_opt_pool_twalk && cols8 >= 65536)) {   // 2: force (tests)   // enough columns to fill the chip
+      DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_k3s1_twalk_kernel<T>, dim3(ew_grid(cols8)), dim3(256), 0,
+                                                 (hipStream_t)stream, make_view(*dy), argmax, make_view(*dx), accumulate, cols8);)
+      return vn_launch_status("maxpool3d_bwd(k3s1 twalk)");
+    }
     const long total8 = view_voxels(*dx) * (dx->C / 8);
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_k3s1_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
                                                make_view(*dy), argmax, make_view(*dx), accumulate, total8);)
