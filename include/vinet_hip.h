@@ -145,6 +145,13 @@ int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* desc, char* buf, int32_
  * Replaces the implicit weight reads of every nn.Conv3d above. */
 int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_t ntaps, int32_t transpose, int32_t stem,
                        int32_t dtype, void* out, void* stream);
+
+/* Multi-tensor vinet_pack_weights: one launch for every weight of the model (they all go stale together
+ * after the optimizer step; replaces ~170 launches of model_utils.py conv weights per training step).
+ * `table` is DEVICE memory: (njobs + 1) rows of 8 int64
+ *   { w (const float*), out (packed, dtype), N, Cin, ntaps, transpose | stem << 1, first output index, 0 }
+ * the last row carrying only the total in its prefix field; layouts exactly as vinet_pack_weights. */
+int vinet_pack_weights_multi(const int64_t* table, int32_t njobs, int64_t total, int32_t dtype, void* stream);
 /* packed fp32 dw -> torch layout; grad (+)= dw. */
 int vinet_unpack_wgrad(const float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem, int32_t accumulate,
                        float* grad, void* stream);

@@ -248,6 +248,14 @@ class AbiEmulator:
         raw[:] = o.reshape(-1) if dtype == F32 else _f2bf(o.reshape(-1))
         return 0
 
+    def vinet_pack_weights_multi(self, table, njobs, total, dtype, stream):
+        tab = np.ctypeslib.as_array((C.c_int64 * (8 * (njobs + 1))).from_address(table)).reshape(njobs + 1, 8)
+        assert int(tab[njobs, 6]) == total
+        for j in range(njobs):
+            w, out, N, Cin, ntaps, flags = (int(v) for v in tab[j, :6])
+            self.vinet_pack_weights(w, N, Cin, ntaps, flags & 1, (flags >> 1) & 1, dtype, out, stream)
+        return 0
+
     def vinet_unpack_wgrad(self, dw, N, Cin, ntaps, stem, accumulate, grad, stream):
         g = _f32(grad, N * Cin * ntaps).reshape(N, Cin, ntaps)
         if stem:

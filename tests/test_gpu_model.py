@@ -10,6 +10,7 @@ import os
 import pytest
 import torch
 
+from oracle import vinet_cpu as O
 from tests import goldens as G
 from tests import model_cases as MC
 from vinet_amd import _lib as L
@@ -130,6 +131,45 @@ def test_avinet_fp32():
     d = MC.close(y, z["y"], 1e-4, "avinet map")
     assert int(y.reshape(-1).argmax()) == meta["argmax"]
     _note("avinet_fp32", dict(max_abs=d, top2_gap=meta["top2_gap"]))
+
+
+def test_avinet_train_step_fp32():
+    """BASELINE config 4: gradients reach the SoundNet branch and the bilinear fusion and agree with the oracle.
+    Batch 1 (the BatchNorms see one clip), so the comparison is as loose as the reference's own fp32-vs-fp64
+    spread; conv biases that feed a train-mode BatchNorm have a true gradient of exactly zero and are skipped."""
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    E.set_default_dtype("fp32")
+    T, H, W = 32, 224, 384
+    o = O.VideoAudioSaliencyModel(num_clips=T)
+    sd = synth.synth_state_dict(o.state_dict(), 3)
+    o.load_state_dict(sd)
+    o.train()
+    m = VM.VideoAudioSaliencyModel(num_clips=T)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    x = synth.clip(1, T, H, W, 5).permute(0, 2, 1, 3, 4).contiguous()
+    a = synth.audio(1, 70560, 5)
+    gt = synth.gt_map(1, H, W, 5)
+    po = o(x, a)
+    O.kldiv(po, gt).backward()
+    pm = m(x.to(DEV), a.to(DEV))
+    VL.kldiv(pm, gt.to(DEV)).backward()
+    MC.close(pm, po.detach(), 1e-4, "avinet train-mode map")
+    ref = dict(o.named_parameters())
+    worst = {}
+    for k, p in m.named_parameters():
+        if ref[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        if k.startswith("audionet.conv") and k.endswith(".bias") and "conv8" not in k:
+            continue
+        e = float((p.grad.cpu() - ref[k].grad).norm() / (ref[k].grad.norm() + 1e-30))
+        grp = k.split(".")[0]
+        worst[grp] = max(worst.get(grp, 0.0), e)
+        assert e < 0.25, "%s: relative gradient error %.3e" % (k, e)
+    assert "audionet" in worst and "bilinear" in worst
+    _note("avinet_train_fp32", dict(worst_rel_grad_err=worst))
 
 
 def test_graphed_inference_matches_eager():

@@ -115,6 +115,50 @@ extern "C" int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_
   return vn_launch_status("pack_weights");
 }
 
+// Multi-tensor form: every weight of the model is re-packed after each optimizer step, 170 launches of a few
+// microseconds each when done one by one.  `table` (device memory) holds 8 int64 per job:
+//   { w pointer, out pointer, N, Cin, ntaps, transpose | stem << 1, first output index (prefix sum), unused }
+// plus one trailing row whose prefix field is the total; one thread per output element, job by binary search.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long* __restrict__ table, int njobs, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = njobs;               // last job with prefix <= i
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (table[mid * 8 + 6] <= i) lo = mid; else hi = mid;
+    }
+    const long* J = table + lo * 8;
+    const float* w = (const float*)J[0];
+    T* out = (T*)J[1];
+    const int N = (int)J[2], Cin = (int)J[3], ntaps = (int)J[4];
+    const int transpose = (int)(J[5] & 1), stem = (int)((J[5] >> 1) & 1);
+    const long e = i - J[6];
+    const int rows = (stem || !transpose) ? N : Cin;
+    const int Kp = stem ? 32 : ((transpose ? N : Cin) + 31) / 32 * 32;
+    const int k = (int)(e % Kp);
+    const int r = (int)((e / Kp) % rows);
+    const int sl = (int)(e / ((long)Kp * rows));
+    float v = 0.f;
+    if (stem) {
+      const int kw = k >> 2, c = k & 3;
+      if (kw < 7 && c < Cin) v = w[((long)r * Cin + c) * ntaps + sl * 7 + kw];
+    } else if (!transpose) {
+      if (k < Cin) v = w[((long)r * Cin + k) * ntaps + sl];
+    } else {
+      if (k < N) v = w[((long)k * Cin + r) * ntaps + sl];
+    }
+    store1<T>(out + e, v);
+  }
+}
+
+extern "C" int vinet_pack_weights_multi(const int64_t* table, int32_t njobs, int64_t total, int32_t dtype, void* stream) {
+  VN_CHECK_ARG(table && njobs > 0 && total > 0, "pack_weights_multi: bad arguments");
+  int grid = ew_grid(total); if (grid > 16384) grid = 16384;
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL(pack_weights_multi_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                          (const long*)table, njobs, (long)total);)
+  return vn_launch_status("pack_weights_multi");
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dw, int N, int Cin, int ntaps, int stem, int Kp,
                                     int accumulate, float* __restrict__ grad) {
   const long total = (long)N * Cin * ntaps;

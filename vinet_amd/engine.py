@@ -22,6 +22,7 @@ import ctypes as C
 import itertools
 import math
 import os
+import weakref
 
 import torch
 
@@ -452,23 +453,73 @@ class ConvPlan:
     # ---- packed weights -----------------------------------------------------
     def packed(self, ctx, transpose=False):
         key = (ctx.dt, transpose, str(ctx.device))
-        stamp = (self.weight._version, _WEIGHTS_EPOCH, self.weight.data_ptr())
+        stamp = self._pack_stamp()
         ent = self._packs.get(key)
         if ent is not None and ent[0] == stamp:
             return ent[1]
+        if ent is not None and _PACKS.repack_all(ctx, key):     # stale: every registered weight in one launch
+            return self._packs[key][1]
         w = self.weight.detach()
         assert w.dtype == torch.float32 and w.is_contiguous()
-        if self.stem and not transpose:
-            n = 7 * self.N * 32
-        elif not transpose:
-            n = self.ntaps * self.N * self.kp(False)
-        else:
-            n = self.ntaps * self.Cin * self.kp(True)
-        buf = ent[1] if ent is not None else torch.empty(n, dtype=TORCH_DT[ctx.dt], device=ctx.device)
+        buf = ent[1] if ent is not None else torch.empty(self.pack_numel(transpose), dtype=TORCH_DT[ctx.dt], device=ctx.device)
         ctx.call("vinet_pack_weights", w.data_ptr(), self.N, self.Cin, self.ntaps, 1 if transpose else 0,
                  1 if (self.stem and not transpose) else 0, ctx.dt, buf.data_ptr(), ctx.stream)
         self._packs[key] = (stamp, buf)
+        _PACKS.register(self, key)
         return buf
+
+    def _pack_stamp(self):
+        return (self.weight._version, _WEIGHTS_EPOCH, self.weight.data_ptr())
+
+    def pack_numel(self, transpose):
+        if self.stem and not transpose:
+            return 7 * self.N * 32
+        if not transpose:
+            return self.ntaps * self.N * self.kp(False)
+        return self.ntaps * self.Cin * self.kp(True)
+
+
+class _PackRegistry:
+    """Every (plan, dtype, transpose, device) pack that has been built once.  After an optimizer step all of them
+    are stale together, so the first stale request re-packs the whole group with ONE vinet_pack_weights_multi
+    launch (a device-side job table, rebuilt only when the set of jobs or a weight pointer changes)."""
+
+    def __init__(self):
+        self.groups = {}      # (dt, device str) -> dict(jobs=[(weakref(plan), key)], table=None, sig=None, total=0)
+
+    def register(self, plan, key):
+        g = self.groups.setdefault((key[0], key[2]), dict(jobs=[], table=None, sig=None, total=0))
+        g["jobs"].append((weakref.ref(plan), key))
+        g["table"] = None
+
+    def repack_all(self, ctx, key):
+        g = self.groups.get((key[0], key[2]))
+        if g is None:
+            return False
+        live = [(r(), k) for r, k in g["jobs"] if r() is not None and k in r()._packs]
+        if len(live) != len(g["jobs"]):
+            g["jobs"] = [(weakref.ref(p), k) for p, k in live]
+            g["table"] = None
+        if len(live) < 2:
+            return False
+        sig = tuple((p.weight.data_ptr(), p._packs[k][1].data_ptr()) for p, k in live)
+        if g["table"] is None or g["sig"] != sig:
+            rows, off = [], 0
+            for p, k in live:
+                tr = 1 if k[1] else 0
+                stem = 1 if (p.stem and not k[1]) else 0
+                rows.append([p.weight.data_ptr(), p._packs[k][1].data_ptr(), p.N, p.Cin, p.ntaps, tr | (stem << 1), off, 0])
+                off += p.pack_numel(k[1])
+            rows.append([0, 0, 0, 0, 0, 0, off, 0])
+            g["table"] = torch.tensor(rows, dtype=torch.int64).to(ctx.device)
+            g["sig"], g["total"] = sig, off
+        ctx.call("vinet_pack_weights_multi", g["table"].data_ptr(), len(live), g["total"], key[0], ctx.stream)
+        for p, k in live:
+            p._packs[k] = (p._pack_stamp(), p._packs[k][1])
+        return True
+
+
+_PACKS = _PackRegistry()
 
 
 class BNState:
