@@ -998,13 +998,16 @@ extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, Vin
   VN_CHECK_ARG(d->kT * d->kH * d->kW <= 255 && d->kT > 0 && d->kH > 0 && d->kW > 0, "maxpool3d: window too large");
   const PoolP p = make_poolp(d);
   if (d->kT == 3 && d->sT == 1 && d->pT == 1 && y->T == x->T && x->T >= 2 && oct_ok(*x) && oct_ok(*y) &&
-      (!argmax || ((uintptr_t)argmax % 8) == 0)) {
+      (!argmax || ((uintptr_t)argmax % 8) == 0) &&
+      (g_vinet_opt_pool_twalk >= 2 || (long)y->B * y->H * y->W * (y->C / 8) >= 65536)) {
+    // (fewer columns than that cannot fill the chip while each lane walks T serially: batch-1 inference
+    //  takes the one-thread-per-output kernel below)
     const long cols8 = (long)y->B * y->H * y->W * (y->C / 8);
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_tslide8_kernel<T>, dim3(ew_grid(cols8)), dim3(256), 0,
                                                (hipStream_t)stream, p, make_view(*x), make_affine(pre), make_view(*y), argmax, cols8);)
     return vn_launch_status("maxpool3d(tslide8)");
   }
-  if (d->kT == 3 && d->sT == 1 && d->pT == 1 && y->T == x->T && x->T >= 2) {
+  if (d->kT == 3 && d->sT == 1 && d->pT == 1 && y->T == x->T && x->T >= 2 && !(oct_ok(*x) && oct_ok(*y))) {
     const long cols = (long)y->B * y->H * y->W * (y->C / 4);
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_tslide_kernel<T>, dim3(ew_grid(cols)), dim3(256), 0,
                                                (hipStream_t)stream, p, make_view(*x), make_affine(pre), make_view(*y), argmax, cols);)

@@ -525,9 +525,16 @@ _PACKS = _PackRegistry()
 class BNState:
     """parameters/buffers of one BatchNorm + per-forward scratch."""
 
-    def __init__(self, gamma, beta, running_mean, running_var, eps, momentum):
+    def __init__(self, gamma, beta, running_mean, running_var, eps, momentum, fold_cache=None):
         self.gamma, self.beta, self.rm, self.rv, self.eps, self.momentum = gamma, beta, running_mean, running_var, eps, momentum
         self.steps = 0   # forwards in training mode since the counter buffer was last synced
+        # eval-mode (scale, shift) of the folded BN, owned by the module: inference re-folds only when a
+        # parameter / buffer / conv bias changed (tensor versions, pointers, optimizer epoch)
+        self.fold_cache = fold_cache
+
+    def fold_stamp(self, bias, dt, device):
+        ts = (self.gamma, self.beta, self.rm, self.rv, bias)
+        return (tuple((t._version, t.data_ptr()) if t is not None else None for t in ts), _WEIGHTS_EPOCH, dt, str(device))
 
 
 def _param_grad(p):
@@ -617,8 +624,18 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
             res.scale, res.shift, res.relu = scale, shift, (act == L.ACT_RELU)
             keep.update(mean=bn.rm, invstd=invstd)
         else:
-            ctx.call("vinet_bn_fold", _ptr(bn.gamma), _ptr(bn.beta), bn.rm.data_ptr(), bn.rv.data_ptr(),
-                     _ptr(plan.bias), float(bn.eps), plan.N, scale.data_ptr(), shift.data_ptr(), None, ctx.stream)
+            cached = None
+            if scale_out is None and shift_out is None and bn.fold_cache is not None:
+                stamp = bn.fold_stamp(plan.bias, ctx.dt, ctx.device)
+                cached = bn.fold_cache.get("fold")
+                if cached is not None and cached[0] == stamp:
+                    scale, shift = cached[1], cached[2]
+                else:
+                    cached = None
+                    bn.fold_cache["fold"] = (stamp, scale, shift)
+            if cached is None:
+                ctx.call("vinet_bn_fold", _ptr(bn.gamma), _ptr(bn.beta), bn.rm.data_ptr(), bn.rv.data_ptr(),
+                         _ptr(plan.bias), float(bn.eps), plan.N, scale.data_ptr(), shift.data_ptr(), None, ctx.stream)
             d.out_scale, d.out_shift, d.act, d.stats = scale.data_ptr(), shift.data_ptr(), act, None
             ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
             res.scale = res.shift = None

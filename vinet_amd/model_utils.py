@@ -36,10 +36,12 @@ class _BNMixin:
         raise RuntimeError("BatchNorm parameters only; call the owning vinet_amd block")
 
     def state(self):
-        return E.BNState(self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum)
+        return E.BNState(self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
+                         fold_cache=self.__dict__.setdefault("_vinet_fold", {}))
 
     def note_training_step(self):
         self.__dict__["_vinet_pending"] = self.__dict__.get("_vinet_pending", 0) + 1
+        self.__dict__.setdefault("_vinet_fold", {}).clear()   # running statistics changed under the cached fold
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         pend = self.__dict__.get("_vinet_pending", 0)
