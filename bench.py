@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
     ap.add_argument("--clip", type=int, default=32)
     ap.add_argument("--height", type=int, default=224)
     ap.add_argument("--width", type=int, default=384)
@@ -247,8 +247,9 @@ def main():
         traffic, pmc = None, None
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f)["kernels"].get(dom.replace(" ", ""))
-            if pmc is not None and B == 32 and args.mode == "train":
+                pj = json.load(f)
+                pmc = pj["kernels"].get(dom.replace(" ", ""))
+            if pmc is not None and B == pj.get("batch", 32) and args.mode == "train":
                 traffic = pmc["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass

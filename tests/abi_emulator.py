@@ -89,7 +89,7 @@ def _gather(x, idx, axis, size):
     return g * ok.reshape(shape)
 
 
-def _tile_m(dtype, mode, M, N):
+def _tile_m(dtype, mode, M, N, kchunks=0):
     if mode == 1:
         return 256 if dtype == BF16 else 128
     nts = [8, 6, 4, 3, 2, 1]
@@ -101,6 +101,8 @@ def _tile_m(dtype, mode, M, N):
             nt = c
             break
     if dtype == F32:
+        return 128
+    if nt == 4 and 0 < kchunks <= 32 and M >= (1 << 20):
         return 128
     bm = 256
     if nt in (8, 4):
@@ -143,7 +145,7 @@ class AbiEmulator:
             tiles = ((M + 255) // 256) * ((N + bn - 1) // bn)
             if N >= 160 and nkt >= 16 and tiles >= 128:
                 return 256
-        return _tile_m(d.dtype, d.mode, M, N)
+        return _tile_m(d.dtype, d.mode, M, N, d.ntaps * (d.Kp // 32))
 
     def vinet_conv3d_kernel_name(self, d, buf, n):
         return 0

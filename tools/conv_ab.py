@@ -39,6 +39,10 @@ SITES = [
     ("dg 3c s 192->128", 8, 16, 28, 48, 192, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("dg 4x s 320->160", 8, 8, 14, 24, 320, 160, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("dg 4x t 320->320", 8, 8, 14, 24, 320, 320, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    # 64-channel outputs at huge M: short K loops, epilogue / latency bound
+    ("dg stem_t 64->64 4taps", 8, 16, 112, 192, 64, 64, (4, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("dg b1.3s 192->64 1x3x3", 8, 16, 56, 96, 192, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("stem folded 32->64 7taps", 8, 32, 118, 100, 32, 64, (1, 7, 1), (1, 1, 1), (0, 0, 0)),
 ]
 
 
@@ -73,11 +77,12 @@ def main():
             variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), True))
         libs = []
     for ln, lib in libs:
-        variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=1), False))
-        variants.append((ln + ":pp192", lib, dict(dma=1, pp=4, tperm=1), False))
-        variants.append((ln + ":dma", lib, dict(dma=1, pp=0, tperm=1), False))
-        variants.append((ln + ":dma-noperm", lib, dict(dma=1, pp=0, tperm=0), False))
-        variants.append((ln + ":dma+pre", lib, dict(dma=1, pp=0, tperm=1), True))
+        variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=0, n64_tile=0), False))
+        variants.append((ln + ":pp192", lib, dict(dma=1, pp=4, tperm=0, n64_tile=0), False))
+        variants.append((ln + ":dma", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0), False))
+        variants.append((ln + ":dma-bm128", lib, dict(dma=1, pp=0, tperm=0, n64_tile=1), False))
+        variants.append((ln + ":dma-bm64", lib, dict(dma=1, pp=0, tperm=0, n64_tile=2), False))
+        variants.append((ln + ":dma+pre", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0), True))
 
     print("%-26s" % "site" + "".join("%22s" % (v[0][-21:].replace("libvinet_hip", "")) for v in variants) + "   (ms | TF/s)")
     for (name, B, T, H, W, Cin, N, k, s, p) in SITES:

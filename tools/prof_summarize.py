@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of tools/prof_run.sh (gpurun_out/prof_<tag>/) into the committed evidence:
+profiles/<tag>_rocprofv3_kernel_stats.csv, <tag>_pmc_summary.json, pmc_traffic.json (read by bench.py)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1_v4"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+out = os.path.join(ROOT, "profiles")
+
+
+def load(name):
+    f = glob.glob(os.path.join(base, "pmc_%s*" % name, "*", "*_counter_collection.csv"))[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for r in csv.DictReader(open(f)):
+        a = agg[r["Kernel_Name"]][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+    return agg
+
+
+fe, wr, sq = load("FETCH_SIZE"), load("WRITE_SIZE"), load("SQ_VALU_MFMA")
+stats_csv = glob.glob(os.path.join(base, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats_csv, os.path.join(out, tag + "_rocprofv3_kernel_stats.csv"))
+for name in ("bench.json", "bench_under_rocprof.json"):
+    if os.path.exists(os.path.join(base, name)):
+        shutil.copy(os.path.join(base, name), os.path.join(out, "%s_%s" % (tag, name)))
+stats = {r["Name"]: (int(r["Calls"]), float(r["AverageNs"]), float(r["Percentage"])) for r in csv.DictReader(open(stats_csv))}
+rows = []
+for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2])[:32]:
+    f = fe.get(k, {}).get("FETCH_SIZE", [0, 1])
+    w = wr.get(k, {}).get("WRITE_SIZE", [0, 1])
+    m = sq.get(k, {})
+    mf, ga = m.get("SQ_VALU_MFMA_BUSY_CYCLES", [0, 1]), m.get("GRBM_GUI_ACTIVE", [0, 1])
+    fetch_kb, write_kb = f[0] / max(f[1], 1), w[0] / max(w[1], 1)
+    hbm = (2 * fetch_kb + write_kb) * 1024
+    rows.append(dict(kernel=k, pct_of_gpu_time=pct, calls=calls, avg_us=round(avg / 1e3, 1),
+                     FETCH_SIZE_KB_raw_per_launch=round(fetch_kb, 1), WRITE_SIZE_KB_per_launch=round(write_kb, 1),
+                     traffic_bytes_per_launch=int(hbm), traffic_GBps=round(hbm / (avg * 1e-9) / 1e9) if avg else 0,
+                     mfma_busy_frac=round((mf[0] / mf[1]) / ((ga[0] / ga[1]) / 8 * 256 * 4), 3) if ga[0] else None))
+note = ("rocprofv3 --pmc, one pass per counter group (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES "
+        "GRBM_GUI_ACTIVE), command: python bench.py --steps 1 --warmup 1 --no-cpu-baseline (batch %d); per-launch averages over all "
+        "launches of the kernel.  traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes "
+        "for 16 B/lane streams (MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are included, so this is L2-miss (fabric) "
+        "traffic, an upper bound on HBM bytes.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 256 CUs * 4 SIMDs). "
+        "avg_us from the separate --kernel-trace --stats run of `python bench.py --steps 4 --warmup 2 --no-cpu-baseline`." % batch)
+json.dump(dict(note=note, kernels=rows), open(os.path.join(out, tag + "_pmc_summary.json"), "w"), indent=1)
+short = {}
+for r in rows:
+    k = re.sub(r"^void ", "", r["kernel"])
+    k = re.sub(r"\(.*\)$", "", k).replace(" ", "")
+    k = k.replace(",false>", ",plain>").replace(",true>", ",pre>")
+    k = k.replace("conv_pp_kernel<2,4,256>", "conv_pp_kernel<256>").replace("conv_pp_kernel<4,2,192>", "conv_pp_kernel<192>")
+    m = re.match(r"conv_wgrad_dma_kernel<(\d+),(\d+),(\d+),(\d+),(\w+)>", k)
+    if m:
+        k = "conv_wgrad_dma_kernel<%s,%s,%s,%s>" % (m[1], m[2], m[3], m[5])
+    short[k] = dict(traffic_bytes_per_launch=r["traffic_bytes_per_launch"], mfma_busy_frac=r["mfma_busy_frac"], avg_us=r["avg_us"])
+json.dump(dict(source="profiles/%s_pmc_summary.json" % tag, batch=batch, kernels=short), open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+for r in rows[:14]:
+    print("%-72s %5.1f%% %9.1f us  traffic %8.1f MB  mfma busy %s" % (r["kernel"][:72], r["pct_of_gpu_time"], r["avg_us"], r["traffic_bytes_per_launch"] / 1e6, r["mfma_busy_frac"]))

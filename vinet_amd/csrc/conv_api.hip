@@ -6,6 +6,7 @@
 
 static thread_local char g_err[512] = "";
 extern int g_vinet_opt_tperm;
+extern int g_vinet_opt_n64_tile;
 
 void vinet_set_error(const char* fmt, ...) {
   va_list ap;
@@ -19,7 +20,7 @@ extern "C" int vinet_abi_version(void) { return VINET_ABI_VERSION; }
 
 // Largest BN whose padded width is within 25% of the best achievable padding;
 // then shrink BM while the grid would leave most of the 256 CUs idle.
-ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N) {
+ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks) {
   if (mode == VINET_CONV_STEM) return dtype == VINET_BF16 ? ConvTile{4, 4, 4, 1} : ConvTile{2, 4, 4, 1};
   static const int nts[6] = {8, 6, 4, 3, 2, 1};
   int best_pad = 1 << 30;
@@ -36,6 +37,11 @@ ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N) {
   }
   if (dtype == VINET_F32) return ConvTile{2, nt, 4, 1};  // BM = 128
   ConvTile t{4, nt, 4, 1};                               // BM = 256
+  if (g_vinet_opt_n64_tile && nt == 4) return g_vinet_opt_n64_tile == 1 ? ConvTile{4, 2, 2, 2} : ConvTile{2, 2, 2, 2};   // tuning
+  // 64-wide outputs with a short K loop (the stem, its 7x1x1 partner and their dgrads: 7-16 K steps at
+  // 10-20 M voxels) are prologue / epilogue bound: 128-row tiles put 4-6 workgroups on a CU instead of 2-3
+  // (+5...17 % measured, tools/conv_ab.py)
+  if (nt == 4 && kchunks > 0 && kchunks <= 32 && M >= (1L << 20)) return ConvTile{4, 2, 2, 2};
   if (nt == 8 || nt == 4) {
     const int bn = nt * 16;
     const long tilesN = (N + bn - 1) / bn;
@@ -89,7 +95,7 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   a.act = d->act; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == VINET_F32;
   const int oeb = a.out_f32 ? 4 : 2;
   a.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && (a.sBy % 4 == 0) && ((((uintptr_t)d->y.ptr) % (4 * oeb)) == 0);
-  t = vinet_pick_conv_tile(d->dtype, d->mode, M, a.N);
+  t = vinet_pick_conv_tile(d->dtype, d->mode, M, a.N, (long)d->ntaps * (d->Kp / 32));
   a.perm_P = a.perm_T = 0;
   a.dPT = a.dPermT = make_fastdiv(1);
   if (g_vinet_opt_tperm && d->dtype == VINET_BF16 && d->mode == VINET_CONV_GENERIC && t.BM() == 256 && d->oT > 1 &&
@@ -110,10 +116,11 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   if (!d) return -1;
   if (use_pp(d)) return 256;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
-  return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C).BM();
+  return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32)).BM();
 }
 
 int g_vinet_opt_dma = 1;
+int g_vinet_opt_n64_tile = 0;   // tuning: 64-wide layers on 128x64 (1) or 64x64 (2) tiles instead of 256x64
 int g_vinet_opt_pool_twalk = 1; // T-walking 3x3x3/s1 max-pool backward
 int g_vinet_opt_tperm = 0;      // t-fastest M-tile order (L2 reuse across temporal taps): measured neutral on the whole step, off
 int g_vinet_opt_wgrad_tr = 1;
@@ -125,6 +132,7 @@ int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
   if (name && !strcmp(name, "pool_twalk")) { g_vinet_opt_pool_twalk = value; return 0; }
+  if (name && !strcmp(name, "n64_tile")) { g_vinet_opt_n64_tile = value; return 0; }
   if (name && !strcmp(name, "tperm")) { g_vinet_opt_tperm = value; return 0; }
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }
@@ -169,7 +177,7 @@ static bool use_pp(const VinetConvDesc* d) {
 extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32_t n) {
   if (!d || !buf || n <= 0) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
-  const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C);
+  const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32));
   if (use_pp(d)) snprintf(buf, n, "conv_pp_kernel<%d>", pp_bn(d->y.C));
   else if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
   else snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", t.MT, t.NT, t.WM, t.WN, d->mode);
