@@ -565,11 +565,24 @@ POOLS = [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), (
 def test_maxpool_k3s1_twalk_backward(dt):
     """the T-walking 3x3x3/s1 backward (chosen for large tensors only) forced on the small test shape"""
     lib = _lib()
-    assert lib.vinet_set_option(b"pool_twalk", 2) == 0
+    assert lib.vinet_set_option(b"pool_twalk", 2) == 0 and lib.vinet_set_option(b"pool_lds", 0) == 0
     try:
         test_maxpool(dt, ((3, 3, 3), (1, 1, 1), (1, 1, 1)))
     finally:
         lib.vinet_set_option(b"pool_twalk", 1)
+        lib.vinet_set_option(b"pool_lds", 1)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_maxpool_k3s1_lds_forward(dt):
+    """the LDS halo-tile 3x3x3/s1 forward (chosen for large tensors only) forced on the small test shape
+    (partial spatial tiles, partial channel group)"""
+    lib = _lib()
+    assert lib.vinet_set_option(b"pool_lds", 2) == 0
+    try:
+        test_maxpool(dt, ((3, 3, 3), (1, 1, 1), (1, 1, 1)))
+    finally:
+        lib.vinet_set_option(b"pool_lds", 1)
 
 
 @pytest.mark.parametrize("dt", DTS)

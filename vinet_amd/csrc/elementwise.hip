@@ -6,6 +6,7 @@
 #include "common.h"
 
 extern int g_vinet_opt_pool_twalk;
+extern int g_vinet_opt_pool_lds;
 
 // ---- 4-channel ("quad") typed access -----------------------------------------
 template <typename T> VN_DEV float4 ldq(const T* p);
@@ -991,12 +992,145 @@ __global__ __launch_bounds__(256) void maxpool_tslide8_kernel(PoolP p, TView x, 
   }
 }
 
+// 3x3x3 / s1 / p1 forward through an LDS halo tile: a 512-thread workgroup owns 8 x 8 outputs x 64 channels of
+// one clip and walks T.  Per input plane the 10 x 10 halo (affine + ReLU applied once per element, fp32) is staged
+// in LDS (double buffered: one barrier per plane), every lane takes its 3 x 3 window maximum from LDS, and the
+// last three plane maxima live in named registers as in maxpool_tslide8_kernel.  One global read per input
+// element (plus halo) instead of nine cached ones: the T-walking kernel is bound by the CU's load path (0.8 TB/s).
+// Out-of-range halo positions hold -inf: strict comparisons never select them, so the tie rule is unchanged.
+template <typename T>
+__global__ __launch_bounds__(512) void maxpool_k3s1_lds_kernel(TView x, Affine pre, TView y, uint8_t* __restrict__ argmax,
+                                                               int tilesH, int tilesW) {
+  __shared__ __attribute__((aligned(16))) float P[2][100][64];
+  const int tid = threadIdx.x;
+  const int oct = tid & 7, pos = tid >> 3;          // 8 channel octets x 64 positions
+  const int ph = pos >> 3, pw = pos & 7;
+  int bid = blockIdx.x;
+  const int ncg = (x.C + 63) >> 6;                  // channel groups of 64 (the last may be partial)
+  const int cg = bid % ncg; bid /= ncg;
+  const int tw = bid % tilesW; bid /= tilesW;
+  const int th = bid % tilesH; bid /= tilesH;
+  const int b = bid;
+  const int h0 = th * 8, w0 = tw * 8, c0 = cg * 64 + oct * 8;
+  const int ho = h0 + ph, wo = w0 + pw;
+  const bool out_ok = ho < y.H && wo < y.W && c0 < x.C;
+  // scale / shift of the tile's 64 channels in LDS (16 more live registers per lane would cost a workgroup of
+  // occupancy, which this latency-bound walk cannot afford)
+  __shared__ __attribute__((aligned(16))) float S[2][64];
+  if (tid < 64) {
+    const bool ok = pre.scale != nullptr && cg * 64 + tid < x.C;
+    S[0][tid] = ok ? pre.scale[cg * 64 + tid] : 1.f;
+    S[1][tid] = ok ? pre.shift[cg * 64 + tid] : 0.f;
+  }
+  __syncthreads();
+  float m_a[8], m_b[8], m_c[8];
+  unsigned long long i_a = 0, i_b = 0, i_c = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { m_a[e] = -INFINITY; m_b[e] = -INFINITY; m_c[e] = -INFINITY; }
+  const int T_ = x.T;
+  for (int tp = 0; tp <= T_; ++tp) {
+    float (*buf)[64] = P[tp & 1];
+    if (tp < T_) {
+      // stage the halo of plane tp: 100 positions x 8 octets = 800 items over 512 threads
+      for (int it = tid; it < 800; it += 512) {
+        const int o8 = oct, hp = it >> 3;           // (it & 7) == oct
+        const int hh = h0 - 1 + hp / 10, ww = w0 - 1 + hp % 10;
+        float v[8];
+        if (cg * 64 + o8 * 8 >= x.C) continue;        // partial last channel group
+        if ((unsigned)hh < (unsigned)x.H && (unsigned)ww < (unsigned)x.W) {
+          ld8<T>((const T*)x.p + vox_off(x, b, tp, hh, ww) + cg * 64 + o8 * 8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = fmaf(v[e], S[0][oct * 8 + e], S[1][oct * 8 + e]);
+            if (pre.relu) v[e] = fmaxf(v[e], 0.f);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = -INFINITY;
+        }
+        *(float4*)&buf[hp][o8 * 8] = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)&buf[hp][o8 * 8 + 4] = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    __syncthreads();     // plane tp staged; every lane finished reading the buffer staged two planes ago
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m_a[e] = m_b[e]; m_b[e] = m_c[e]; m_c[e] = -INFINITY; }
+    i_a = i_b; i_b = i_c; i_c = 0;
+    if (tp < T_) {
+      // window maximum of the plane, 4 channels at a time: the max by four 3-input maxima, then the FIRST tap
+      // that equals it (scan from the last tap down, so the smallest index is the one left standing) -- 20 VALU
+      // per element instead of ~45 for compare-and-track.  v_max3 drops NaNs where aten propagates them: a NaN
+      // anywhere in the window (sum test) takes the compare-and-track path.
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float f[9][4];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float4 q = *(const float4*)&buf[(ph + kh) * 10 + pw + kw][oct * 8 + half * 4];
+            f[kh * 3 + kw][0] = q.x; f[kh * 3 + kw][1] = q.y; f[kh * 3 + kw][2] = q.z; f[kh * 3 + kw][3] = q.w;
+          }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int e = half * 4 + c;
+          const float sum = ((f[0][c] + f[1][c]) + (f[2][c] + f[3][c])) + ((f[4][c] + f[5][c]) + (f[6][c] + f[7][c])) + f[8][c];
+          float m;
+          unsigned idx;
+          if (sum == sum) {
+            m = fmaxf(fmaxf(fmaxf(f[0][c], f[1][c]), f[2][c]), fmaxf(fmaxf(fmaxf(f[3][c], f[4][c]), f[5][c]), fmaxf(fmaxf(f[6][c], f[7][c]), f[8][c])));
+            idx = 8;
+#pragma unroll
+            for (int k = 7; k >= 0; --k) idx = (f[k][c] == m) ? (unsigned)k : idx;
+          } else {
+            m = -INFINITY; idx = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+              if (f[k][c] > m || (f[k][c] != f[k][c] && m == m)) { m = f[k][c]; idx = (unsigned)k; }
+          }
+          m_c[e] = m;
+          i_c |= (unsigned long long)idx << (8 * e);
+        }
+      }
+    }
+    const int to = tp - 1;
+    if (to < 0 || !out_ok) continue;
+    float o[8];
+    unsigned long long oi = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float best = -INFINITY;
+      unsigned long long bi = 0;
+      if (to >= 1 && (m_a[e] > best || (m_a[e] != m_a[e] && best == best))) { best = m_a[e]; bi = (i_a >> (8 * e)) & 0xffull; }
+      if (m_b[e] > best || (m_b[e] != m_b[e] && best == best)) { best = m_b[e]; bi = 9ull + ((i_b >> (8 * e)) & 0xffull); }
+      if (to + 1 < T_ && (m_c[e] > best || (m_c[e] != m_c[e] && best == best))) { best = m_c[e]; bi = 18ull + ((i_c >> (8 * e)) & 0xffull); }
+      o[e] = best;
+      oi |= bi << (8 * e);
+    }
+    st8<T>((T*)y.p + vox_off(y, b, to, ho, wo) + c0, o);
+    if (argmax) {
+      const long ovox = (((long)b * y.T + to) * y.H + ho) * y.W + wo;
+      *(unsigned long long*)(argmax + ovox * y.C + c0) = oi;
+    }
+  }
+}
+
 extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, VinetAffine pre, const VinetTensor* y,
                                uint8_t* argmax, void* stream) {
   VN_CHECK_ARG(d && x && y && quad_ok(*x, esize(d->dtype)) && quad_ok(*y, esize(d->dtype)) && x->C == y->C && x->B == y->B,
                "maxpool3d: bad views");
   VN_CHECK_ARG(d->kT * d->kH * d->kW <= 255 && d->kT > 0 && d->kH > 0 && d->kW > 0, "maxpool3d: window too large");
   const PoolP p = make_poolp(d);
+  const bool k3s1 = d->kT == 3 && d->kH == 3 && d->kW == 3 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 1 && d->pH == 1 &&
+                    d->pW == 1 && y->T == x->T && y->H == x->H && y->W == x->W;
+  if (k3s1 && g_vinet_opt_pool_lds && x->T >= 2 && oct_ok(*x) && oct_ok(*y) && (!argmax || ((uintptr_t)argmax % 8) == 0) &&
+      (g_vinet_opt_pool_lds >= 2 || (long)y->B * y->H * y->W * (y->C / 8) >= 65536)) {
+    const int tilesH = (y->H + 7) / 8, tilesW = (y->W + 7) / 8;
+    const long blocks = (long)y->B * tilesH * tilesW * ((y->C + 63) / 64);
+    DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_k3s1_lds_kernel<T>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream,
+                                               make_view(*x), make_affine(pre), make_view(*y), argmax, tilesH, tilesW);)
+    return vn_launch_status("maxpool3d(k3s1 lds)");
+  }
   if (d->kT == 3 && d->sT == 1 && d->pT == 1 && y->T == x->T && x->T >= 2 && oct_ok(*x) && oct_ok(*y) &&
       (!argmax || ((uintptr_t)argmax % 8) == 0) &&
       (g_vinet_opt_pool_twalk >= 2 || (long)y->B * y->H * y->W * (y->C / 8) >= 65536)) {
