@@ -682,3 +682,78 @@ def test_bilinear(dt):
     run_both("vinet_bilinear_bwd", lambda s: [x1.ptr(s), x2.ptr(s), do.ptr(s), dt, w.ptr(s), B, Cc, I, J, O, d1.ptr(s), d2.ptr(s), dw.ptr(s), db.ptr(s), _stream() if s == "gpu" else 0])
     for a, nm in ((d1, "dx1"), (d2, "dx2"), (dw, "dw"), (db, "dbias")):
         _cmp(a.get("gpu"), a.get("cpu"), 5e-5 if dt == E.F32 else 3e-2, "bilinear bwd " + nm)
+
+
+def test_pingpong_kernels_race_screen():
+    """The ping-pong kernels order LDS-DMA writes against fragment reads by counted vmcnt + barriers only; a
+    misplaced wait shows up as RARE wrong tiles.  Screen: large layer shapes (many workgroups per CU, every
+    pipeline stage exercised), repeated launches, compared with the conv_dma / wgrad_dma result of the same
+    descriptor (same math, different accumulation order)."""
+    lib = _lib()
+    dev = _dev()
+    B, T, H, W, Cin, N, k = 4, 8, 28, 48, 256, 384, (1, 3, 3)
+    x = (_rand("rsx", (B * T * H * W * Cin,), 1)).to(torch.bfloat16).to(dev)
+    ntaps = 9
+    w = (_rand("rsw", (ntaps * N * Cin,), 2, 1.0 / math.sqrt(Cin * ntaps))).to(torch.bfloat16).to(dev)
+    taps = torch.tensor(_fwd_taps(k, (0, 1, 1)), dtype=torch.int32, device=dev)
+    ys = [torch.empty(B * T * H * W * N, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+
+    def conv(y):
+        d = L.CConvDesc()
+        d.dtype = d.out_dtype = E.BF16
+        d.mode = 0
+        d.x = L.CTensor(x.data_ptr(), B, T, H, W, Cin, Cin, T * H * W * Cin)
+        d.y = L.CTensor(y.data_ptr(), B, T, H, W, N, N, T * H * W * N)
+        d.oT, d.oH, d.oW = T, H, W
+        d.sT = d.sH = d.sW = 1
+        d.omT = d.omH = d.omW = 1
+        d.ntaps, d.taps, d.w, d.Kp = ntaps, taps.data_ptr(), w.data_ptr(), Cin
+        d.pre = L.CAffine(None, None, 0)
+        assert lib.vinet_conv3d(C.byref(d), _stream()) == 0, lib.vinet_last_error()
+
+    try:
+        lib.vinet_set_option(b"pp", 0)
+        conv(ys[0])
+        torch.cuda.synchronize()
+        ref = ys[0].float()
+        scale = float(ref.abs().max())
+        for shape in (3, 4):
+            lib.vinet_set_option(b"pp", shape)
+            for it in range(12):
+                ys[1].zero_()
+                conv(ys[1])
+                torch.cuda.synchronize()
+                d = float((ys[1].float() - ref).abs().max())
+                assert d <= 2e-2 * scale, "conv_pp shape %d, launch %d: max diff %g (scale %g)" % (shape, it, d, scale)
+    finally:
+        lib.vinet_set_option(b"pp", 1)
+
+    # weight gradient: dy = the conv output above, x as is
+    dws = [torch.zeros(ntaps * N * Cin, device=dev) for _ in range(2)]
+
+    def wgrad(dw):
+        d = L.CWgradDesc()
+        d.dtype, d.mode = E.BF16, 0
+        d.x = L.CTensor(x.data_ptr(), B, T, H, W, Cin, Cin, T * H * W * Cin)
+        d.dy = L.CTensor(ys[0].data_ptr(), B, T, H, W, N, N, T * H * W * N)
+        d.sT = d.sH = d.sW = 1
+        d.ntaps, d.taps, d.dw, d.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), Cin
+        d.pre = L.CAffine(None, None, 0)
+        assert lib.vinet_conv3d_wgrad(C.byref(d), _stream()) == 0, lib.vinet_last_error()
+
+    try:
+        lib.vinet_set_option(b"wgrad_pp", 0)
+        wgrad(dws[0])
+        torch.cuda.synchronize()
+        ref = dws[0].clone()
+        scale = float(ref.abs().max())
+        for shape in (3, 4):
+            lib.vinet_set_option(b"wgrad_pp", shape)
+            for it in range(8):
+                dws[1].zero_()
+                wgrad(dws[1])
+                torch.cuda.synchronize()
+                d = float((dws[1] - ref).abs().max())
+                assert d <= 5e-3 * scale, "wgrad_pp tile %d, launch %d: max diff %g (scale %g)" % (shape, it, d, scale)
+    finally:
+        lib.vinet_set_option(b"wgrad_pp", 1)
