@@ -387,7 +387,7 @@ def test_conv3d_wgrad_pingpong(case, shape):
     try:
         d0 = _run_wgrad_case(case, E.BF16)
         buf = C.create_string_buffer(128)
-        assert lib.vinet_conv3d_wgrad_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_wgrad_pp_kernel")
+        assert lib.vinet_conv3d_wgrad_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_wgrad_pp_kernel<")
     finally:
         lib.vinet_set_option(b"wgrad_pp", 1)
 

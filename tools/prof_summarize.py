@@ -18,7 +18,7 @@ out = os.path.join(ROOT, "profiles")
 
 
 def load(name):
-    f = glob.glob(os.path.join(base, "pmc_%s*" % name, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(base, "pmc_%s*" % name, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # newest run
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for r in csv.DictReader(open(f)):
         a = agg[r["Kernel_Name"]][r["Counter_Name"]]
@@ -28,7 +28,7 @@ def load(name):
 
 
 fe, wr, sq = load("FETCH_SIZE"), load("WRITE_SIZE"), load("SQ_VALU_MFMA")
-stats_csv = glob.glob(os.path.join(base, "trace", "*", "*_kernel_stats.csv"))[0]
+stats_csv = max(glob.glob(os.path.join(base, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(stats_csv, os.path.join(out, tag + "_rocprofv3_kernel_stats.csv"))
 for name in ("bench.json", "bench_under_rocprof.json"):
     if os.path.exists(os.path.join(base, name)):
@@ -59,6 +59,11 @@ for r in rows:
     k = re.sub(r"\(.*\)$", "", k).replace(" ", "")
     k = k.replace(",false>", ",plain>").replace(",true>", ",pre>")
     k = k.replace("conv_pp_kernel<2,4,256>", "conv_pp_kernel<256>").replace("conv_pp_kernel<4,2,192>", "conv_pp_kernel<192>")
+    k = k.replace("conv_wgrad_pp_kernel<true,", "conv_wgrad_pp_kernel<pre,").replace("conv_wgrad_pp_kernel<false,", "conv_wgrad_pp_kernel<plain,")
+    k = k.replace("conv_wgrad_pp_kernel<pre,3>", "conv_wgrad_pp_kernel<pre,192>").replace("conv_wgrad_pp_kernel<pre,4>", "conv_wgrad_pp_kernel<pre,256>")
+    k = k.replace("conv_wgrad_pp_kernel<plain,3>", "conv_wgrad_pp_kernel<plain,192>").replace("conv_wgrad_pp_kernel<plain,4>", "conv_wgrad_pp_kernel<plain,256>")
+    k = re.sub(r"^channel_reduce8_kernel<\w+,1>$", "vinet_bn_bwd_reduce", k)
+    k = re.sub(r"^bn_bwd_apply8_kernel<\w+>$", "vinet_bn_bwd_apply", k)
     m = re.match(r"conv_wgrad_dma_kernel<(\d+),(\d+),(\d+),(\d+),(\w+)>", k)
     if m:
         k = "conv_wgrad_dma_kernel<%s,%s,%s,%s>" % (m[1], m[2], m[3], m[5])

@@ -17,6 +17,7 @@ extern int g_vinet_opt_wgrad_tg;
 int vinet_launch_wgrad_dma(const VinetWgradDesc* d, hipStream_t s);
 int vinet_wgrad_dma_name(const VinetWgradDesc* d, char* buf, int n);
 bool vinet_wgrad_use_pp(const VinetWgradDesc* d);
+int vinet_wgrad_pp_rows(int N);
 int vinet_launch_wgrad_pp(const VinetWgradDesc* d, hipStream_t s);
 
 struct WgradArgs {
@@ -251,7 +252,7 @@ static bool wgrad_use_dma(const VinetWgradDesc* d) {
 
 extern "C" int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* d, char* buf, int32_t n) {
   if (!d || !buf || n <= 0) return -1;
-  if (wgrad_use_dma(d) && vinet_wgrad_use_pp(d)) { snprintf(buf, n, "conv_wgrad_pp_kernel<%s>", d->pre.scale ? "pre" : "plain"); return 0; }
+  if (wgrad_use_dma(d) && vinet_wgrad_use_pp(d)) { snprintf(buf, n, "conv_wgrad_pp_kernel<%s,%d>", d->pre.scale ? "pre" : "plain", vinet_wgrad_pp_rows(d->dy.C)); return 0; }
   if (wgrad_use_dma(d)) return vinet_wgrad_dma_name(d, buf, n);
   snprintf(buf, n, "conv_wgrad_kernel<%s,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", d->mode);
   return 0;

@@ -399,6 +399,10 @@ static int wpp_tn(int N) {
   return p192 < p256 ? 192 : 256;
 }
 
+int vinet_wgrad_pp_rows(int N) {
+  return g_vinet_opt_wgrad_pp == 3 ? 256 : (g_vinet_opt_wgrad_pp == 4 ? 192 : wpp_tn(N));
+}
+
 // The ping-pong kernel wants mostly full tiles (rows: output channels; columns: 4 segments of 64
 // input channels), a long voxel range per workgroup and enough workgroups for 256 CUs.
 // Measured (tools/conv_ab.py --wgrad): it wins once >= 60% of the tile is real work.
@@ -440,7 +444,7 @@ int vinet_launch_wgrad_pp(const VinetWgradDesc* d, hipStream_t s) {
   a.cpt = (a.Cin + 63) / 64;
   a.dCpt = make_fastdiv(a.cpt);
   a.nseg = a.ntaps * a.cpt;
-  const int tn = g_vinet_opt_wgrad_pp == 3 ? 256 : (g_vinet_opt_wgrad_pp == 4 ? 192 : wpp_tn(a.N));
+  const int tn = vinet_wgrad_pp_rows(a.N);
   a.tilesN = vn_div_up(a.N, tn);
   a.tilesS = vn_div_up(a.nseg, 4);
   a.nkt = vn_div_up(a.M, 64);

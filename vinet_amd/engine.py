@@ -679,15 +679,20 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         rows = ctx.lib.vinet_stats_rows(C.byref(dz.ct()))
         ws = ctx.f32(rows * 2 * Ny)
         fwd = res.affine()
+        nb = float(dz.nvox * dz.C * ESIZE[dz.dt])
         ctx.call("vinet_bn_bwd_reduce", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
-                 keep["invstd"].data_ptr(), ws.data_ptr(), ctx.stream)
+                 keep["invstd"].data_ptr(), ws.data_ptr(), ctx.stream,
+                 tag=("vinet_bn_bwd_reduce | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
+                 work=dict(flops=0.0, bytes=2 * nb))
         c1, c2 = ctx.f32(Ny), ctx.f32(Ny)
         dg = _param_grad(bn.gamma) if bn.gamma is not None and bn.gamma.requires_grad else None
         db = _param_grad(bn.beta) if bn.beta is not None and bn.beta.requires_grad else None
         ctx.call("vinet_bn_bwd_finalize", ws.data_ptr(), rows, Ny, float(M), res.scale.data_ptr(), 1 if train_bn else 0,
                  _ptr(dg), _ptr(db), keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), ctx.stream)
         ctx.call("vinet_bn_bwd_apply", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
-                 keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), C.byref(dz.ct()), ctx.stream)
+                 keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), C.byref(dz.ct()), ctx.stream,
+                 tag=("vinet_bn_bwd_apply | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
+                 work=dict(flops=0.0, bytes=3 * nb))
         dy = dz
     elif act != L.ACT_NONE:
         if dz.dt == ctx.dt:
