@@ -244,7 +244,8 @@ int vinet_upsample2x_bwd(const VinetTensor* dy, const VinetTensor* dx, int32_t d
 
 /* ------------------------------------------------------------------------
  * Losses (loss.py:13-99): per-sample reductions in fp64, maps fp32 (or fp64
- * ground truth).  `which`: 0 kldiv, 1 cc, 2 similarity.
+ * ground truth).  `which`: 0 kldiv, 1 cc, 2 similarity, 3 nss (loss.py:101-120, the
+ * validation metric; forward only, vinet_loss_bwd rejects it).
  *  fwd: per_sample[b] and the batch mean in *loss (fp32, device);
  *       `saved` (fp64 [B][8]) keeps the per-sample reductions for backward.
  *  bwd: ds[b,i] (+)= gscale * dloss/ds.

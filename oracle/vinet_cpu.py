@@ -338,6 +338,16 @@ def cc(s_map, gt):
     return torch.mean(ab / torch.sqrt(aa * bb))
 
 
+def nss(s_map, gt):
+    """loss.py:101-120, equal-size branch (the size-mismatch branch is a cv2.resize on the host)."""
+    assert s_map.size() == gt.size()
+    b = s_map.size(0)
+    a = s_map.reshape(b, -1)
+    g = gt.reshape(b, -1)
+    z = (a - a.mean(1, keepdim=True)) / (a.std(1, keepdim=True) + 2.2204e-16)
+    return torch.mean((z * g).sum(1) / g.sum(1))
+
+
 def get_loss(pred_map, gt, args):
     """utils.py:9-20 without the CUDA-only zero tensor."""
     loss = torch.zeros(1, dtype=torch.float32, device=pred_map.device)

@@ -477,6 +477,9 @@ class AbiEmulator:
             a = (s - s.mean(1, keepdim=True)) / s.std(1, keepdim=True)
             b = (g - g.mean(1, keepdim=True)) / g.std(1, keepdim=True)
             return (a * b).sum(1) / torch.sqrt((a * a).sum(1) * (b * b).sum(1))
+        if which == 3:
+            z = (s - s.mean(1, keepdim=True)) / (s.std(1, keepdim=True) + eps)
+            return (z * g).sum(1) / g.sum(1)
         ns = (s - s.min(1, keepdim=True)[0]) / (s.max(1, keepdim=True)[0] - s.min(1, keepdim=True)[0])
         ng = (g - g.min(1, keepdim=True)[0]) / (g.max(1, keepdim=True)[0] - g.min(1, keepdim=True)[0])
         return torch.min(ns / ns.sum(1, keepdim=True), ng / ng.sum(1, keepdim=True)).sum(1)

@@ -250,6 +250,11 @@ def loss_case(RL, seed, out):
         # float64 ground truth as on the DIEM path
         v64 = RL.kldiv(s, g.double())
         res["%s_kldiv_gt64" % tag] = _np(v64)
+        # nss (loss.py:101-120, equal-size branch) against a binary fixation mask
+        fix = (g > 0.5 * g.amax(dim=(1, 2), keepdim=True)).float()
+        n_r, n_o = RL.nss(s, fix), O.nss(s, fix)
+        _check("loss/%s/nss" % tag, n_r, n_o, meta)
+        res["%s_nss" % tag] = _np(n_r)
     res["meta"] = np.array(json.dumps(dict(meta, seed=seed)))
     np.savez_compressed(os.path.join(out, "loss.npz"), **res)
     print("loss ok", {k: float(v) for k, v in res.items() if k.startswith("full_") and v.ndim == 0})
@@ -356,6 +361,9 @@ def main():
     torch.set_num_threads(os.cpu_count())
     RM, RU, RL = _import_reference()
     out = HERE
+    if sys.argv[1:] == ["loss"]:        # regenerate one fixture
+        loss_case(RL, 3, out)
+        return
     block_case("basic_16_32", lambda: RU.BasicConv3d(16, 32, 1, 1), lambda: O.BasicConv3d(16, 32, 1, 1), (2, 16, 4, 6, 8), 11, out)
     block_case("sep_16_32_k3", lambda: RU.SepConv3d(16, 32, 3, 1, 1), lambda: O.SepConv3d(16, 32, 3, 1, 1), (2, 16, 4, 6, 8), 12, out)
     block_case("sep_3_64_k7s2", lambda: RU.SepConv3d(3, 64, 7, 2, 3), lambda: O.SepConv3d(3, 64, 7, 2, 3), (1, 3, 8, 16, 24), 13, out)

@@ -106,6 +106,8 @@ def losses_case(dev, vtol=2e-6, gtol=1e-7):
         v64 = VL.kldiv(s, g.double())
         assert v64.dtype == torch.float64
         assert abs(float(v64) - float(z["%s_kldiv_gt64" % tag])) < 1e-6
+        fix = (g > 0.5 * g.amax(dim=(1, 2), keepdim=True)).float()
+        close(VL.nss(s, fix), z["%s_nss" % tag], 5e-6, "%s nss" % tag)
 
 
 def decoder8_case(dev, ftol=2e-5, gtol=3e-4):

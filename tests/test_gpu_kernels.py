@@ -645,6 +645,22 @@ def test_losses(which, g64):
     assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, "loss bwd %g vs scale %g" % (float((a - b).abs().max()), float(b.abs().max()))
 
 
+@pytest.mark.parametrize("g64", [0, 1])
+def test_nss_forward(g64):
+    B, H, W = 3, 40, 56
+    s = Pair(synth.uniform("ns", (B, H, W), 1, 0.01, 0.99))
+    g = synth.gt_map(B, H, W, 2)
+    g = (g > 0.5 * g.amax(dim=(1, 2), keepdim=True)).float()
+    g = Pair(g.double() if g64 else g)
+    saved = Pair(torch.zeros(B * 8, dtype=torch.float64))
+    out = Pair(torch.zeros(1))
+    run_both("vinet_loss_fwd", lambda sd: [3, s.ptr(sd), g.ptr(sd), g64, B, H * W, saved.ptr(sd), out.ptr(sd), _stream() if sd == "gpu" else 0])
+    _cmp(out.get("gpu"), out.get("cpu"), 1e-6, "nss")
+    lib = _lib()
+    ds = torch.zeros(B * H * W, device=_dev())
+    assert lib.vinet_loss_bwd(3, s.gpu.data_ptr(), g.gpu.data_ptr(), g64, B, H * W, saved.gpu.data_ptr(), None, 1.0, 0, ds.data_ptr(), _stream()) != 0
+
+
 def test_adam_and_fill():
     n = 10007
     n4 = (n + 3) // 4 * 4

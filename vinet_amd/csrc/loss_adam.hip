@@ -55,6 +55,7 @@ VN_DEV double block_max_d(double v, double* sh) {
 //  kldiv: S_s, S_g, loss_b
 //  cc:    mu_s, mu_g, Sxx, Syy, Sxy, r
 //  sim:   lo_s, D_s, lo_g, D_g, argmin_s, loss_b
+//  nss:   mu_s, std_s (unbiased), sum((s-mu)/(std+eps)*g), sum(g), -, nss_b      (loss.py:101-120, forward only)
 template <bool G64>
 __global__ __launch_bounds__(1024) void loss_fwd_kernel(int which, const float* __restrict__ s, const void* gt, int n,
                                                         double* __restrict__ saved) {
@@ -86,6 +87,17 @@ __global__ __launch_bounds__(1024) void loss_fwd_kernel(int which, const float* 
     }
     xx = block_sum_d(xx, sh); yy = block_sum_d(yy, sh); xy = block_sum_d(xy, sh);
     if (threadIdx.x == 0) { sv[0] = ms; sv[1] = mg; sv[2] = xx; sv[3] = yy; sv[4] = xy; sv[5] = xy / sqrt(xx * yy); }
+  } else if (which == 3) {
+    double a = 0, c = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { a += (double)sp[i]; c += ldg<G64>(gt, gb + i); }
+    const double ms = block_sum_d(a, sh) / n, cnt = block_sum_d(c, sh);
+    double xx = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const double x = (double)sp[i] - ms; xx += x * x; }
+    const double sd = sqrt(block_sum_d(xx, sh) / (n - 1));     // torch.std: unbiased
+    double l = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) l += ((double)sp[i] - ms) / (sd + LOSS_EPS) * ldg<G64>(gt, gb + i);
+    l = block_sum_d(l, sh);
+    if (threadIdx.x == 0) { sv[0] = ms; sv[1] = sd; sv[2] = l; sv[3] = cnt; sv[5] = l / cnt; }
   } else {
     double mn = INFINITY, mg = INFINITY;
     int mi = 0x7fffffff;
@@ -118,7 +130,7 @@ __global__ void loss_mean_kernel(int which, const double* saved, int B, float* l
 
 extern "C" int vinet_loss_fwd(int32_t which, const float* s, const void* gt, int32_t gt_is_f64, int32_t B, int32_t n,
                               double* saved, float* loss, void* stream) {
-  VN_CHECK_ARG(which >= 0 && which <= 2 && s && gt && saved && loss && B > 0 && n > 0, "loss_fwd: bad arguments");
+  VN_CHECK_ARG(which >= 0 && which <= 3 && s && gt && saved && loss && B > 0 && n > 0, "loss_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (gt_is_f64) hipLaunchKernelGGL(loss_fwd_kernel<true>, dim3(B), dim3(1024), 0, st, which, s, gt, n, saved);
   else hipLaunchKernelGGL(loss_fwd_kernel<false>, dim3(B), dim3(1024), 0, st, which, s, gt, n, saved);

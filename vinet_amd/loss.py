@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 from . import engine as E
 
-_WHICH = {"kldiv": 0, "cc": 1, "similarity": 2}
+_WHICH = {"kldiv": 0, "cc": 1, "similarity": 2, "nss": 3}
 
 
 class _LossFn(torch.autograd.Function):
@@ -64,3 +64,24 @@ def cc(s_map, gt):
 def similarity(s_map, gt):
     """loss.py:52-78 (with normalize_map, loss.py:41-50)."""
     return _LossFn.apply(s_map, gt, 2)
+
+
+@torch.no_grad()
+def nss(s_map, gt):
+    """loss.py:101-120 for maps of equal size (the reference `cv2.resize`s s_map to gt's size first when they
+    differ, which is host post-processing): z-score of the saliency map with the unbiased
+    std (+2.2204e-16), mean over the fixation mask; batch mean.  A validation metric: no gradient."""
+    assert s_map.size() == gt.size(), "nss: resize the saliency map to the fixation map first"
+    assert s_map.dim() == 3, "expected [B,H,W] maps"
+    s = s_map.detach().float().contiguous()
+    g = gt.detach()
+    if g.dtype not in (torch.float32, torch.float64):
+        g = g.float()
+    g = g.contiguous()
+    B, n = s.shape[0], s.shape[1] * s.shape[2]
+    lib = L.get()
+    saved = torch.empty(B * 8, dtype=torch.float64, device=s.device)
+    out = torch.empty((), dtype=torch.float32, device=s.device)
+    L.check(lib.vinet_loss_fwd(3, s.data_ptr(), g.data_ptr(), 1 if g.dtype == torch.float64 else 0, B, n,
+                               saved.data_ptr(), out.data_ptr(), E._stream_for(s.device)), "vinet_loss_fwd")
+    return out.double() if g.dtype == torch.float64 else out
