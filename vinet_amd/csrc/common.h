@@ -148,6 +148,32 @@ VN_DEV void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
 // wait states between a VALU write of an MFMA A/B operand and the MFMA that reads it
 VN_DEV void valu_to_mfma_pad() { asm volatile("s_nop 1"); }
 
+// relu(x*s + h) on a packed bf16 pair in 5 VALU instructions (unpack 2, v_pk_fma_f32, v_cvt_pk_bf16_f32,
+// v_pk_max_i16 against 0) instead of 7 (two fma, two max): as signed 16-bit integers every negative bf16
+// (including -0 and a sign-bit NaN) is < 0, every non-negative one is >= 0 and ordered like its value.
+// Out-of-range activations of the PRE kernels are fetched from a page of 0xFFFF (NEGATIVE quiet NaN): the NaN
+// survives the fma and the conversion with its sign and the integer max turns it into +0 -- the same
+// "padding needs no mask" property the float max(NaN, 0) = 0 gave.  (-DVINET_PRE_FLOAT_MAX: the 7-instruction form.)
+typedef __attribute__((ext_vector_type(2))) float f32x2_v;
+VN_DEV uint32_t pre_relu_pair(uint32_t u, f32x2_v s, f32x2_v h) {
+#ifdef VINET_PRE_FLOAT_MAX
+  const float lo = fmaxf(fmaf(__uint_as_float(u << 16), s.x, h.x), 0.f);
+  const float hi = fmaxf(fmaf(__uint_as_float(u & 0xffff0000u), s.y, h.y), 0.f);
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+#else
+  f32x2_v x, y;
+  x.x = __uint_as_float(u << 16);
+  x.y = __uint_as_float(u & 0xffff0000u);
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(x), "v"(s), "v"(h));
+  uint32_t p, r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(y.x), "v"(y.y));
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(p));
+  return r;
+#endif
+}
+
 VN_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

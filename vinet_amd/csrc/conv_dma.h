@@ -25,8 +25,8 @@ __device__ __attribute__((aligned(64))) uint4 g_vinet_zero_page[4];
 // They are fetched from a page of bf16 quiet NaNs: fma(NaN,s,b) = NaN and
 // v_max_f32(NaN, 0) = 0 (IEEE maxNum), so padding needs no per-element mask.
 __device__ __attribute__((aligned(64))) uint4 g_vinet_nan_page[4] = {
-    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu},
-    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}};
+    {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu},
+    {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};
 
 VN_DEV uint32_t cvt_pk_bf16(float lo, float hi) {
   uint32_t r;
@@ -182,18 +182,14 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
       const float* sp = aff + cmp_c + (lane >> 4) * 8;
       const float4 s0 = *(const float4*)sp, s1 = *(const float4*)(sp + 4);
       const float4 h0 = *(const float4*)(sp + a.Kp), h1 = *(const float4*)(sp + a.Kp + 4);
-      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      const f32x2_v sc2[4] = {{s0.x, s0.y}, {s0.z, s0.w}, {s1.x, s1.y}, {s1.z, s1.w}};
+      const f32x2_v sh2[4] = {{h0.x, h0.y}, {h0.z, h0.w}, {h1.x, h1.y}, {h1.z, h1.w}};
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         union { bf16x8_v v; uint32_t u[4]; } q;
         q.v = af[i];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = fmaxf(fmaf(__uint_as_float(q.u[e] << 16), sc[2 * e], sh[2 * e]), 0.f);
-          const float hi = fmaxf(fmaf(__uint_as_float(q.u[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), 0.f);
-          q.u[e] = cvt_pk_bf16(lo, hi);
-        }
+        for (int e = 0; e < 4; ++e) q.u[e] = pre_relu_pair(q.u[e], sc2[e], sh2[e]);
         af[i] = q.v;
       }
       cmp_c += 32;

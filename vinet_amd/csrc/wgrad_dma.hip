@@ -28,8 +28,8 @@ extern int g_vinet_opt_tperm;
 // (device globals are per translation unit without -fgpu-rdc: own copies of the pad pages)
 __device__ __attribute__((aligned(64))) uint4 g_wg_zero_page[4];
 __device__ __attribute__((aligned(64))) uint4 g_wg_nan_page[4] = {
-    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu},
-    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}};
+    {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu},
+    {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};
 
 struct WgradDmaArgs {
   const char* x;
@@ -223,11 +223,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
           union { bf16x8_v v; uint32_t w[4]; } q;
           q.v = bf;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = fmaxf(fmaf(__uint_as_float(q.w[e] << 16), sc[j], sh[j]), 0.f);
-            const float hi = fmaxf(fmaf(__uint_as_float(q.w[e] & 0xffff0000u), sc[j], sh[j]), 0.f);
-            q.w[e] = wg_cvt_pk_bf16(lo, hi);
-          }
+          for (int e = 0; e < 4; ++e) q.w[e] = pre_relu_pair(q.w[e], (f32x2_v){sc[j], sc[j]}, (f32x2_v){sh[j], sh[j]});
           bf = q.v;
           valu_to_mfma_pad();
         }

@@ -25,8 +25,8 @@
 
 __device__ __attribute__((aligned(64))) uint4 g_wpp_zero_page[4];
 __device__ __attribute__((aligned(64))) uint4 g_wpp_nan_page[4] = {
-    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu},
-    {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}, {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu}};
+    {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu},
+    {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};
 
 struct WgradPPArgs {
   const char* x;
@@ -252,11 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(const WgradPPArgs
           union { bf16x8_v v; uint32_t w[4]; } q;
           q.v = bf[jj][s];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = fmaxf(fmaf(__uint_as_float(q.w[e] << 16), scl, sft), 0.f);
-            const float hi = fmaxf(fmaf(__uint_as_float(q.w[e] & 0xffff0000u), scl, sft), 0.f);
-            q.w[e] = wpp_cvt_pk_bf16(lo, hi);
-          }
+          for (int e = 0; e < 4; ++e) q.w[e] = pre_relu_pair(q.w[e], (f32x2_v){scl, scl}, (f32x2_v){sft, sft});
           bf[jj][s] = q.v;
         }
       }
