@@ -22,8 +22,9 @@
 
 __device__ __attribute__((aligned(64))) uint4 g_vinet_zero_page[4];
 // PRE variant: activations that are out of range must be zero AFTER relu(scale*x+shift).
-// They are fetched from a page of bf16 quiet NaNs: fma(NaN,s,b) = NaN and
-// v_max_f32(NaN, 0) = 0 (IEEE maxNum), so padding needs no per-element mask.
+// They are fetched from a page of 0xFFFF (NEGATIVE bf16 quiet NaN): the NaN keeps its sign through the fma and
+// the bf16 conversion, and pre_relu_pair's integer max (common.h) maps every sign-bit pattern to +0, so padding
+// needs no per-element mask.
 __device__ __attribute__((aligned(64))) uint4 g_vinet_nan_page[4] = {
     {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu},
     {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}};

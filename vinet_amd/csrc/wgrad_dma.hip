@@ -13,7 +13,7 @@
 //     chunk index is XOR-swizzled with the row so the K-major fragment reads
 //     (ds_read_b64_tr_b16, hardware transpose) do not serialise on banks;
 //   * out-of-range sources read a zero page (dY, plain X) or a NaN page (X
-//     with a pending BN+ReLU: max(fma(NaN,s,b),0) == 0), so every wave issues
+//     with a pending BN+ReLU: pre_relu_pair maps the sign-bit NaN to 0), so every wave issues
 //     exactly LPS DMAs per stage and the counted vmcnt wait is exact;
 //   * the pending affine is applied at fragment time: a B fragment holds 8
 //     voxels of ONE channel per lane, so scale/shift are two scalars per lane;
