@@ -199,11 +199,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8_v*)(Bs + j * 16 * 64);
+#ifndef VINET_PP_NO_MMA   // (tuning build: K loop without MFMAs)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         mfma_bf16_acc(acc[i][j], af[i], bfr[j]);
+#endif
   };
 
   // ---- pipeline ------------------------------------------------------------------
