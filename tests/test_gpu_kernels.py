@@ -324,6 +324,19 @@ def test_stem_folded(dt, hw):
 
     run_both("vinet_conv3d_wgrad", mkw)
     _cmp(dw.get("gpu"), dw.get("cpu"), 3e-5 if dt == E.F32 else 2e-2, "folded stem wgrad")
+    if dt == E.BF16:
+        # the 7-taps-per-group, 32-channel-tile kernel the real stem (22 M voxels) gets
+        lib = _lib()
+        lib.vinet_set_option(b"wgrad_tg", 7)
+        try:
+            dw.gpu.zero_()
+            dw.cpu.zero_()
+            run_both("vinet_conv3d_wgrad", mkw)
+            nbuf = C.create_string_buffer(128)
+            assert lib.vinet_conv3d_wgrad_kernel_name(mkw("gpu")[0], nbuf, 128) == 0 and nbuf.value == b"conv_wgrad_dma_kernel<64,32,7,plain>"
+        finally:
+            lib.vinet_set_option(b"wgrad_tg", 0)
+        _cmp(dw.get("gpu"), dw.get("cpu"), 2e-2, "folded stem wgrad (32-channel tile)")
 
 
 @pytest.mark.parametrize("dt", DTS)

@@ -72,16 +72,23 @@ template <int TN, int TC, int TG, int STAGES, bool PRE>
 struct WgCfg {
   static constexpr int KV = 32;
   static constexpr int D_BYTES = KV * TN * 2, X_BYTES = KV * TC * 2;
-  static constexpr int STAGE_BYTES = D_BYTES + TG * X_BYTES;
+  static constexpr int STAGE_BYTES = D_BYTES + TG * X_BYTES + (TC == 32 ? 1024 : 0);   // (+ dummy piece)
   static constexpr int D_IPW = (TN / 64);          // DMA instructions per wave for the dY tile (KV*TN*2/1024/4)
   static constexpr int X_IPW = (TC / 64);
-  static constexpr int LPS = D_IPW + TG * X_IPW;
+  // TC == 32 (the folded stem, Cin = 32): an X tile is 32 rows x 64 B = two wave-instructions; the TG*2 pieces of
+  // a stage are dealt round-robin to the four waves (pieces past the end are zero-page dummies into a scratch
+  // piece behind the stage) so that every wave still issues the same number of DMAs
+  static constexpr int X32_PPW = (TG * 2 + 3) / 4;
+  static constexpr int LPS = D_IPW + (TC == 32 ? X32_PPW : TG * X_IPW);
   static constexpr int SMEM = STAGES * STAGE_BYTES;
   static constexpr int MT = TN / 32, NT = TC / 32;  // 16x16 fragments per wave (2x2 waves)
 };
 
 // tile row r (0..31) of a [32][TW channels] bf16 tile, 16-byte chunk ch -> byte offset with swizzle
-template <int TW> VN_DEV int wg_swz(int r) { return TW == 64 ? (((r >> 1) & 1) << 1) : ((r & 3) << 1); }
+template <int TW> VN_DEV int wg_swz(int r) {
+  if (TW == 32) return ((r >> 3) & 1) << 1;   // 64-byte rows: rows r and r+8 share banks, move one to the other half
+  return TW == 64 ? (((r >> 1) & 1) << 1) : ((r & 3) << 1);
+}
 
 template <int TN, int TC, int TG, int STAGES, bool PRE>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs a) {
@@ -143,6 +150,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
                                        (__attribute__((address_space(3))) void*)(stage + q * 1024), 16, 0, 0);
     }
     // ---- X tiles, one per tap of the group ----
+    if constexpr (TC == 32) {
+#pragma unroll
+      for (int j = 0; j < Cfg::X32_PPW; ++j) {
+        const int pc = wave + 4 * j;                 // piece = (tap g, half q) of the stage
+        const int g = pc >> 1, q = pc & 1;
+        const bool pok = pc < TG * 2;
+        const int r = q * X_RPI + x_lr;
+        const int m = mbase + r;
+        const uint32_t t1 = fdiv((uint32_t)m, a.dW);
+        const int wo = m - (int)t1 * a.Wo;
+        const uint32_t t2 = fdiv(t1, a.dH);
+        const int ho = (int)t1 - (int)t2 * a.Ho;
+        const uint32_t b = fdiv(t2, a.dT);
+        const int to = (int)t2 - (int)b * a.To;
+        const int sch = x_ch ^ wg_swz<TC>(r);
+        const int c = c0 + sch * 8;
+        // taps of this piece: selected from the (scalar) group table by the wave-uniform g
+        int4 tg = tp[0];
+        bool tok = tap_ok[0];
+#pragma unroll
+        for (int k = 1; k < TG; ++k)
+          if (g == k) { tg = tp[k]; tok = tap_ok[k]; }
+        const int ti = to * a.sT + tg.x, hi = ho * a.sH + tg.y, wi = wo * a.sW + tg.z;
+        const unsigned ok = (unsigned)pok & (unsigned)live & (unsigned)(m < a.M) & (unsigned)(c < a.Cin) & (unsigned)tok &
+                            (unsigned)((unsigned)ti < (unsigned)a.Ti) & (unsigned)((unsigned)hi < (unsigned)a.Hi) &
+                            (unsigned)((unsigned)wi < (unsigned)a.Wi);
+        const char* p = a.x + ((long)b * a.sBx + c + ((long)(ti * a.Hi + hi) * a.Wi + wi) * (long)a.ldx) * 2;
+        const char* src = xpad + ((p - xpad) & -(long)ok);
+        char* dst = pok ? stage + Cfg::D_BYTES + g * Cfg::X_BYTES + q * 1024 : stage + Cfg::D_BYTES + TG * Cfg::X_BYTES;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < Cfg::X_IPW; ++j) {
       const int q = wave + 4 * j;
@@ -320,7 +360,8 @@ static const char* wg_pick(int N, int Cin, int ntaps, long M, int* tn, int* tg) 
 int vinet_wgrad_dma_name(const VinetWgradDesc* d, char* buf, int n) {
   int tn, tg;
   wg_pick(d->dy.C, d->x.C, d->ntaps, (long)d->dy.B * d->dy.T * d->dy.H * d->dy.W, &tn, &tg);
-  snprintf(buf, n, "conv_wgrad_dma_kernel<%d,%d,%d,%s>", tn, tn, tg, d->pre.scale ? "pre" : "plain");
+  const int tc = (d->x.C <= 32 && tn == 64 && tg == 7 && !d->pre.scale) ? 32 : tn;
+  snprintf(buf, n, "conv_wgrad_dma_kernel<%d,%d,%d,%s>", tn, tc, tg, d->pre.scale ? "pre" : "plain");
   return 0;
 }
 
@@ -345,6 +386,7 @@ int vinet_launch_wgrad_dma(const VinetWgradDesc* d, hipStream_t s) {
   int tn, tg;
   wg_pick(a.N, a.Cin, a.ntaps, a.M, &tn, &tg);
   const bool pre = d->pre.scale != nullptr;
+  if (a.Cin <= 32 && tn == 64 && tg == 7 && !pre) return launch_wg<64, 32, 7, 2, false>(a, s);   // the folded stem
 #define WG(TN_, TG_, ST_) \
   if (tn == TN_ && tg == TG_) return pre ? launch_wg<TN_, TN_, TG_, ST_, true>(a, s) : launch_wg<TN_, TN_, TG_, ST_, false>(a, s);
   WG(128, 1, 3) WG(64, 1, 3) WG(64, 2, 3) WG(64, 3, 3) WG(64, 7, 2) WG(64, 9, 2)
