@@ -151,32 +151,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
     }
     // ---- X tiles, one per tap of the group ----
     if constexpr (TC == 32) {
+      // piece pc = wave + 4j -> half q = pc & 1 = wave & 1 for every piece of this wave: one voxel decode per chunk
+      const int q = wave & 1;
+      const int r = q * X_RPI + x_lr;
+      const int m = mbase + r;
+      const uint32_t t1 = fdiv((uint32_t)m, a.dW);
+      const int wo = m - (int)t1 * a.Wo;
+      const uint32_t t2 = fdiv(t1, a.dH);
+      const int ho = (int)t1 - (int)t2 * a.Ho;
+      const uint32_t b = fdiv(t2, a.dT);
+      const int to = (int)t2 - (int)b * a.To;
+      const int sch = x_ch ^ wg_swz<TC>(r);
+      const int c = c0 + sch * 8;
+      const unsigned rowok = (unsigned)live & (unsigned)(m < a.M) & (unsigned)(c < a.Cin);
+      const long base = (long)b * a.sBx + c;
+      const int t0 = to * a.sT, h0 = ho * a.sH, w0 = wo * a.sW;
 #pragma unroll
       for (int j = 0; j < Cfg::X32_PPW; ++j) {
-        const int pc = wave + 4 * j;                 // piece = (tap g, half q) of the stage
-        const int g = pc >> 1, q = pc & 1;
-        const bool pok = pc < TG * 2;
-        const int r = q * X_RPI + x_lr;
-        const int m = mbase + r;
-        const uint32_t t1 = fdiv((uint32_t)m, a.dW);
-        const int wo = m - (int)t1 * a.Wo;
-        const uint32_t t2 = fdiv(t1, a.dH);
-        const int ho = (int)t1 - (int)t2 * a.Ho;
-        const uint32_t b = fdiv(t2, a.dT);
-        const int to = (int)t2 - (int)b * a.To;
-        const int sch = x_ch ^ wg_swz<TC>(r);
-        const int c = c0 + sch * 8;
-        // taps of this piece: selected from the (scalar) group table by the wave-uniform g
+        const int g = (wave >> 1) + 2 * j;           // tap of piece wave + 4j
+        const bool pok = g < TG;
         int4 tg = tp[0];
         bool tok = tap_ok[0];
 #pragma unroll
         for (int k = 1; k < TG; ++k)
           if (g == k) { tg = tp[k]; tok = tap_ok[k]; }
-        const int ti = to * a.sT + tg.x, hi = ho * a.sH + tg.y, wi = wo * a.sW + tg.z;
-        const unsigned ok = (unsigned)pok & (unsigned)live & (unsigned)(m < a.M) & (unsigned)(c < a.Cin) & (unsigned)tok &
-                            (unsigned)((unsigned)ti < (unsigned)a.Ti) & (unsigned)((unsigned)hi < (unsigned)a.Hi) &
-                            (unsigned)((unsigned)wi < (unsigned)a.Wi);
-        const char* p = a.x + ((long)b * a.sBx + c + ((long)(ti * a.Hi + hi) * a.Wi + wi) * (long)a.ldx) * 2;
+        const int ti = t0 + tg.x, hi = h0 + tg.y, wi = w0 + tg.z;
+        const unsigned ok = rowok & (unsigned)pok & (unsigned)tok & (unsigned)((unsigned)ti < (unsigned)a.Ti) &
+                            (unsigned)((unsigned)hi < (unsigned)a.Hi) & (unsigned)((unsigned)wi < (unsigned)a.Wi);
+        const char* p = a.x + (base + ((long)(ti * a.Hi + hi) * a.Wi + wi) * (long)a.ldx) * 2;
         const char* src = xpad + ((p - xpad) & -(long)ok);
         char* dst = pok ? stage + Cfg::D_BYTES + g * Cfg::X_BYTES + q * 1024 : stage + Cfg::D_BYTES + TG * Cfg::X_BYTES;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -386,7 +388,8 @@ int vinet_launch_wgrad_dma(const VinetWgradDesc* d, hipStream_t s) {
   int tn, tg;
   wg_pick(a.N, a.Cin, a.ntaps, a.M, &tn, &tg);
   const bool pre = d->pre.scale != nullptr;
-  if (a.Cin <= 32 && tn == 64 && tg == 7 && !pre) return launch_wg<64, 32, 7, 2, false>(a, s);   // the folded stem
+  if (a.Cin <= 32 && tn == 64 && tg == 7 && !pre) return launch_wg<64, 32, 7, 2, false>(a, s);   // the folded stem (4 stages / 2 workgroups per CU measured 1.7x slower:
+                                                                                                   // the kernel is bound by its address VALU, more resident waves win)
 #define WG(TN_, TG_, ST_) \
   if (tn == TN_ && tg == TG_) return pre ? launch_wg<TN_, TN_, TG_, ST_, true>(a, s) : launch_wg<TN_, TN_, TG_, ST_, false>(a, s);
   WG(128, 1, 3) WG(64, 1, 3) WG(64, 2, 3) WG(64, 3, 3) WG(64, 7, 2) WG(64, 9, 2)
