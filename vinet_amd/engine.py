@@ -37,6 +37,7 @@ _DEFAULT_DTYPE = BF16
 _WEIGHTS_EPOCH = 0
 # Weight gradients are off the backward critical path (only the optimizer consumes them):
 # they run on a second HIP stream, concurrently with the dgrad / BN-backward chain.
+ROW_ALIGN = int(os.environ.get("VINET_ROW_ALIGN", "0"))      # bytes; 0 = dense rows.  128 measured neutral on the whole step
 STEM_FOLD = os.environ.get("VINET_STEM_FOLD", "1") != "0"   # padded/folded stem input (A/B switch)
 WGRAD_SIDE_STREAM = True
 _SIDE_STREAMS = {}
@@ -114,9 +115,15 @@ class View:
 
     @staticmethod
     def alloc(B, T, H, W, Cc, dt, device, zero=False):
-        n = B * T * H * W * Cc
+        # Optional (VINET_ROW_ALIGN=128): voxel rows start on 128-byte lines.  The microbenchmark
+        # (tools/ubench/l2_to_lds) moves 8 rows x 128 B per LDS-DMA at 33 B/clk/CU from 960-byte rows (480 channels)
+        # against 55-65 from line-aligned rows, but no layer of the real step got faster: left off.
+        ld = Cc
+        if ROW_ALIGN and Cc * ESIZE[dt] > ROW_ALIGN and (Cc * ESIZE[dt]) % ROW_ALIGN:
+            ld = rup(Cc * ESIZE[dt], ROW_ALIGN) // ESIZE[dt]
+        n = B * T * H * W * ld
         buf = (torch.zeros if zero else torch.empty)(n, dtype=TORCH_DT[dt], device=device)
-        return View(buf, 0, B, T, H, W, Cc, Cc, T * H * W * Cc, dt)
+        return View(buf, 0, B, T, H, W, Cc, ld, T * H * W * ld, dt)
 
     @property
     def device(self):
@@ -800,8 +807,6 @@ def maxpool_forward(ctx, x, k, s, p, dst=None):
     if rec:
         def bwd():
             dy = dst.grad_view()
-            if dy.ld != dy.C or dy.sB != dy.T * dy.H * dy.W * dy.C:
-                raise RuntimeError("maxpool backward expects a dense output gradient")
             dx = x.grad_view()
             ctx.call("vinet_maxpool3d_bwd", C.byref(pd), C.byref(dy.ct()), am.data_ptr(), C.byref(dx.ct()),
                      1 if x.is_grad_ready() else 0, ctx.stream, tag="maxpool_bwd_kernel | " + ptag,
