@@ -90,6 +90,43 @@ def test_train_step_with_torch_adam_gives_same_update():
     assert not torch.equal(before, m.conv.weight.detach())
 
 
+def test_eval_fold_cache_follows_parameter_and_statistics_changes():
+    """eval-mode BN folds are cached per module; they must be recomputed after load_state_dict, after a
+    training-mode forward (running statistics move) and after an optimizer step, and reused otherwise"""
+    from vinet_amd import model_utils as MU
+    from vinet_amd import optim as VO
+    m = MU.BasicConv3d(16, 32, 1, 1)
+    o = O.BasicConv3d(16, 32, 1, 1)
+    sd = synth.synth_state_dict(o.state_dict(), 5)
+    m.load_state_dict(sd)
+    o.load_state_dict(sd)
+    x = synth.normal("fc", (2, 16, 2, 4, 4), 1)
+
+    def check(what):
+        m.eval()
+        o.eval()
+        with torch.no_grad():
+            MC.close(m(x), o(x), 1e-5, what)
+
+    check("initial")
+    check("cached")
+    sd2 = synth.synth_state_dict(o.state_dict(), 6)
+    m.load_state_dict(sd2)
+    o.load_state_dict(sd2)
+    check("after load_state_dict")
+    for mod in (m, o):                       # a training-mode forward moves the running statistics
+        mod.train()
+        mod(x * 3 + 1)
+    check("after a training forward")
+    m.train()
+    opt = VO.Adam(m.parameters(), lr=1e-2)
+    opt.zero_grad()
+    m(x).sum().backward()
+    opt.step()
+    o.load_state_dict(m.state_dict())
+    check("after an optimizer step")
+
+
 def test_product_path_refuses_cpu_without_library_double():
     """no CPU fallback: without the test double a CPU tensor must raise"""
     from vinet_amd import model_utils as MU
