@@ -786,3 +786,12 @@ def test_pingpong_kernels_race_screen():
                 assert d <= 5e-3 * scale, "wgrad_pp tile %d, launch %d: max diff %g (scale %g)" % (shape, it, d, scale)
     finally:
         lib.vinet_set_option(b"wgrad_pp", 1)
+
+
+def test_pingpong_kernels_random_shapes():
+    """a seeded slice of tools/fuzz_pp.py: random geometry forced through conv_pp / conv_wgrad_pp vs the ABI model"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pp.py"), "16", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
