@@ -3,6 +3,7 @@ model of the same contract (tests/abi_emulator.py), on identical descriptors and
 seeded inputs.  fp32 must agree to fp32 round-off; bf16 to bf16 round-off."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
