@@ -41,23 +41,25 @@ def loss_func(pred_map, gt, args):
     return get_loss(pred_map, gt, args)
 
 
-class AverageMeter(object):
-    """utils.py:41-59."""
+class AverageMeter:
+    """Running mean of a logged quantity; same public surface as the reference's meter
+    (utils.py:41-59: attributes val / sum / count / avg, methods reset() and update(val, n=1))."""
+
+    __slots__ = ("val", "sum", "count")
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.val = 0
-        self.avg = 0
-        self.sum = 0
-        self.count = 0
+        self.val, self.sum, self.count = 0, 0, 0
+
+    @property
+    def avg(self):
+        return self.sum / self.count if self.count else 0
 
     def update(self, val, n=1):
         self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count
+        self.sum, self.count = self.sum + val * n, self.count + n
 
 
 def num_params(model):
