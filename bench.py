@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
+    ap.add_argument("--model", choices=["vinet", "avinet"], default="vinet",
+                    help="avinet = BASELINE config 4: VideoAudioSaliencyModel with the SoundNet branch + bilinear fusion (32x224x384 only)")
     ap.add_argument("--clip", type=int, default=32)
     ap.add_argument("--height", type=int, default=224)
     ap.add_argument("--width", type=int, default=384)
@@ -83,24 +85,26 @@ def cpu_baseline(args):
     from vinet_amd import synth
     cores = min(host_cores(), 64)   # oneDNN stops scaling (and starts thrashing) far below 256 SMT threads
     torch.set_num_threads(cores)
-    m = O.VideoSaliencyModel(num_clips=args.clip)
+    av = args.model == "avinet"
+    m = (O.VideoAudioSaliencyModel if av else O.VideoSaliencyModel)(num_clips=args.clip)
     m.load_state_dict(synth.synth_state_dict(m.state_dict(), 0))
     x = synth.clip(1, args.clip, args.height, args.width, 0).permute(0, 2, 1, 3, 4)
     gt = synth.gt_map(1, args.height, args.width, 0)
+    inputs = (x, synth.audio(1, 70560, 0)) if av else (x,)
     if args.mode == "train":
         m.train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 
         def step():
             opt.zero_grad()
-            O.kldiv(m(x), gt).backward()
+            O.kldiv(m(*inputs), gt).backward()
             opt.step()
     else:
         m.eval()
 
         def step():
             with torch.no_grad():
-                m(x)
+                m(*inputs)
     t0 = time.perf_counter()
     step()  # warm-up (oneDNN primitive creation)
     warm = time.perf_counter() - t0
@@ -127,7 +131,9 @@ def main():
     engine.WGRAD_SIDE_STREAM = not args.no_side_stream
 
     B = args.batch
-    m = model.VideoSaliencyModel(num_clips=args.clip)
+    av = args.model == "avinet"
+    assert not av or (args.clip, args.height, args.width) == (32, 224, 384), "AViNet's bilinear fusion fixes the clip shape"
+    m = (model.VideoAudioSaliencyModel if av else model.VideoSaliencyModel)(num_clips=args.clip)
     m.load_state_dict(synth.synth_state_dict(m.state_dict(), 0))
     m = m.to(dev)
     # synthetic clip as the loaders hand it over: [B,T,3,H,W], permuted like train.py:205
@@ -135,6 +141,7 @@ def main():
     g.manual_seed(1234 + rank)
     x = torch.randn((B, args.clip, 3, args.height, args.width), generator=g, device=dev).permute(0, 2, 1, 3, 4)
     gt = synth.gt_map(B, args.height, args.width, rank).to(dev)
+    inputs = (x, synth.audio(B, 70560, rank).to(dev)) if av else (x,)
 
     if args.mode == "train":
         m.train()
@@ -143,7 +150,7 @@ def main():
 
         def step():
             opt.zero_grad()
-            l = loss.kldiv(m(x), gt)
+            l = loss.kldiv(m(*inputs), gt)
             l.backward()
             parallel.allreduce_gradients(opt)
             opt.step()
@@ -160,7 +167,7 @@ def main():
         else:
             def step():
                 with torch.no_grad():
-                    return m(x)
+                    return m(*inputs)
 
     def sync():
         torch.cuda.synchronize()
@@ -265,7 +272,7 @@ def main():
             "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "ViNet DHF1K %s, %dx%dx%d %s, %d clip(s)/GPU/step, kldiv + fused Adam, %s"
+            "config": {"workload": ("AViNet (SoundNet + bilinear fusion)" if av else "ViNet DHF1K") + " %s, %dx%dx%d %s, %d clip(s)/GPU/step, kldiv + fused Adam, %s"
                                    % ("training" if args.mode == "train" else "inference", args.clip, args.height,
                                       args.width, args.dtype, B,
                                       "1xMI355X" if world == 1 else "%dxMI355X RCCL all-reduce" % world),
