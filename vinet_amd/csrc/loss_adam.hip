@@ -258,24 +258,37 @@ extern "C" int vinet_adam_step(float* p, const float* g, float* m, float* v, int
 #define BIL_MAX_I 48
 #define BIL_MAX_J 4
 
+// lane <-> channel c (C is the fastest axis of x1 / x2 / out: every access is a coalesced row); the I + J inputs of
+// the lane's channel live in registers (fully unrolled, predicated loops: runtime-indexed arrays would go to
+// scratch), the weights are wave-uniform (scalar loads), blockIdx.z splits the O outputs.
 template <typename T>
-__global__ void bilinear_fwd_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const float* __restrict__ w,
-                                    const float* __restrict__ bias, int C, int I, int J, int O, T* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void bilinear_fwd_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, int C, int I, int J, int O, int o_per, T* __restrict__ out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
   const int b = blockIdx.y;
-  if (c >= C) return;
+  const bool ok = c < C;
+  const int cc = ok ? c : 0;
   float a[BIL_MAX_I], d[BIL_MAX_J];
-  for (int i = 0; i < I; ++i) a[i] = load1<T>(x1 + ((long)b * I + i) * C + c);
-  for (int j = 0; j < J; ++j) d[j] = load1<T>(x2 + ((long)b * J + j) * C + c);
-  for (int o = 0; o < O; ++o) {
+#pragma unroll
+  for (int i = 0; i < BIL_MAX_I; ++i) a[i] = i < I ? load1<T>(x1 + ((long)b * I + i) * C + cc) : 0.f;
+#pragma unroll
+  for (int j = 0; j < BIL_MAX_J; ++j) d[j] = j < J ? load1<T>(x2 + ((long)b * J + j) * C + cc) : 0.f;
+  const int o0 = blockIdx.z * o_per;
+  const int o1 = o0 + o_per < O ? o0 + o_per : O;
+  for (int o = o0; o < o1; ++o) {
     const float* wo = w + (long)o * I * J;
     float acc = bias ? bias[o] : 0.f;
-    for (int i = 0; i < I; ++i) {
-      float t = 0.f;
-      for (int j = 0; j < J; ++j) t = fmaf(wo[i * J + j], d[j], t);
-      acc = fmaf(a[i], t, acc);
+#pragma unroll
+    for (int i = 0; i < BIL_MAX_I; ++i) {
+      if (i < I) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < BIL_MAX_J; ++j)
+          if (j < J) t = fmaf(wo[i * J + j], d[j], t);
+        acc = fmaf(a[i], t, acc);
+      }
     }
-    store1<T>(out + ((long)b * O + o) * C + c, acc);
+    if (ok) store1<T>(out + ((long)b * O + o) * C + c, acc);
   }
 }
 
@@ -283,59 +296,142 @@ extern "C" int vinet_bilinear_fwd(const void* x1, const void* x2, int32_t dtype,
                                   int32_t B, int32_t C, int32_t I, int32_t J, int32_t O, void* out, void* stream) {
   VN_CHECK_ARG(x1 && x2 && w && out && B > 0 && C > 0 && I > 0 && I <= BIL_MAX_I && J > 0 && J <= BIL_MAX_J && O > 0,
                "bilinear_fwd: bad arguments");
-  const dim3 grid((C + 63) / 64, B), blk(64);
-  if (dtype == VINET_F32) hipLaunchKernelGGL(bilinear_fwd_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)x1, (const float*)x2, w, bias, C, I, J, O, (float*)out);
-  else hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const bf16_t*)x1, (const bf16_t*)x2, w, bias, C, I, J, O, (bf16_t*)out);
+  const int o_per = 16;
+  const dim3 grid((C + 63) / 64, B, (O + o_per - 1) / o_per), blk(64);
+  if (dtype == VINET_F32) hipLaunchKernelGGL(bilinear_fwd_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)x1, (const float*)x2, w, bias, C, I, J, O, o_per, (float*)out);
+  else hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const bf16_t*)x1, (const bf16_t*)x2, w, bias, C, I, J, O, o_per, (bf16_t*)out);
   return vn_launch_status("bilinear_fwd");
 }
 
+// dx1[b,i,c] = sum_{o,j} dout[b,o,c] w[o,i,j] x2[b,j,c];  dx2[b,j,c] = sum_{o,i} dout[b,o,c] w[o,i,j] x1[b,i,c].
+// One workgroup per (b, 64-channel tile): lane <-> channel, the four waves split the I inputs (register
+// accumulators, fully unrolled), weights go through LDS 16 outputs at a time (wave-uniform broadcast reads), the
+// dx2 partial sums of the four waves meet in LDS at the end.
+#define BILX_IPW ((BIL_MAX_I + 3) / 4)
 template <typename T>
-__global__ void bilinear_bwd_x_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const T* __restrict__ dout,
-                                      const float* __restrict__ w, int C, int I, int J, int O, T* __restrict__ dx1,
-                                      T* __restrict__ dx2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bilinear_bwd_x_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const T* __restrict__ dout,
+                                                             const float* __restrict__ w, int C, int I, int J, int O, T* __restrict__ dx1,
+                                                             T* __restrict__ dx2) {
+  __shared__ float Ws[16][BIL_MAX_I * BIL_MAX_J];
+  __shared__ float Gd[4][BIL_MAX_J][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.x * 64 + lane;
   const int b = blockIdx.y;
-  if (c >= C) return;
-  float a[BIL_MAX_I], d[BIL_MAX_J], ga[BIL_MAX_I], gd[BIL_MAX_J];
-  for (int i = 0; i < I; ++i) { a[i] = load1<T>(x1 + ((long)b * I + i) * C + c); ga[i] = 0.f; }
-  for (int j = 0; j < J; ++j) { d[j] = load1<T>(x2 + ((long)b * J + j) * C + c); gd[j] = 0.f; }
-  for (int o = 0; o < O; ++o) {
-    const float g = load1<T>(dout + ((long)b * O + o) * C + c);
-    const float* wo = w + (long)o * I * J;
-    for (int i = 0; i < I; ++i)
-      for (int j = 0; j < J; ++j) {
-        const float wv = wo[i * J + j] * g;
-        ga[i] = fmaf(wv, d[j], ga[i]);
-        gd[j] = fmaf(wv, a[i], gd[j]);
+  const bool ok = c < C;
+  const int cc = ok ? c : 0;
+  const int ipw = (I + 3) / 4, i0 = wave * ipw;
+  const int IJ = I * J;
+  float a[BILX_IPW], ga[BILX_IPW], d[BIL_MAX_J], gd[BIL_MAX_J];
+#pragma unroll
+  for (int k = 0; k < BILX_IPW; ++k) { a[k] = (k < ipw && i0 + k < I) ? load1<T>(x1 + ((long)b * I + i0 + k) * C + cc) : 0.f; ga[k] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < BIL_MAX_J; ++j) { d[j] = j < J ? load1<T>(x2 + ((long)b * J + j) * C + cc) : 0.f; gd[j] = 0.f; }
+  for (int o0 = 0; o0 < O; o0 += 16) {
+    __syncthreads();
+    for (int e = tid; e < 16 * IJ; e += 256) {
+      const int ol = e / IJ, ij = e - ol * IJ;
+      Ws[ol][ij] = o0 + ol < O ? w[(long)(o0 + ol) * IJ + ij] : 0.f;
+    }
+    __syncthreads();
+    for (int ol = 0; ol < 16 && o0 + ol < O; ++ol) {
+      const float g = load1<T>(dout + ((long)b * O + o0 + ol) * C + cc);
+      const float* wo = &Ws[ol][i0 * J];
+#pragma unroll
+      for (int k = 0; k < BILX_IPW; ++k) {
+        if (k < ipw && i0 + k < I) {
+#pragma unroll
+          for (int j = 0; j < BIL_MAX_J; ++j)
+            if (j < J) {
+              const float wv = wo[k * J + j] * g;
+              ga[k] = fmaf(wv, d[j], ga[k]);
+              gd[j] = fmaf(wv, a[k], gd[j]);
+            }
+        }
       }
+    }
   }
-  if (dx1) for (int i = 0; i < I; ++i) store1<T>(dx1 + ((long)b * I + i) * C + c, ga[i]);
-  if (dx2) for (int j = 0; j < J; ++j) store1<T>(dx2 + ((long)b * J + j) * C + c, gd[j]);
+  if (dx1 && ok) {
+#pragma unroll
+    for (int k = 0; k < BILX_IPW; ++k)
+      if (k < ipw && i0 + k < I) store1<T>(dx1 + ((long)b * I + i0 + k) * C + c, ga[k]);
+  }
+  if (dx2) {
+#pragma unroll
+    for (int j = 0; j < BIL_MAX_J; ++j) Gd[wave][j][lane] = gd[j];
+    __syncthreads();
+    if (wave == 0 && ok) {
+#pragma unroll
+      for (int j = 0; j < BIL_MAX_J; ++j)
+        if (j < J) store1<T>(dx2 + ((long)b * J + j) * C + c, Gd[0][j][lane] + Gd[1][j][lane] + Gd[2][j][lane] + Gd[3][j][lane]);
+    }
+  }
 }
 
-// dw[o][i][j] = sum_{b,c} dout[b,o,c] x1[b,i,c] x2[b,j,c];  dbias[o] = sum dout
+// dw[o][i][j] += sum_{b,c} dout[b,o,c] x1[b,i,c] x2[b,j,c];  dbias[o] += sum dout.
+// A workgroup owns 16 outputs o x all (i,j) (+ one bias column) and walks a strided share of the (b, 64-channel
+// tile) pairs: the x1 / x2 / dout tiles of a pair are staged in LDS as fp32, every lane keeps its 8 (o, ij)
+// accumulators in registers and sweeps the 64 channels starting at a lane-dependent offset (all three arrays are
+// [row][64]: a common c would put the whole wave on one bank).  One atomicAdd per (o, ij) and workgroup at the end;
+// the per-(o,ij)-block version read every input 127 x 336 times from global memory (6 ms of AViNet's step).
+#define BILW_OT 16
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_bwd_w_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
                                                              const T* __restrict__ dout, int B, int C, int I, int J,
                                                              int O, float* __restrict__ dw, float* __restrict__ dbias) {
-  const int o = blockIdx.x;
-  const int ij = blockIdx.y;   // one (i, j) pair per block row; ij == I*J is the bias
-  const int i = ij / J, j = ij % J;
-  float acc = 0.f;
-  for (long e = threadIdx.x; e < (long)B * C; e += blockDim.x) {
-    const int b = (int)(e / C), c = (int)(e % C);
-    const float g = load1<T>(dout + ((long)b * O + o) * C + c);
-    if (ij < I * J) acc += g * load1<T>(x1 + ((long)b * I + i) * C + c) * load1<T>(x2 + ((long)b * J + j) * C + c);
-    else acc += g;
+  __shared__ float A[BIL_MAX_I][64], D[BIL_MAX_J][64], G[BILW_OT][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int o0 = blockIdx.x * BILW_OT;
+  const int IJ = I * J, cols = IJ + 1;                 // last column = bias
+  const int nout = BILW_OT * cols;
+  const int ctiles = (C + 63) / 64, npairs = B * ctiles;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int p = blockIdx.y; p < npairs; p += gridDim.y) {
+    const int b = p / ctiles, c0 = (p - b * ctiles) * 64;
+    __syncthreads();
+    for (int e = tid; e < I * 64; e += 256) { const int i = e >> 6, c = c0 + (e & 63); A[i][e & 63] = c < C ? load1<T>(x1 + ((long)b * I + i) * C + c) : 0.f; }
+    for (int e = tid; e < J * 64; e += 256) { const int j = e >> 6, c = c0 + (e & 63); D[j][e & 63] = c < C ? load1<T>(x2 + ((long)b * J + j) * C + c) : 0.f; }
+    for (int e = tid; e < BILW_OT * 64; e += 256) {
+      const int o = o0 + (e >> 6), c = c0 + (e & 63);
+      G[e >> 6][e & 63] = (o < O && c < C) ? load1<T>(dout + ((long)b * O + o) * C + c) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {          // (static k: acc[] stays in registers; the sweeps below must NOT be unrolled
+      const int idx = tid + 256 * k;       //  further -- fully unrolled this kernel needs 2048 live LDS reads and spills 4 KB/lane)
+      if (idx < nout) {
+        const int ol = idx / cols, ij = idx - ol * cols;
+        const float* gp = &G[ol][0];
+        float a0 = 0.f, a1 = 0.f;
+        if (ij < IJ) {
+          const int i = ij / J, j = ij - i * J;
+          const float* ap = &A[i][0];
+          const float* dp = &D[j][0];
+#pragma unroll 2
+          for (int cc = 0; cc < 64; cc += 2) {
+            const int c = (cc + lane) & 63, c2 = (cc + 1 + lane) & 63;
+            a0 = fmaf(gp[c] * ap[c], dp[c], a0);
+            a1 = fmaf(gp[c2] * ap[c2], dp[c2], a1);
+          }
+        } else {
+#pragma unroll 4
+          for (int cc = 0; cc < 64; ++cc) a0 += gp[(cc + lane) & 63];
+        }
+        acc[k] += a0 + a1;
+      }
+    }
   }
-  __shared__ float sh[4];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float t = sh[0] + sh[1] + sh[2] + sh[3];
-    if (ij < I * J) dw[(long)o * I * J + ij] += t;
-    else if (dbias) dbias[o] += t;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < nout) {
+      const int ol = idx / cols, ij = idx - ol * cols, o = o0 + ol;
+      if (o < O) {
+        if (ij < IJ) atomicAdd(dw + (long)o * IJ + ij, acc[k]);
+        else if (dbias) atomicAdd(dbias + o, acc[k]);
+      }
+    }
   }
 }
 
@@ -345,8 +441,11 @@ extern "C" int vinet_bilinear_bwd(const void* x1, const void* x2, const void* do
   VN_CHECK_ARG(x1 && x2 && dout && w && B > 0 && C > 0 && I > 0 && I <= BIL_MAX_I && J > 0 && J <= BIL_MAX_J && O > 0,
                "bilinear_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  const dim3 gx((C + 63) / 64, B), bx(64);
-  const dim3 gw(O, I * J + 1), bw(256);
+  const dim3 gx((C + 63) / 64, B), bx(256);
+  VN_CHECK_ARG(BILW_OT * (I * J + 1) <= 8 * 256, "bilinear_bwd: I*J too large");
+  int splits = B * ((C + 63) / 64);
+  if (splits > 32) splits = 32;
+  const dim3 gw((O + BILW_OT - 1) / BILW_OT, splits), bw(256);
   if (dtype == VINET_F32) {
     if (dx1 || dx2) hipLaunchKernelGGL(bilinear_bwd_x_kernel<float>, gx, bx, 0, s, (const float*)x1, (const float*)x2, (const float*)dout, w, C, I, J, O, (float*)dx1, (float*)dx2);
     if (dw) hipLaunchKernelGGL(bilinear_bwd_w_kernel<float>, gw, bw, 0, s, (const float*)x1, (const float*)x2, (const float*)dout, B, C, I, J, O, dw, dbias);
