@@ -42,6 +42,9 @@ ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks) 
   // 10-20 M voxels) are prologue / epilogue bound: 128-row tiles put 4-6 workgroups on a CU instead of 2-3
   // (+5...17 % measured, tools/conv_ab.py)
   if (nt == 4 && kchunks > 0 && kchunks <= 32 && M >= (1L << 20)) return ConvTile{4, 2, 2, 2};
+  // the 96-wide shape has no small-M variants: a grid that covers under a quarter of the CUs (batch-1 decoder
+  // convs) moves to the 128-wide family, which does
+  if (nt == 6 && ((M + 255) / 256) * ((N + 95) / 96) < 64) nt = 8;
   if (nt == 8 || nt == 4) {
     const int bn = nt * 16;
     const long tilesN = (N + bn - 1) / bn;
