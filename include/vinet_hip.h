@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 1
+#define VINET_ABI_VERSION 2
 
 enum { VINET_F32 = 0, VINET_BF16 = 1 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
@@ -108,9 +108,18 @@ typedef struct VinetConvDesc {
   float* stats;
   int32_t n_valid;      /* 0 = y.C; else only channels < n_valid have weights /
                            affine (the rest of a channel-padded y gets act(0)) */
+  float* splitk_ws;     /* optional fp32 scratch for split-K (low-M, long-K convs: batch-1 inference): at least
+                           vinet_conv3d_splitk_bytes(desc) bytes, contents irrelevant on entry and undefined
+                           on return; NULL (or too small) = never split */
+  int64_t splitk_ws_bytes;
 } VinetConvDesc;
 
 int vinet_conv3d(const VinetConvDesc* desc, void* stream);
+/* Bytes of fp32 scratch with which vinet_conv3d would split this problem's K loop over several workgroups
+ * (each split stores its partial sums to its own slab; a finishing pass adds the slabs in a fixed order, so the
+ * result is run-to-run deterministic, and applies the epilogue); 0 when it would not split (enough tiles,
+ * short K, statistics or accumulate requested). */
+int64_t vinet_conv3d_splitk_bytes(const VinetConvDesc* desc);
 /* BM of the tile configuration vinet_conv3d will pick for this problem. */
 int vinet_conv3d_tile_m(const VinetConvDesc* desc);
 /* Name of the kernel instantiation vinet_conv3d will launch for this problem

@@ -137,6 +137,9 @@ class AbiEmulator:
         return 0
 
     # -- conv ----------------------------------------------------------------
+    def vinet_conv3d_splitk_bytes(self, d):
+        return 0          # the model never splits; results are identical by construction
+
     def vinet_conv3d_tile_m(self, d):
         d = _deref(d)
         M, N = d.x.B * d.oT * d.oH * d.oW, d.y.C

@@ -170,7 +170,35 @@ def test_conv3d_pingpong(case, shape):
         lib.vinet_set_option(b"pp", 1)
 
 
-def _run_conv_case(case, dt, forced=False):
+# split-K (grids too small for the chip): long-K decoder shape, placement through a concat slice, padded fp32
+# head, a T-sliced input, a pending affine, a chunk count that does not divide over the splits
+SPLITK_CASES = [
+    ("sk_dec_bigK", (1, 5, 4, 6), 480, 192, (5, 3, 3), (5, 1, 1), (0, 1, 1), dict(act=1, epi=True)),
+    ("sk_concat", (1, 2, 6, 6), 256, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(out_ld=96, out_coff=32, act=1)),
+    ("sk_head", (2, 1, 8, 12), 224, 1, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(epi_shift=True, act=2, out_f32=True, head=True)),
+    ("sk_tslice", (2, 3, 5, 5), 96, 48, (3, 3, 3), (3, 1, 1), (0, 1, 1), dict(in_ttotal=5, in_toff=1)),
+    ("sk_pre", (1, 2, 9, 11), 160, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(pre=True)),
+    ("sk_m300", (1, 3, 10, 10), 832, 384, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(epi=True, act=1)),
+]
+
+
+@pytest.mark.parametrize("min_per", [1, 2, 7], ids=["default", "per2", "per7"])
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
+def test_conv3d_splitk(case, min_per):
+    lib = _lib()
+    assert lib.vinet_set_option(b"splitk", min_per) == 0
+    try:
+        ex = dict(case[7], splitk=True)
+        _run_conv_case(case[:7] + (ex,), E.BF16)
+        # deterministic: the slabs are added in a fixed order
+        a = _run_conv_case(case[:7] + (ex,), E.BF16, want_y=True)
+        b = _run_conv_case(case[:7] + (ex,), E.BF16, want_y=True)
+        assert torch.equal(a, b)
+    finally:
+        lib.vinet_set_option(b"splitk", 1)
+
+
+def _run_conv_case(case, dt, forced=False, want_y=False):
     name, (B, T, H, W), Cin, N, k, s, p, ex = case
     oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
     xp, xmk = view_pair(B, T, H, W, Cin, dt, "x" + name, 1, t_total=ex.get("in_ttotal"), t_off=ex.get("in_toff", 0))
@@ -206,8 +234,15 @@ def _run_conv_case(case, dt, forced=False):
         d.accumulate = 1 if ex.get("accumulate") else 0
         d.stats = stats.ptr(side) if ex.get("stats") else None
         d.n_valid = N if head else 0
+        if ex.get("splitk") and side == "gpu":
+            nb = _lib().vinet_conv3d_splitk_bytes(C.byref(d))
+            assert nb >= 2 * M * Ny * 4, "split-K plan expected for " + name
+            ws = torch.full((nb // 4,), float("nan"), device="cuda")     # scratch contents must not matter
+            keep_ws.append(ws)
+            d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), nb
         return [C.byref(d), _stream() if side == "gpu" else 0]
 
+    keep_ws = []
     run_both("vinet_conv3d", mk)
     _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "conv " + name)
     if ex.get("stats"):
@@ -218,6 +253,8 @@ def _run_conv_case(case, dt, forced=False):
         sg = stats.get("gpu")[:r * 2 * N].view(r, 2, N).double().sum(0)
         sc = stats.get("cpu")[:r * 2 * N].view(r, 2, N).double().sum(0)
         _cmp(sg, sc, 1e-4 if dt == E.F32 else 2e-2, "conv stats " + name)
+    if want_y:
+        return yp.get("gpu").clone()
     return mk("gpu")[0]._obj
 
 

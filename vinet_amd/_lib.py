@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class CTensor(C.Structure):
@@ -34,7 +34,8 @@ class CConvDesc(C.Structure):
                 ("ooT", C.c_int32), ("ooH", C.c_int32), ("ooW", C.c_int32),
                 ("ntaps", C.c_int32), ("taps", C.c_void_p), ("w", C.c_void_p), ("Kp", C.c_int32),
                 ("pre", CAffine), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p),
-                ("act", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("n_valid", C.c_int32)]
+                ("act", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("n_valid", C.c_int32),
+                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64)]
 
 
 class CWgradDesc(C.Structure):
@@ -54,6 +55,7 @@ _PT, _PC, _PW, _PP = C.POINTER(CTensor), C.POINTER(CConvDesc), C.POINTER(CWgradD
 SIGNATURES = {
     "vinet_conv3d": [_PC, _vp],
     "vinet_conv3d_tile_m": [_PC],
+    "vinet_conv3d_splitk_bytes": [_PC],
     "vinet_conv3d_kernel_name": [_PC, C.c_char_p, _i32],
     "vinet_conv3d_wgrad": [_PW, _vp],
     "vinet_conv3d_wgrad_kernel_name": [_PW, C.c_char_p, _i32],
@@ -87,7 +89,7 @@ SIGNATURES = {
     "vinet_abi_version": [],
     "vinet_last_error": [],
 }
-_RESTYPE = {"vinet_last_error": C.c_char_p}
+_RESTYPE = {"vinet_last_error": C.c_char_p, "vinet_conv3d_splitk_bytes": C.c_int64}
 
 _LIB = None
 _TEST_DOUBLE = None

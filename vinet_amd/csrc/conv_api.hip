@@ -110,6 +110,7 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   }
   a.tilesM = vn_div_up(M, t.BM());
   a.tilesN = vn_div_up(a.N, t.BN());
+  a.splits = 1; a.chunks_per_split = 0; a.ws = nullptr;
   return 0;
 }
 
@@ -123,6 +124,7 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
 }
 
 int g_vinet_opt_dma = 1;
+extern int g_vinet_opt_splitk;
 int g_vinet_opt_n64_tile = 0;   // tuning: 64-wide layers on 128x64 (1) or 64x64 (2) tiles instead of 256x64
 int g_vinet_opt_pool_lds = 1;   // LDS halo-tile 3x3x3/s1 max-pool forward (C % 64 == 0)
 int g_vinet_opt_pool_twalk = 1; // T-walking 3x3x3/s1 max-pool backward
@@ -140,6 +142,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "n64_tile")) { g_vinet_opt_n64_tile = value; return 0; }
   if (name && !strcmp(name, "tperm")) { g_vinet_opt_tperm = value; return 0; }
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
+  if (name && !strcmp(name, "splitk")) { g_vinet_opt_splitk = value; return 0; }
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
   if (name && !strcmp(name, "wgrad_dma")) { g_vinet_opt_wgrad_dma = value; return 0; }
@@ -179,6 +182,61 @@ static bool use_pp(const VinetConvDesc* d) {
   return N >= 160 && nkt >= 16 && tiles >= 128;
 }
 
+// ---- split-K for grids that cannot fill the chip (batch-1 inference) ---------------------------
+int g_vinet_opt_splitk = 1;     // 0 = off; n >= 2 = tuning: minimum K chunks (of 32) per split
+struct SplitK { int splits, per; long bytes; };
+static SplitK splitk_plan(const VinetConvDesc* d) {
+  SplitK p{1, 0, 0};
+  if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || d->stats || d->accumulate) return p;
+  const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  const int nchunks = d->ntaps * (d->Kp / 32);
+  const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, nchunks);
+  const long tiles = vn_div_up(M, t.BM()) * vn_div_up(d->y.C, t.BN());
+  const int min_per = g_vinet_opt_splitk >= 2 ? g_vinet_opt_splitk : 6;   // measured flat between 3 and 8 (batch-1 graph replay)
+  // workgroup slots of the chip for this tile shape: 3 stages of (BM + BN) rows x 64 B in 160 KB of LDS, 4 at most
+  const long smem = 3L * (t.BM() + t.BN()) * 64 + (d->pre.scale ? 2L * d->Kp * 4 : 0);
+  long per_cu = (160 * 1024) / smem;
+  if (per_cu > 4) per_cu = 4;
+  const long slots = 256 * per_cu;
+  if (tiles * 2 > slots) return p;
+  int s = (int)(slots / tiles);
+  if (s > nchunks / min_per) s = nchunks / min_per;
+  if (s > 16) s = 16;
+  if (s < 2) return p;
+  p.per = (nchunks + s - 1) / s;
+  p.splits = (nchunks + p.per - 1) / p.per;
+  p.bytes = (long)p.splits * M * d->y.C * 4;
+  return p;
+}
+
+extern "C" int64_t vinet_conv3d_splitk_bytes(const VinetConvDesc* d) {
+  if (!d) return 0;
+  return splitk_plan(d).bytes;
+}
+
+// y = act(scale * sum_s ws[s][m][n] + shift) with the placement of the conv epilogue
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs a) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)a.M * a.N) return;
+  const int m = (int)(e / a.N), n = (int)(e - (long)m * a.N);
+  float v = 0.f;
+  for (int s = 0; s < a.splits; ++s) v += a.ws[((long)s * a.M + m) * a.N + n];
+  const bool nok = n < a.Nw;
+  v = fmaf(v, (a.out_scale && nok) ? a.out_scale[n] : 1.f, (a.out_shift && nok) ? a.out_shift[n] : 0.f);
+  if (a.act == VINET_ACT_RELU) v = fmaxf(v, 0.f);
+  else if (a.act == VINET_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+  long off;
+  if (a.y_linear) {
+    off = (long)m * a.ldy + n;
+  } else {
+    int b, to, ho, wo;
+    decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
+    off = (long)b * a.sBy + ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) * (long)a.ldy + n;
+  }
+  if (a.out_f32) ((float*)a.y)[off] = v;
+  else ((bf16_t*)a.y)[off] = f2bf(v);
+}
+
 extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32_t n) {
   if (!d || !buf || n <= 0) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
@@ -200,7 +258,18 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
     a.tilesN = vn_div_up(a.N, bn);
     return vinet_launch_conv_pp_bf16(bn, a, (hipStream_t)stream);
   }
-  if (use_dma(d)) return vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);
+  if (use_dma(d)) {
+    const SplitK sp = splitk_plan(d);
+    if (sp.splits > 1 && d->splitk_ws && d->splitk_ws_bytes >= sp.bytes) {
+      a.splits = sp.splits; a.chunks_per_split = sp.per; a.ws = d->splitk_ws;
+      rc = vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);
+      if (rc) return rc;
+      const long n = (long)a.M * a.N;
+      hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)vn_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+      return vn_launch_status("conv_splitk_finish");
+    }
+    return vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);
+  }
   if (d->dtype == VINET_BF16) return vinet_launch_conv_bf16(t, d->mode, a, (hipStream_t)stream);
   return vinet_launch_conv_f32(t, d->mode, a, (hipStream_t)stream);
 }

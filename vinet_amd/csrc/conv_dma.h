@@ -120,11 +120,19 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   }
 
   const int cpt = a.Kp / 32;
-  const int nchunks = a.ntaps * cpt;
+  int nchunks = a.ntaps * cpt;
   const long slice_bytes = (long)a.Nw * a.Kp * 2;
 
   // issue state: K chunk `isu` = (tap isu_tap, channel offset isu_c)
   int isu = 0, isu_tap = 0, isu_c = 0;
+  if (a.splits > 1) {          // this workgroup's share of the K loop
+    isu = blockIdx.y * a.chunks_per_split;
+    const int cend = isu + a.chunks_per_split;
+    if (cend < nchunks) nchunks = cend;
+    isu_tap = isu / cpt;
+    isu_c = (isu - isu_tap * cpt) * 32;
+  }
+  const int chunk0 = isu;
   auto issue = [&](int slot) {
     char* stage = smem + slot * Cfg::STAGE_BYTES;
     if (isu < nchunks) {
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   // fragment read offsets: row (lane&15) of a 16-row group, k chunk (lane>>4), swizzled
   const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) * 16);
 
-  int cmp_c = 0;   // channel offset of the chunk being computed (PRE)
+  int cmp_c = isu_c;   // channel offset of the chunk being computed (PRE)
   auto compute = [&](int slot) {
     const char* As = smem + slot * Cfg::STAGE_BYTES + (wm * MT * 16) * 64 + frag_off;
     const char* Bs = smem + slot * Cfg::STAGE_BYTES + (BM + wn * NT * 16) * 64 + frag_off;
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s);
   int slot = 0, fill = STAGES - 1;
-  for (int it = 0; it < nchunks; ++it) {
+  for (int it = chunk0; it < nchunks; ++it) {
     wait_vmcnt<Cfg::LPS*(STAGES - 2)>();      // my DMAs of stage `it` have landed
     __builtin_amdgcn_s_barrier();              // everyone's have; everyone finished reading slot `fill`
     asm volatile("" ::: "memory");
@@ -231,6 +239,19 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
 #ifdef VINET_CONV_TIMING
   const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
 #endif
+  if (a.splits > 1) {          // raw partial sums -> this split's slab of the workspace [splits][M][N]
+    const int m_wave = tile_m * BM + wm * MT * 16, n_wave = tile_n * BN + wn * NT * 16;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m_wave + i * 16 + (lane >> 4) * 4 + r, n = n_wave + j * 16 + (lane & 15);
+          if (m < a.M && n < a.N) a.ws[((long)blockIdx.y * a.M + m) * a.N + n] = acc[i][j][r];
+        }
+    return;
+  }
   conv_epilogue<MT, NT, WARPS_M, WARPS_N>(a, acc, smem, tile_m, tile_n);
 #ifdef VINET_CONV_TIMING
   if (tid == 0 && a.out_shift) {   // tuning build only: out_shift doubles as a [grid][4] float dump
@@ -253,6 +274,6 @@ static int launch_conv_dma_cfg(const ConvArgs& a, hipStream_t s) {
     if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_dma): %s", hipGetErrorString(e)); return (int)e; }
     attr_done[dev & 63] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(256), Cfg::smem_bytes(a.Kp), s, a);
+  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN, a.splits > 1 ? a.splits : 1), dim3(256), Cfg::smem_bytes(a.Kp), s, a);
   return vn_launch_status("conv_dma");
 }

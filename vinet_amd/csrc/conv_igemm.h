@@ -44,6 +44,11 @@ struct ConvArgs {
   // tensors).  perm_P == 0: identity.
   int perm_P, perm_T;
   FastDiv dPT, dPermT;
+  // split-K (conv_dma_kernel, no statistics): blockIdx.y owns K chunks [y*per, (y+1)*per) and stores its raw
+  // accumulators to slab y of the fp32 workspace; conv_splitk_finish_kernel adds the slabs in a fixed order
+  // (run-to-run deterministic) and applies the epilogue
+  int splits, chunks_per_split;
+  float* ws;
 };
 
 // logical M-tile index -> tile position in memory order

@@ -563,6 +563,18 @@ def _wgrad_kernel_name(ctx, wd):
     return buf.value.decode() or "wgrad"
 
 
+def _splitk_scratch(ctx, d):
+    """Grids too small for the chip (batch-1 inference) split their K loop when the caller lends scratch
+    memory (include/vinet_hip.h: splitk_ws).  The tensor comes from torch's stream-ordered caching
+    allocator, so dropping the reference right after the launch is safe (and graph capture keeps it)."""
+    nbytes = ctx.lib.vinet_conv3d_splitk_bytes(C.byref(d))
+    if nbytes <= 0:
+        return None
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=ctx.device)
+    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), nbytes
+    return ws
+
+
 def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n_pad=None):
     """x -> conv (-> BN) (-> act).  Returns the output Act.
 
@@ -615,6 +627,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     if bn is None:
         d.out_scale, d.out_shift = None, _ptr(plan.bias)
         d.act, d.stats = act, None
+        ws = _splitk_scratch(ctx, d)
         ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
         res.scale = res.shift = None
         res.relu = False
@@ -644,6 +657,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
                 ctx.call("vinet_bn_fold", _ptr(bn.gamma), _ptr(bn.beta), bn.rm.data_ptr(), bn.rv.data_ptr(),
                          _ptr(plan.bias), float(bn.eps), plan.N, scale.data_ptr(), shift.data_ptr(), None, ctx.stream)
             d.out_scale, d.out_shift, d.act, d.stats = scale.data_ptr(), shift.data_ptr(), act, None
+            ws = _splitk_scratch(ctx, d)
             ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
             res.scale = res.shift = None
             res.relu = False
