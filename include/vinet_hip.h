@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 2
+#define VINET_ABI_VERSION 3
 
 enum { VINET_F32 = 0, VINET_BF16 = 1 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
@@ -158,8 +158,11 @@ int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_t ntaps, in
 /* Multi-tensor vinet_pack_weights: one launch for every weight of the model (they all go stale together
  * after the optimizer step; replaces ~170 launches of model_utils.py conv weights per training step).
  * `table` is DEVICE memory: (njobs + 1) rows of 8 int64
- *   { w (const float*), out (packed, dtype), N, Cin, ntaps, transpose | stem << 1, first output index, 0 }
- * the last row carrying only the total in its prefix field; layouts exactly as vinet_pack_weights. */
+ *   { w (const float*), out (packed, dtype), N, Cin, ntaps, transpose | stem << 1, first output index, ld | col << 32 }
+ * the last row carrying only the total in its prefix field; layouts exactly as vinet_pack_weights.  A transposed
+ * job with ld != 0 writes its N columns at [col, col + N) of rows `ld` elements apart (padding columns are the
+ * caller's to zero): the 1x1x1 convs of an Inception block that share an input are packed side by side along K
+ * so that their data gradients are ONE conv (model_utils.py:176-187). */
 int vinet_pack_weights_multi(const int64_t* table, int32_t njobs, int64_t total, int32_t dtype, void* stream);
 /* packed fp32 dw -> torch layout; grad (+)= dw. */
 int vinet_unpack_wgrad(const float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem, int32_t accumulate,
@@ -197,7 +200,8 @@ int vinet_copy_affine(const VinetTensor* src, int32_t src_dtype, VinetAffine pre
  * var; write mean, invstd, and the consumer-side affine scale = gamma*invstd,
  * shift = beta - mean*scale; update running stats with `momentum` (unbiased
  * variance), as aten native_batch_norm does. */
-int vinet_bn_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* gamma,
+/* `ld` (0 = C): row stride of the partials when the C channels are a slice of a wider epilogue's columns. */
+int vinet_bn_finalize(const float* partials, int32_t rows, int32_t C, int32_t ld, double count, const float* gamma,
                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                       float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* Eval: scale = gamma / sqrt(running_var + eps), shift = beta + (conv_bias - running_mean)*scale. */
@@ -214,7 +218,7 @@ int vinet_stats_rows(const VinetTensor* x);
  * native_batch_norm_backward + threshold_backward (train.py:216). */
 int vinet_bn_bwd_reduce(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,
                         const float* mean, const float* invstd, float* partials, void* stream);
-int vinet_bn_bwd_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* scale,
+int vinet_bn_bwd_finalize(const float* partials, int32_t rows, int32_t C, int32_t ld, double count, const float* scale,
                           int32_t train, float* dgamma_acc, float* dbeta_acc, const float* invstd, float* c1, float* c2,
                           void* stream);
 int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,

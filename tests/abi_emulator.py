@@ -260,6 +260,14 @@ class AbiEmulator:
         assert int(tab[njobs, 6]) == total
         for j in range(njobs):
             w, out, N, Cin, ntaps, flags = (int(v) for v in tab[j, :6])
+            ld, col = int(tab[j, 7]) & 0xffffffff, int(tab[j, 7]) >> 32
+            if ld:
+                assert flags == 1
+                W = _f32(w, N * Cin * ntaps).reshape(N, Cin, ntaps)
+                raw = _raw(out, ntaps * Cin * ld, dtype).reshape(ntaps, Cin, ld)
+                o = W.transpose(2, 1, 0)
+                raw[:, :, col:col + N] = o if dtype == F32 else _f2bf(o.reshape(-1)).reshape(o.shape)
+                continue
             self.vinet_pack_weights(w, N, Cin, ntaps, flags & 1, (flags >> 1) & 1, dtype, out, stream)
         return 0
 
@@ -314,8 +322,10 @@ class AbiEmulator:
         return 0
 
     # -- BN ----------------------------------------------------------------------
-    def vinet_bn_finalize(self, partials, rows, Cc, count, gamma, beta, eps, momentum, rm, rv, mean, invstd, scale, shift, stream):
-        P = _f32(partials, rows * 2 * Cc).reshape(rows, 2, Cc).astype(np.float64)
+    def vinet_bn_finalize(self, partials, rows, Cc, ld, count, gamma, beta, eps, momentum, rm, rv, mean, invstd, scale, shift, stream):
+        ld = ld or Cc
+        P = _f32(partials, (rows * 2 - 1) * ld + Cc).copy()
+        P = np.lib.stride_tricks.as_strided(P, (rows, 2, Cc), (8 * ld, 4 * ld, 4)).astype(np.float64)
         s, q = P[:, 0].sum(0), P[:, 1].sum(0)
         mu = s / count
         var = np.maximum(q / count - mu * mu, 0)
@@ -385,8 +395,10 @@ class AbiEmulator:
         P[0, 1] = (g * xhat).reshape(-1, x_raw.C).astype(np.float64).sum(0)
         return 0
 
-    def vinet_bn_bwd_finalize(self, partials, rows, Cc, count, scale, train, dgamma, dbeta, invstd, c1, c2, stream):
-        P = _f32(partials, rows * 2 * Cc).reshape(rows, 2, Cc).astype(np.float64)
+    def vinet_bn_bwd_finalize(self, partials, rows, Cc, ld, count, scale, train, dgamma, dbeta, invstd, c1, c2, stream):
+        ld = ld or Cc
+        P = _f32(partials, (rows * 2 - 1) * ld + Cc).copy()
+        P = np.lib.stride_tricks.as_strided(P, (rows, 2, Cc), (8 * ld, 4 * ld, 4)).astype(np.float64)
         s, p = P[:, 0].sum(0), P[:, 1].sum(0)
         if dgamma:
             _f32(dgamma, Cc)[:] += p.astype(np.float32)

@@ -130,6 +130,12 @@ CONV_CASES = [
     ("accumulate", (1, 2, 6, 6), 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(accumulate=True)),
     ("head_pad", (2, 1, 8, 12), 32, 1, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(epi_shift=True, act=2, out_f32=True, head=True)),
     ("big_m", (2, 4, 28, 48), 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(stats=True)),
+    # input = channel slice of a wider buffer (the fused Inception entry conv's reduce outputs, the block output
+    # behind them): rows ld apart, first channel not on a row start
+    ("xslice_pre", (1, 2, 9, 11), 96, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(pre=True, stats=True, in_ld=368, in_coff=16)),
+    ("xslice_pw", (2, 2, 6, 8), 256, 176, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(pre=True, stats=True, in_ld=368, in_coff=112,
+                                                                              out_ld=480, out_coff=0)),
+    ("xslice_plain", (1, 3, 6, 6), 64, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(in_ld=104, in_coff=40, act=1)),
 ]
 
 
@@ -201,7 +207,8 @@ def test_conv3d_splitk(case, min_per):
 def _run_conv_case(case, dt, forced=False, want_y=False):
     name, (B, T, H, W), Cin, N, k, s, p, ex = case
     oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
-    xp, xmk = view_pair(B, T, H, W, Cin, dt, "x" + name, 1, t_total=ex.get("in_ttotal"), t_off=ex.get("in_toff", 0))
+    xp, xmk = view_pair(B, T, H, W, Cin, dt, "x" + name, 1, t_total=ex.get("in_ttotal"), t_off=ex.get("in_toff", 0),
+                        ld=ex.get("in_ld"), c_off=ex.get("in_coff", 0))
     head = ex.get("head", False)
     Ny = (E.EG[dt] if head else N)
     odt = E.F32 if ex.get("out_f32") else dt
@@ -411,6 +418,11 @@ WGRAD_CASES = [
     ("dec", (2, 6, 5, 7), 64, 160, (3, 3, 3), (3, 1, 1), (0, 1, 1), True),
     ("splitk", (2, 4, 28, 48), 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), False),
     ("cin24_n208", (1, 2, 6, 6), 24, 208, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+    # x and dy as channel slices of wider buffers (fused Inception entry conv: dy = [b1r | b2r | b0] of the
+    # block's gradient buffer, x = the previous block's output behind its own reduce channels)
+    ("pw_slices", (2, 3, 7, 9), 96, 48, (1, 1, 1), (1, 1, 1), (0, 0, 0), True, dict(x_ld=160, x_coff=32, dy_ld=112, dy_coff=16)),
+    ("sp3_xslice", (1, 2, 9, 11), 32, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), True, dict(x_ld=80, x_coff=16)),
+    ("pw_big_slices", (4, 8, 28, 48), 192, 176, (1, 1, 1), (1, 1, 1), (0, 0, 0), True, dict(x_ld=304, x_coff=112, dy_ld=432, dy_coff=0)),
 ]
 
 
@@ -444,10 +456,11 @@ def test_conv3d_wgrad_pingpong(case, shape):
 
 
 def _run_wgrad_case(case, dt):
-    name, (B, T, H, W), Cin, N, k, s, p, pre = case
+    name, (B, T, H, W), Cin, N, k, s, p, pre = case[:8]
+    ex = case[8] if len(case) > 8 else {}
     oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
-    xp, xmk = view_pair(B, T, H, W, Cin, dt, "wx" + name, 1)
-    dp, dmk = view_pair(B, oT, oH, oW, N, dt, "wd" + name, 2)
+    xp, xmk = view_pair(B, T, H, W, Cin, dt, "wx" + name, 1, ld=ex.get("x_ld"), c_off=ex.get("x_coff", 0))
+    dp, dmk = view_pair(B, oT, oH, oW, N, dt, "wd" + name, 2, ld=ex.get("dy_ld"), c_off=ex.get("dy_coff", 0))
     ntaps = k[0] * k[1] * k[2]
     Kp = E.rup(Cin, 32)
     dw = Pair(torch.zeros(ntaps * N * Kp))
@@ -561,7 +574,7 @@ def test_bn_kernels(dt, Cc):
     rm, rv = fvec("rm", Cc, 5), fvec("rv", Cc, 6, 0.5, 1.5)
     mean, istd, sc, sh = [Pair(torch.zeros(Cc)) for _ in range(4)]
     stats = Pair(part.cpu.clone())
-    run_both("vinet_bn_finalize", lambda s: [stats.ptr(s), rows, Cc, n, gam.ptr(s), bet.ptr(s), 1e-3, 0.001, rm.ptr(s), rv.ptr(s), mean.ptr(s), istd.ptr(s), sc.ptr(s), sh.ptr(s), _stream() if s == "gpu" else 0])
+    run_both("vinet_bn_finalize", lambda s: [stats.ptr(s), rows, Cc, 0, n, gam.ptr(s), bet.ptr(s), 1e-3, 0.001, rm.ptr(s), rv.ptr(s), mean.ptr(s), istd.ptr(s), sc.ptr(s), sh.ptr(s), _stream() if s == "gpu" else 0])
     for a, nm in ((mean, "mean"), (istd, "invstd"), (sc, "scale"), (sh, "shift"), (rm, "rm"), (rv, "rv")):
         _cmp(a.get("gpu"), a.get("cpu"), 2e-6, "bn_finalize " + nm)
     # fold
@@ -577,7 +590,7 @@ def test_bn_kernels(dt, Cc):
     _cmp(part2.get("gpu").view(rows, 2, Cc).double().sum(0), part2.get("cpu").view(rows, 2, Cc).double().sum(0), 2e-5, "bn_bwd_reduce")
     dg, db, c1, c2 = [Pair(torch.zeros(Cc)) for _ in range(4)]
     p2 = Pair(part2.cpu.clone())
-    run_both("vinet_bn_bwd_finalize", lambda s: [p2.ptr(s), rows, Cc, n, sc.ptr(s), 1, dg.ptr(s), db.ptr(s), istd.ptr(s), c1.ptr(s), c2.ptr(s), _stream() if s == "gpu" else 0])
+    run_both("vinet_bn_bwd_finalize", lambda s: [p2.ptr(s), rows, Cc, 0, n, sc.ptr(s), 1, dg.ptr(s), db.ptr(s), istd.ptr(s), c1.ptr(s), c2.ptr(s), _stream() if s == "gpu" else 0])
     for a in (dg, db, c1, c2):
         _cmp(a.get("gpu"), a.get("cpu"), 2e-6, "bn_bwd_finalize")
     dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "bndx", 8)
@@ -642,7 +655,7 @@ def test_maxpool(dt, ksp):
     k, s, p = ksp
     B, T, H, W, Cc = 2, 8, 9, 10, 24
     od = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
-    xp, xmk = view_pair(B, T, H, W, Cc, dt, "px", 1)
+    xp, xmk = view_pair(B, T, H, W, Cc, dt, "px", 1, ld=40, c_off=8)      # input / its gradient: slices of a wider buffer
     yp, ymk = view_pair(B, od[0], od[1], od[2], Cc, dt, "py", 2)
     am = Pair(torch.zeros(B * od[0] * od[1] * od[2] * Cc, dtype=torch.uint8))
     ps, ph = fvec("pps", Cc, 3, -1.5, 1.5), fvec("pph", Cc, 4)
@@ -655,7 +668,7 @@ def test_maxpool(dt, ksp):
     diff = am.get("gpu") != am.get("cpu")
     assert not bool((diff & (yp.get("cpu").float() != 0)).any())
     gp, gmk = view_pair(B, od[0], od[1], od[2], Cc, dt, "pg", 5)
-    dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "pdx", 6)
+    dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "pdx", 6, ld=40, c_off=8)
     amc = Pair(am.cpu.clone())
     run_both("vinet_maxpool3d_bwd", lambda sd: [C.byref(pd()), C.byref(gmk(sd).ct()), amc.ptr(sd), C.byref(dxmk(sd).ct()), 1, _stream() if sd == "gpu" else 0])
     _cmp(dxp.get("gpu"), dxp.get("cpu"), 1e-5 if dt == E.F32 else 2e-2, "maxpool bwd")

@@ -172,6 +172,36 @@ def test_avinet_train_step_fp32():
     _note("avinet_train_fp32", dict(worst_rel_grad_err=worst))
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("dt", [E.F32, E.BF16], ids=["fp32", "bf16"])
+def test_mixed_joint_entry_equals_per_conv(mode, dt):
+    """the fused Inception entry conv ([b1 reduce | b2 reduce | b0] as one conv, one dgrad, one wgrad) against the
+    three separate convs: same outputs, input / parameter gradients and running statistics"""
+    from vinet_amd import model_utils as MU
+    res = []
+    for joint in (1, 0):
+        E.JOINT_ENTRY = joint
+        try:
+            torch.manual_seed(3)
+            blk = MU.Mixed_4b().cuda()
+            blk.compute_dtype = dt
+            blk.train(mode == "train")
+            x = synth.uniform("jx", (2, 480, 4, 14, 12), 5, -1.0, 1.0).cuda().requires_grad_(mode == "train")
+            if mode == "train":
+                y = blk(x)
+                (y * synth.uniform("jg", tuple(y.shape), 6, -1.0, 1.0).cuda()).sum().backward()
+                res.append([y.detach(), x.grad] + [p.grad for p in blk.parameters()] + [b.float() for b in blk.buffers()])
+            else:
+                with torch.no_grad():
+                    res.append([blk(x)])
+        finally:
+            E.JOINT_ENTRY = 1
+    tol = 2e-5 if dt == E.F32 else 3e-2
+    for a, b in zip(*res):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= tol * scale
+
+
 def test_graphed_inference_matches_eager():
     """hipGraph replay of the forward == eager forward, and survives new inputs"""
     from vinet_amd import model as VM

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CTensor(C.Structure):
@@ -65,12 +65,12 @@ SIGNATURES = {
     "vinet_import_ncdhw_pad": [_vp, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _PT, _i32, _vp],
     "vinet_export_ncdhw": [_PT, _i32, CAffine, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "vinet_copy_affine": [_PT, _i32, CAffine, _PT, _i32, _i32, _vp],
-    "vinet_bn_finalize": [_vp, _i32, _i32, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "vinet_bn_finalize": [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "vinet_bn_fold": [_vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "vinet_channel_stats": [_PT, _i32, _vp, _vp],
     "vinet_stats_rows": [_PT],
     "vinet_bn_bwd_reduce": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp],
-    "vinet_bn_bwd_finalize": [_vp, _i32, _i32, _f64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "vinet_bn_bwd_finalize": [_vp, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "vinet_bn_bwd_apply": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp, _PT, _vp],
     "vinet_act_bwd": [_PT, _i32, _PT, _i32, _i32, _PT, _i32, _vp],
     "vinet_channel_sum": [_PT, _i32, _vp, _i32, _vp, _i32, _vp],

@@ -118,7 +118,9 @@ extern "C" int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_
 
 // Multi-tensor form: every weight of the model is re-packed after each optimizer step, 170 launches of a few
 // microseconds each when done one by one.  `table` (device memory) holds 8 int64 per job:
-//   { w pointer, out pointer, N, Cin, ntaps, transpose | stem << 1, first output index (prefix sum), unused }
+//   { w pointer, out pointer, N, Cin, ntaps, transpose | stem << 1, first output index (prefix sum), ld | col << 32 }
+// ld != 0 (transposed jobs only): rows of the destination are `ld` elements apart and this job owns columns
+// [col, col + N) of them -- several convs that share an input, packed side by side along K for ONE dgrad.
 // plus one trailing row whose prefix field is the total; one thread per output element, job by binary search.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long* __restrict__ table, int njobs, long total) {
@@ -147,6 +149,11 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long* __r
       if (k < Cin) v = w[((long)r * Cin + k) * ntaps + sl];
     } else {
       if (k < N) v = w[((long)k * Cin + r) * ntaps + sl];
+      const long ld = J[7] & 0xffffffffl;
+      if (ld) {          // side-by-side destination: only the job's own columns are written
+        if (k < N) store1<T>(out + ((long)sl * rows + r) * ld + (J[7] >> 32) + k, v);
+        continue;
+      }
     }
     store1<T>(out + e, v);
   }
@@ -303,15 +310,15 @@ extern "C" int vinet_copy_affine(const VinetTensor* src, int32_t src_dtype, Vine
 // ============================================================================
 // BatchNorm
 // ============================================================================
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int rows, int C, double count,
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int rows, int C, int ld, double count,
                                    const float* gamma, const float* beta, float eps, float momentum,
                                    float* running_mean, float* running_var, float* mean_o, float* invstd_o,
                                    float* scale_o, float* shift_o) {
   const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
   for (int r = threadIdx.x; r < rows; r += blockDim.x) {
-    s += (double)partials[((long)r * 2 + 0) * C + c];
-    q += (double)partials[((long)r * 2 + 1) * C + c];
+    s += (double)partials[((long)r * 2 + 0) * ld + c];
+    q += (double)partials[((long)r * 2 + 1) * ld + c];
   }
   __shared__ double red[2][4];
   s = wave_sum_d(s); q = wave_sum_d(q);
@@ -338,11 +345,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partials, int rows,
   }
 }
 
-extern "C" int vinet_bn_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* gamma,
+extern "C" int vinet_bn_finalize(const float* partials, int32_t rows, int32_t C, int32_t ld, double count, const float* gamma,
                                  const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                  float* mean, float* invstd, float* scale, float* shift, void* stream) {
-  VN_CHECK_ARG(partials && rows > 0 && C > 0 && count > 0 && scale && shift, "bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, rows, C, count, gamma,
+  VN_CHECK_ARG(partials && rows > 0 && C > 0 && (ld == 0 || ld >= C) && count > 0 && scale && shift, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, rows, C, ld ? ld : C, count, gamma,
                      beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   return vn_launch_status("bn_finalize");
 }
@@ -556,14 +563,14 @@ extern "C" int vinet_bn_bwd_reduce(const VinetTensor* dz, const VinetTensor* x_r
 }
 
 // one workgroup per channel: rows are reduced in parallel (fp64), lane 0 finishes
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int C, int ld,
                                                               double count, const float* scale, int train, float* dgamma,
                                                               float* dbeta, const float* invstd, float* c1, float* c2) {
   const int c = blockIdx.x;
   double s = 0.0, p = 0.0;
   for (int r = threadIdx.x; r < rows; r += blockDim.x) {
-    s += (double)partials[((long)r * 2) * C + c];
-    p += (double)partials[((long)r * 2 + 1) * C + c];
+    s += (double)partials[((long)r * 2) * ld + c];
+    p += (double)partials[((long)r * 2 + 1) * ld + c];
   }
   __shared__ double red[2][4];
   s = wave_sum_d(s); p = wave_sum_d(p);
@@ -579,11 +586,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
-extern "C" int vinet_bn_bwd_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* scale,
+extern "C" int vinet_bn_bwd_finalize(const float* partials, int32_t rows, int32_t C, int32_t ld, double count, const float* scale,
                                      int32_t train, float* dgamma_acc, float* dbeta_acc, const float* invstd, float* c1,
                                      float* c2, void* stream) {
-  VN_CHECK_ARG(partials && rows > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, rows, C, count,
+  VN_CHECK_ARG(partials && rows > 0 && C > 0 && (ld == 0 || ld >= C) && count > 0, "bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, rows, C, ld ? ld : C, count,
                      scale, train, dgamma_acc, dbeta_acc, invstd, c1, c2);
   return vn_launch_status("bn_bwd_finalize");
 }

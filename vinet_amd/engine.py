@@ -88,6 +88,8 @@ class Profiler:
 
 
 PROFILER = None
+# Inception blocks run their three input-side 1x1x1 convs as one (model_utils._Mixed._fwd_joint); 0 = per conv
+JOINT_ENTRY = int(os.environ.get("VINET_JOINT_ENTRY", "1"))
 
 
 def set_profiler(p):
@@ -165,13 +167,16 @@ class View:
 
 class Act:
     """activation = view + pending affine/relu + gradient bookkeeping."""
-    __slots__ = ("v", "scale", "shift", "relu", "_grad", "grad_ready", "needs_grad", "parent", "pc0", "pt0", "fold")
+    __slots__ = ("v", "scale", "shift", "relu", "_grad", "grad_ready", "needs_grad", "parent", "pc0", "pt0", "fold",
+                 "indep", "ready_of")
 
     def __init__(self, v, scale=None, shift=None, relu=False, needs_grad=False):
         self.v, self.scale, self.shift, self.relu = v, scale, shift, relu
         self._grad, self.grad_ready, self.needs_grad = None, False, needs_grad
         self.parent, self.pc0, self.pt0 = None, 0, 0
         self.fold = None
+        self.indep = False       # channel region with its own "gradient written" flag (see region())
+        self.ready_of = None     # span over several regions: ready when all of them are
 
     @property
     def plain(self):
@@ -187,14 +192,23 @@ class Act:
         a.parent, a.pc0, a.pt0 = self, c0, None
         return a
 
+    def region(self, c0, c1):
+        """channel slice that shares gradient STORAGE with self but is written by its own set of consumers:
+        the first of them stores, the rest accumulate, independently of the neighbouring regions (the fused
+        Inception entry conv writes [b1 reduce | b2 reduce | b0] side by side with the concat output)."""
+        a = self.sub_chan(c0, c1)
+        a.indep = True
+        return a
+
     def sub_t(self, t0, t1):
         a = Act(self.v.tslice(t0, t1), self.scale, self.shift, self.relu, self.needs_grad)
         a.parent, a.pt0, a.pc0 = self, t0, None
         return a
 
     def root(self):
+        """owner of the gradient-ready flag"""
         a = self
-        while a.parent is not None:
+        while a.parent is not None and not a.indep:
             a = a.parent
         return a
 
@@ -202,6 +216,11 @@ class Act:
     def grad_view(self, dt=None, zero=False):
         """gradient storage (allocated on first use; slices resolve into the parent's)."""
         if self.parent is not None:
+            if self.indep and zero:
+                top = self.parent
+                while top.parent is not None:
+                    top = top.parent
+                assert top._grad is None, "zero-filled gradient requested for a region of live shared storage"
             g = self.parent.grad_view(dt, zero)
             if self.pt0 is None:
                 return g.chan(self.pc0, self.pc0 + self.v.C)
@@ -214,6 +233,8 @@ class Act:
         return self._grad
 
     def is_grad_ready(self):
+        if self.ready_of is not None:
+            return all(a.is_grad_ready() for a in self.ready_of)
         return self.root().grad_ready
 
     def mark_grad_ready(self):
@@ -478,6 +499,22 @@ class ConvPlan:
     def _pack_stamp(self):
         return (self.weight._version, _WEIGHTS_EPOCH, self.weight.data_ptr())
 
+    def pack_jobs(self, key):
+        """rows of the multi-pack job table (without the prefix field): (w, out, N, Cin, ntaps, flags, elements, ld|col<<32)"""
+        tr = 1 if key[1] else 0
+        stem = 1 if (self.stem and not key[1]) else 0
+        return [(self.weight.data_ptr(), self._packs[key][1].data_ptr(), self.N, self.Cin, self.ntaps, tr | (stem << 1),
+                 self.pack_numel(key[1]), 0)]
+
+    def wants_wgrad(self):
+        return self.weight.requires_grad
+
+    def unpack_wgrad(self, ctx, dw):
+        """packed fp32 dw -> += .grad in torch layout"""
+        gw = _param_grad(self.weight)
+        ctx.call("vinet_unpack_wgrad", dw.data_ptr(), self.N, self.Cin, self.ntaps, 1 if self.stem else 0, 1,
+                 gw.data_ptr(), ctx.stream)
+
     def pack_numel(self, transpose):
         if self.stem and not transpose:
             return 7 * self.N * 32
@@ -486,13 +523,84 @@ class ConvPlan:
         return self.ntaps * self.Cin * self.kp(True)
 
 
+def pack_table(jobs, device):
+    """device-side job table of vinet_pack_weights_multi (include/vinet_hip.h) -> (table, total elements)"""
+    rows, off = [], 0
+    for w, out, N, Cin, ntaps, flags, numel, ldcol in jobs:
+        rows.append([w, out, N, Cin, ntaps, flags, off, ldcol])
+        off += numel
+    rows.append([0, 0, 0, 0, 0, 0, off, 0])
+    return torch.tensor(rows, dtype=torch.int64).to(device), off
+
+
+class JointConvPlan(ConvPlan):
+    """Several 1x1x1 convs over the SAME input (the entry convs of an Inception block, model_utils.py:176-187)
+    run as one conv: forward packs stacked along N, transposed packs side by side along K, one weight-gradient
+    launch whose rows are handed back to each member's .grad.  The members keep their own parameters."""
+
+    def __init__(self, members):
+        m0 = members[0]
+        assert all(m.k == (1, 1, 1) and m.s == (1, 1, 1) and m.p == (0, 0, 0) and m.Cin == m0.Cin and m.bias is None and not m.stem
+                   for m in members)
+        self.members = list(members)
+        self.offs = [sum(m.N for m in members[:i]) for i in range(len(members))]
+        self.weight, self.bias = None, None
+        self.k, self.s, self.p = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+        self.N, self.Cin, self.ntaps, self.stem = sum(m.N for m in members), m0.Cin, 1, False
+        self._packs, self._taps = {}, {}
+
+    def _pack_stamp(self):
+        return tuple(m._pack_stamp() for m in self.members)
+
+    def wants_wgrad(self):
+        assert len({m.weight.requires_grad for m in self.members}) == 1, "joint conv: freeze all members or none"
+        return self.members[0].weight.requires_grad
+
+    def pack_jobs(self, key):
+        dt, transpose = key[0], key[1]
+        base, es = self._packs[key][1].data_ptr(), ESIZE[dt]
+        jobs = []
+        for m, off in zip(self.members, self.offs):
+            w = m.weight.detach()
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            if transpose:
+                jobs.append((w.data_ptr(), base, m.N, m.Cin, 1, 1, m.Cin * rup(m.N, 32), self.kp(True) | (off << 32)))
+            else:
+                jobs.append((w.data_ptr(), base + off * self.kp(False) * es, m.N, m.Cin, 1, 0, m.N * self.kp(False), 0))
+        return jobs
+
+    def packed(self, ctx, transpose=False):
+        key = (ctx.dt, transpose, str(ctx.device))
+        stamp = self._pack_stamp()
+        ent = self._packs.get(key)
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
+        if ent is not None and _PACKS.repack_all(ctx, key):
+            return self._packs[key][1]
+        if ent is None:     # zero-filled once: the side-by-side jobs never touch the K padding columns
+            self._packs[key] = (None, torch.zeros(self.pack_numel(transpose), dtype=TORCH_DT[ctx.dt], device=ctx.device))
+            _PACKS.register(self, key)
+        jobs = self.pack_jobs(key)
+        table, total = pack_table(jobs, ctx.device)
+        ctx.call("vinet_pack_weights_multi", table.data_ptr(), len(jobs), total, ctx.dt, ctx.stream)
+        self._packs[key] = (stamp, self._packs[key][1])
+        self._keep_table = table       # the launch reads it asynchronously
+        return self._packs[key][1]
+
+    def unpack_wgrad(self, ctx, dw):
+        kp = self.kp(False)
+        for m, off in zip(self.members, self.offs):
+            gw = _param_grad(m.weight)
+            ctx.call("vinet_unpack_wgrad", dw.data_ptr() + off * kp * 4, m.N, m.Cin, 1, 0, 1, gw.data_ptr(), ctx.stream)
+
+
 class _PackRegistry:
     """Every (plan, dtype, transpose, device) pack that has been built once.  After an optimizer step all of them
     are stale together, so the first stale request re-packs the whole group with ONE vinet_pack_weights_multi
     launch (a device-side job table, rebuilt only when the set of jobs or a weight pointer changes)."""
 
     def __init__(self):
-        self.groups = {}      # (dt, device str) -> dict(jobs=[(weakref(plan), key)], table=None, sig=None, total=0)
+        self.groups = {}      # (dt, device str) -> dict(jobs=[(weakref(plan), key)], table=None, sig=None, total=0, njobs=0)
 
     def register(self, plan, key):
         g = self.groups.setdefault((key[0], key[2]), dict(jobs=[], table=None, sig=None, total=0))
@@ -509,18 +617,12 @@ class _PackRegistry:
             g["table"] = None
         if len(live) < 2:
             return False
-        sig = tuple((p.weight.data_ptr(), p._packs[k][1].data_ptr()) for p, k in live)
+        jobs = [j for p, k in live for j in p.pack_jobs(k)]
+        sig = tuple((j[0], j[1]) for j in jobs)
         if g["table"] is None or g["sig"] != sig:
-            rows, off = [], 0
-            for p, k in live:
-                tr = 1 if k[1] else 0
-                stem = 1 if (p.stem and not k[1]) else 0
-                rows.append([p.weight.data_ptr(), p._packs[k][1].data_ptr(), p.N, p.Cin, p.ntaps, tr | (stem << 1), off, 0])
-                off += p.pack_numel(k[1])
-            rows.append([0, 0, 0, 0, 0, 0, off, 0])
-            g["table"] = torch.tensor(rows, dtype=torch.int64).to(ctx.device)
-            g["sig"], g["total"] = sig, off
-        ctx.call("vinet_pack_weights_multi", g["table"].data_ptr(), len(live), g["total"], key[0], ctx.stream)
+            g["table"], g["total"] = pack_table(jobs, ctx.device)
+            g["sig"], g["njobs"] = sig, len(jobs)
+        ctx.call("vinet_pack_weights_multi", g["table"].data_ptr(), g["njobs"], g["total"], key[0], ctx.stream)
         for p, k in live:
             p._packs[k] = (p._pack_stamp(), p._packs[k][1])
         return True
@@ -542,6 +644,54 @@ class BNState:
     def fold_stamp(self, bias, dt, device):
         ts = (self.gamma, self.beta, self.rm, self.rv, bias)
         return (tuple((t._version, t.data_ptr()) if t is not None else None for t in ts), _WEIGHTS_EPOCH, dt, str(device))
+
+    # (pointer offsets: the joint form below runs the same kernels on channel slices)
+    def fold(self, ctx, bias, N, scale, shift, invstd=None, off=0):
+        o = 4 * off
+        ctx.call("vinet_bn_fold", _ptr(self.gamma), _ptr(self.beta), self.rm.data_ptr(), self.rv.data_ptr(), _ptr(bias),
+                 float(self.eps), N, scale.data_ptr() + o, shift.data_ptr() + o,
+                 None if invstd is None else invstd.data_ptr() + o, ctx.stream)
+
+    def finalize(self, ctx, stats, rows, N, M, mean, invstd, scale, shift, off=0, ld=0):
+        o = 4 * off
+        ctx.call("vinet_bn_finalize", stats.data_ptr() + o, rows, N, ld, float(M), _ptr(self.gamma), _ptr(self.beta),
+                 float(self.eps), float(self.momentum), self.rm.data_ptr(), self.rv.data_ptr(), mean.data_ptr() + o,
+                 invstd.data_ptr() + o, scale.data_ptr() + o, shift.data_ptr() + o, ctx.stream)
+        self.steps += 1
+
+    def bwd_finalize(self, ctx, ws, rows, N, M, scale, train_bn, invstd, c1, c2, off=0, ld=0):
+        o = 4 * off
+        dg = _param_grad(self.gamma) if self.gamma is not None and self.gamma.requires_grad else None
+        db = _param_grad(self.beta) if self.beta is not None and self.beta.requires_grad else None
+        ctx.call("vinet_bn_bwd_finalize", ws.data_ptr() + o, rows, N, ld, float(M), scale.data_ptr() + o, 1 if train_bn else 0,
+                 _ptr(dg), _ptr(db), invstd.data_ptr() + o, c1.data_ptr() + o, c2.data_ptr() + o, ctx.stream)
+
+
+class JointBN:
+    """the BatchNorms of a JointConvPlan's members, over consecutive channel ranges of the joint output"""
+
+    def __init__(self, members, widths, fold_cache=None):
+        self.members, self.widths = list(members), list(widths)
+        self.offs = [sum(widths[:i]) for i in range(len(widths))]
+        self.N = sum(widths)
+        self.fold_cache = fold_cache
+        self.eps, self.momentum = members[0].eps, members[0].momentum
+
+    def fold_stamp(self, bias, dt, device):
+        return tuple(m.fold_stamp(None, dt, device) for m in self.members)
+
+    def fold(self, ctx, bias, N, scale, shift, invstd=None):
+        assert bias is None and N == self.N
+        for m, w, o in zip(self.members, self.widths, self.offs):
+            m.fold(ctx, None, w, scale, shift, invstd, off=o)
+
+    def finalize(self, ctx, stats, rows, N, M, mean, invstd, scale, shift):
+        for m, w, o in zip(self.members, self.widths, self.offs):
+            m.finalize(ctx, stats, rows, w, M, mean, invstd, scale, shift, off=o, ld=N)
+
+    def bwd_finalize(self, ctx, ws, rows, N, M, scale, train_bn, invstd, c1, c2):
+        for m, w, o in zip(self.members, self.widths, self.offs):
+            m.bwd_finalize(ctx, ws, rows, w, M, scale, train_bn, invstd, c1, c2, off=o, ld=N)
 
 
 def _param_grad(p):
@@ -636,9 +786,9 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         shift = ctx.f32(plan.N) if shift_out is None else shift_out
         if ctx.recording:
             # eval-mode BN with gradients: keep the raw conv output (+bias), BN(+ReLU) stays pending
+            assert not isinstance(bn, JointBN), "joint convs are not recorded under eval-mode BN"
             invstd = ctx.f32(plan.N)
-            ctx.call("vinet_bn_fold", _ptr(bn.gamma), _ptr(bn.beta), bn.rm.data_ptr(), bn.rv.data_ptr(), None,
-                     float(bn.eps), plan.N, scale.data_ptr(), shift.data_ptr(), invstd.data_ptr(), ctx.stream)
+            bn.fold(ctx, None, plan.N, scale, shift, invstd)
             d.out_scale, d.out_shift, d.act, d.stats = None, _ptr(plan.bias), L.ACT_NONE, None
             ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
             res.scale, res.shift, res.relu = scale, shift, (act == L.ACT_RELU)
@@ -654,8 +804,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
                     cached = None
                     bn.fold_cache["fold"] = (stamp, scale, shift)
             if cached is None:
-                ctx.call("vinet_bn_fold", _ptr(bn.gamma), _ptr(bn.beta), bn.rm.data_ptr(), bn.rv.data_ptr(),
-                         _ptr(plan.bias), float(bn.eps), plan.N, scale.data_ptr(), shift.data_ptr(), None, ctx.stream)
+                bn.fold(ctx, plan.bias, plan.N, scale, shift)
             d.out_scale, d.out_shift, d.act, d.stats = scale.data_ptr(), shift.data_ptr(), act, None
             ws = _splitk_scratch(ctx, d)
             ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
@@ -670,10 +819,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         scale = ctx.f32(plan.N) if scale_out is None else scale_out
         shift = ctx.f32(plan.N) if shift_out is None else shift_out
         mean, invstd = ctx.f32(plan.N), ctx.f32(plan.N)
-        ctx.call("vinet_bn_finalize", stats.data_ptr(), rows, plan.N, float(M), _ptr(bn.gamma), _ptr(bn.beta),
-                 float(bn.eps), float(bn.momentum), bn.rm.data_ptr(), bn.rv.data_ptr(), mean.data_ptr(),
-                 invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), ctx.stream)
-        bn.steps += 1
+        bn.finalize(ctx, stats, rows, plan.N, M, mean, invstd, scale, shift)
         res.scale, res.shift, res.relu = scale, shift, (act == L.ACT_RELU)
         keep.update(mean=mean, invstd=invstd)
 
@@ -706,10 +852,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                  tag=("vinet_bn_bwd_reduce | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
                  work=dict(flops=0.0, bytes=2 * nb))
         c1, c2 = ctx.f32(Ny), ctx.f32(Ny)
-        dg = _param_grad(bn.gamma) if bn.gamma is not None and bn.gamma.requires_grad else None
-        db = _param_grad(bn.beta) if bn.beta is not None and bn.beta.requires_grad else None
-        ctx.call("vinet_bn_bwd_finalize", ws.data_ptr(), rows, Ny, float(M), res.scale.data_ptr(), 1 if train_bn else 0,
-                 _ptr(dg), _ptr(db), keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), ctx.stream)
+        bn.bwd_finalize(ctx, ws, rows, Ny, M, res.scale, train_bn, keep["invstd"], c1, c2)
         ctx.call("vinet_bn_bwd_apply", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
                  keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), C.byref(dz.ct()), ctx.stream,
                  tag=("vinet_bn_bwd_apply | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
@@ -736,7 +879,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         assert Ny % plan.N == 0 and (Ny == plan.N or plan.N == 1)
         ctx.call("vinet_channel_sum", C.byref(dy.ct()), dy.dt, ws.data_ptr(), plan.N, gb.data_ptr(), 1, ctx.stream)
     # ---- weight gradient (side stream) ---------------------------------------------
-    if plan.weight.requires_grad:
+    if plan.wants_wgrad():
         side = ctx.side_stream()
         main_ptr = ctx.stream
         if side is not None:
@@ -764,9 +907,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                                    bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
                 if Ny != plan.N:
                     assert plan.ntaps == 1, "channel-padded outputs are only supported for 1x1x1 convs"
-                gw = _param_grad(plan.weight)
-                ctx.call("vinet_unpack_wgrad", dw.data_ptr(), plan.N, plan.Cin, plan.ntaps, 1 if plan.stem else 0, 1,
-                         gw.data_ptr(), ctx.stream)
+                plan.unpack_wgrad(ctx, dw)
             finally:
                 ctx.stream = main_ptr
     # ---- data gradient -------------------------------------------------------------

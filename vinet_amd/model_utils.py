@@ -151,6 +151,7 @@ class _Mixed(_Block):
         super().__init__()
         cin, b0, b1r, b1, b2r, b2, b3 = MIXED_WIDTHS[self._name]
         self.widths = (b0, b1, b2, b3)
+        self.reduce = (b1r, b2r)
         self.branch0 = nn.Sequential(BasicConv3d(cin, b0, kernel_size=1, stride=1))
         self.branch1 = nn.Sequential(BasicConv3d(cin, b1r, kernel_size=1, stride=1),
                                      SepConv3d(b1r, b1, kernel_size=3, stride=1, padding=1))
@@ -159,7 +160,47 @@ class _Mixed(_Block):
         self.branch3 = nn.Sequential(_Marker("maxpool3d", kernel_size=(3, 3, 3), stride=1, padding=1),
                                      BasicConv3d(cin, b3, kernel_size=1, stride=1))
 
+    def _entry(self):
+        """the three 1x1x1 convs that read the block input, as one conv with output channels [b1 reduce | b2 reduce | b0]"""
+        mods = (self.branch1[0], self.branch2[0], self.branch0[0])
+        plans = [m.conv.plan() for m in mods]
+        jp = self.__dict__.get("_vinet_joint")
+        if jp is None or any(a is not b for a, b in zip(jp.members, plans)):
+            jp = self.__dict__["_vinet_joint"] = E.JointConvPlan(plans)
+        jbn = E.JointBN([m.bn.state() for m in mods], [p.N for p in plans],
+                        fold_cache=self.__dict__.setdefault("_vinet_joint_fold", {}))
+        return mods, jp, jbn
+
+    def _fwd_joint(self, ctx, x):
+        """One buffer [b1 reduce | b2 reduce | b0 | b1 | b2 | b3] per voxel: the entry conv writes its three outputs
+        side by side (x is read once, and in backward the three data gradients are ONE conv whose K runs over
+        the same channels of the gradient buffer: x.grad is written once instead of read-modify-written three
+        times); the block output is the channel slice behind the two reduce outputs."""
+        xv = x.v
+        b0, b1, b2, b3 = self.widths
+        b1r, b2r = self.reduce
+        R = b1r + b2r
+        big = E.new_concat(ctx, xv.B, xv.T, xv.H, xv.W, R + b0 + b1 + b2 + b3, pending=(ctx.training or ctx.recording))
+        r1, r2, cat = big.region(0, b1r), big.region(b1r, R), big.region(R, R + b0 + b1 + b2 + b3)
+        entry = big.sub_chan(0, R + b0)
+        entry.ready_of = [r1, r2, cat]
+        mods, jp, jbn = self._entry()
+        E.conv_forward(ctx, jp, x, bn=jbn, act=L.ACT_RELU, dst=entry)
+        if ctx.training:
+            for m in mods:
+                m.bn.note_training_step()
+            self.__dict__["_vinet_joint_fold"].clear()
+        o1, o2, o3 = b0, b0 + b1, b0 + b1 + b2
+        self.branch1[1]._fwd(ctx, r1, cat.sub_chan(o1, o2))
+        self.branch2[1]._fwd(ctx, r2, cat.sub_chan(o2, o3))
+        pooled = E.maxpool_forward(ctx, x, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        self.branch3[1]._fwd(ctx, pooled, cat.sub_chan(o3, o3 + b3))
+        return cat
+
     def _fwd(self, ctx, x, dst=None):
+        # (eval-mode BN under autograd keeps per-layer running statistics as the saved mean: per-conv path)
+        if dst is None and E.JOINT_ENTRY and (ctx.training or not ctx.recording):
+            return self._fwd_joint(ctx, x)
         xv = x.v
         b0, b1, b2, b3 = self.widths
         cat = dst if dst is not None else E.new_concat(ctx, xv.B, xv.T, xv.H, xv.W, b0 + b1 + b2 + b3,
