@@ -204,6 +204,10 @@ int vinet_copy_affine(const VinetTensor* src, int32_t src_dtype, VinetAffine pre
 int vinet_bn_finalize(const float* partials, int32_t rows, int32_t C, int32_t ld, double count, const float* gamma,
                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                       float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* Optional pre-reduction of a tall partials table [rows][2][C] into out[out_rows][2][C] (chunks of
+ * ceil(rows / out_rows) consecutive rows; (out_rows - 1) * chunk < rows required), coalesced: the finalize kernels
+ * walk the rows with one workgroup per channel, which is slow for the 10^5 rows of the 64-channel stem layers. */
+int vinet_bn_partials_fold(const float* partials, int32_t rows, int32_t C, float* out, int32_t out_rows, void* stream);
 /* Eval: scale = gamma / sqrt(running_var + eps), shift = beta + (conv_bias - running_mean)*scale. */
 int vinet_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                   const float* conv_bias /* optional */, float eps, int32_t C, float* scale, float* shift,

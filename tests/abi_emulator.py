@@ -322,6 +322,15 @@ class AbiEmulator:
         return 0
 
     # -- BN ----------------------------------------------------------------------
+    def vinet_bn_partials_fold(self, partials, rows, Cc, out, out_rows, stream):
+        per = (rows + out_rows - 1) // out_rows
+        assert (out_rows - 1) * per < rows
+        P = _f32(partials, rows * 2 * Cc).reshape(rows, 2, Cc).astype(np.float64)
+        O = _f32(out, out_rows * 2 * Cc).reshape(out_rows, 2, Cc)
+        for i in range(out_rows):
+            O[i] = P[i * per:(i + 1) * per].sum(0)
+        return 0
+
     def vinet_bn_finalize(self, partials, rows, Cc, ld, count, gamma, beta, eps, momentum, rm, rv, mean, invstd, scale, shift, stream):
         ld = ld or Cc
         P = _f32(partials, (rows * 2 - 1) * ld + Cc).copy()

@@ -603,6 +603,16 @@ def test_bn_kernels(dt, Cc):
     _cmp(out.get("gpu"), out.get("cpu"), 2e-5, "channel_sum")
 
 
+@pytest.mark.parametrize("rows,Cc,out_rows", [(5000, 64, 256), (4097, 176, 256), (300, 24, 7), (64, 832, 64)])
+def test_bn_partials_fold(rows, Cc, out_rows):
+    per = (rows + out_rows - 1) // out_rows
+    out_rows = (rows + per - 1) // per
+    p = Pair(_rand("pf", (rows * 2 * Cc,), 1))
+    o = Pair(torch.zeros(out_rows * 2 * Cc))
+    run_both("vinet_bn_partials_fold", lambda s: [p.ptr(s), rows, Cc, o.ptr(s), out_rows, _stream() if s == "gpu" else 0])
+    _cmp(o.get("gpu"), o.get("cpu"), 1e-6, "bn_partials_fold")
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_act_bwd(dt):
     B, T, H, W, Cc = 2, 2, 5, 6, 32

@@ -70,6 +70,7 @@ SIGNATURES = {
     "vinet_channel_stats": [_PT, _i32, _vp, _vp],
     "vinet_stats_rows": [_PT],
     "vinet_bn_bwd_reduce": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp],
+    "vinet_bn_partials_fold": [_vp, _i32, _i32, _vp, _i32, _vp],
     "vinet_bn_bwd_finalize": [_vp, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "vinet_bn_bwd_apply": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp, _PT, _vp],
     "vinet_act_bwd": [_PT, _i32, _PT, _i32, _i32, _PT, _i32, _vp],

@@ -354,6 +354,38 @@ extern "C" int vinet_bn_finalize(const float* partials, int32_t rows, int32_t C,
   return vn_launch_status("bn_finalize");
 }
 
+// Pre-reduction of a tall partials table (the 64-channel stem layers produce 172 032 rows at 64 clips: the
+// one-workgroup-per-channel finalize would walk them with 4-byte reads 2*C*4 bytes apart).  Block (chunk, 64-channel
+// group): 64 channels x 4 row lanes, whole-row coalesced reads, double accumulation, out[chunk][2][C].
+__global__ __launch_bounds__(256) void bn_partials_fold_kernel(const float* __restrict__ partials, int rows, int C, int per,
+                                                               float* __restrict__ out) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * per;
+  int r1 = r0 + per; if (r1 > rows) r1 = rows;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      s += (double)partials[((long)r * 2 + 0) * C + c];
+      q += (double)partials[((long)r * 2 + 1) * C + c];
+    }
+  __shared__ double red[2][4][64];
+  red[0][rl][threadIdx.x & 63] = s; red[1][rl][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    const int l = threadIdx.x;
+    out[((long)blockIdx.x * 2 + 0) * C + c] = (float)(red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]);
+    out[((long)blockIdx.x * 2 + 1) * C + c] = (float)(red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]);
+  }
+}
+
+extern "C" int vinet_bn_partials_fold(const float* partials, int32_t rows, int32_t C, float* out, int32_t out_rows, void* stream) {
+  VN_CHECK_ARG(partials && out && rows > 0 && C > 0 && out_rows > 0 && out_rows <= rows, "bn_partials_fold: bad arguments");
+  const int per = (rows + out_rows - 1) / out_rows;
+  VN_CHECK_ARG((long)(out_rows - 1) * per < rows, "bn_partials_fold: out_rows=%d leaves empty chunks for rows=%d", out_rows, rows);
+  hipLaunchKernelGGL(bn_partials_fold_kernel, dim3(out_rows, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, rows, C, per, out);
+  return vn_launch_status("bn_partials_fold");
+}
+
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                const float* conv_bias, float eps, int C, float* scale, float* shift, float* invstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -819,6 +819,12 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         scale = ctx.f32(plan.N) if scale_out is None else scale_out
         shift = ctx.f32(plan.N) if shift_out is None else shift_out
         mean, invstd = ctx.f32(plan.N), ctx.f32(plan.N)
+        if rows >= 1024:        # tall table (early, high-resolution layers): coalesced pre-reduction to 256 rows
+            per = (rows + 255) // 256
+            rows2 = (rows + per - 1) // per
+            folded = ctx.f32(rows2 * 2 * plan.N)
+            ctx.call("vinet_bn_partials_fold", stats.data_ptr(), rows, plan.N, folded.data_ptr(), rows2, ctx.stream)
+            stats, rows = folded, rows2
         bn.finalize(ctx, stats, rows, plan.N, M, mean, invstd, scale, shift)
         res.scale, res.shift, res.relu = scale, shift, (act == L.ACT_RELU)
         keep.update(mean=mean, invstd=invstd)
