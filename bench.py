@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
+    ap.add_argument("--batch", type=int, default=128, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
     ap.add_argument("--model", choices=["vinet", "avinet"], default="vinet",
                     help="avinet = BASELINE config 4: VideoAudioSaliencyModel with the SoundNet branch + bilinear fusion (32x224x384 only)")
     ap.add_argument("--clip", type=int, default=32)
