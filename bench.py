@@ -231,6 +231,10 @@ def main():
         domtab = {k: v for k, v in table.items() if k in kernels[dom]["sites"]}
     else:
         domtab = prof.summary()
+        if not sum(v["count"] for v in domtab.values()):
+            # the kernel that led the bracketed warm-up step did not run in the timed steps (a first-step-only
+            # kernel can lead under counter collection with --warmup 1): report it from the warm-up step
+            domtab = {k: v for k, v in table.items() if k in kernels[dom]["sites"]}
     domstat = dict(ms=sum(v["ms"] for v in domtab.values()), count=sum(v["count"] for v in domtab.values()),
                    flops=sum((v["work"] or {}).get("flops", 0.0) * v["count"] for v in domtab.values()),
                    bytes=sum((v["work"] or {}).get("bytes", 0.0) * v["count"] for v in domtab.values()))

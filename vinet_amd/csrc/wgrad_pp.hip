@@ -91,8 +91,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(const WgradPPArgs
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, grp = wave >> 2;
   const int g_w = wc >> 1, p_w = wc & 1;
-  const int tile_s = blockIdx.x % a.tilesS, tile_n = blockIdx.x / a.tilesS;
-  const int kt0 = blockIdx.y * a.kt_per_split;
+  // Workgroups are dealt to the 8 XCDs round-robin in dispatch order: remap so that the column / row tiles of ONE
+  // voxel range (which stage the same dy rows and overlapping x rows) are neighbours on one XCD and share its L2
+  const int wg_lin = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int bx = wg_lin % (int)gridDim.x, by = wg_lin / (int)gridDim.x;
+  const int tile_s = bx % a.tilesS, tile_n = bx / a.tilesS;
+  const int kt0 = by * a.kt_per_split;
   int kt1 = kt0 + a.kt_per_split;
   if (kt1 > a.nkt) kt1 = a.nkt;
   const int n0 = tile_n * TN, seg0 = tile_s * 4;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(const WgradPPArgs
 #undef WPP_PHASE
 #ifdef VINET_CONV_TIMING
   if ((tid & 255) == 0 && a.dbg) {
-    float* dbg = a.dbg + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 4;
+    float* dbg = a.dbg + ((long)(by * gridDim.x + bx) * 2 + grp) * 4;
     for (int k = 0; k < 4; ++k) dbg[k] = (float)tacc[k] / (float)(niter * 8);
   }
 #endif
