@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 3
+#define VINET_ABI_VERSION 4
 
 enum { VINET_F32 = 0, VINET_BF16 = 1 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
@@ -142,6 +142,10 @@ typedef struct VinetWgradDesc {
   float* dw;
   int32_t Kp;
   VinetAffine pre;
+  int32_t tline;        /* 1 = the caller promises a purely temporal kernel: tap kt is (kt - tpad, 0, 0, slice kt),
+                           kt = 0..ntaps-1 (the tap table lives in device memory, the library cannot look);
+                           lets 64 -> 64 channel layers take the frame-streaming kernel.  0 = no promise. */
+  int32_t tpad;
 } VinetWgradDesc;
 
 int vinet_conv3d_wgrad(const VinetWgradDesc* desc, void* stream);

@@ -455,6 +455,32 @@ def test_conv3d_wgrad_pingpong(case, shape):
         lib.vinet_set_option(b"wgrad_pp", 1)
 
 
+# frame-streaming wgrad of temporal 64 -> 64 convs: stride 2 and 1, 7 / 3 / 2 taps, pending affine, sliced views,
+# odd frame counts (window running past the last frame), one clip / several clips
+WGRAD_TS_CASES = [
+    ("ts_k7s2", (2, 9, 8, 16), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), True),
+    ("ts_k7s2_plain", (1, 12, 8, 8), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), False),
+    ("ts_k3s1", (2, 5, 16, 8), 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), True),
+    ("ts_k2s2", (1, 8, 8, 8), 64, 64, (2, 1, 1), (2, 1, 1), (0, 0, 0), False),
+    ("ts_k5s1_slices", (3, 6, 8, 8), 64, 64, (5, 1, 1), (1, 1, 1), (2, 0, 0), True, dict(x_ld=160, x_coff=32, dy_ld=112, dy_coff=16)),
+    ("ts_k7s2_long", (1, 32, 8, 24), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), True),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_TS_CASES, ids=[c[0] for c in WGRAD_TS_CASES])
+def test_conv3d_wgrad_tstream(case):
+    lib = _lib()
+    assert lib.vinet_set_option(b"wgrad_ts", 2) == 0      # force (the heuristic wants thousands of patches)
+    try:
+        ex = dict(case[8]) if len(case) > 8 else {}
+        ex["tline"] = True
+        d0 = _run_wgrad_case(case[:8] + (ex,), E.BF16)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_wgrad_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_wgrad_ts_kernel<")
+    finally:
+        lib.vinet_set_option(b"wgrad_ts", 1)
+
+
 def _run_wgrad_case(case, dt):
     name, (B, T, H, W), Cin, N, k, s, p, pre = case[:8]
     ex = case[8] if len(case) > 8 else {}
@@ -474,6 +500,8 @@ def _run_wgrad_case(case, dt):
         d.sT, d.sH, d.sW = s
         d.ntaps, d.taps, d.dw, d.Kp = ntaps, taps.ptr(side), dw.ptr(side), Kp
         d.pre = L.CAffine(ps.ptr(side), ph.ptr(side), 1) if pre else L.CAffine(None, None, 0)
+        if ex.get("tline"):
+            d.tline, d.tpad = 1, p[0]
         return [C.byref(d), _stream() if side == "gpu" else 0]
 
     run_both("vinet_conv3d_wgrad", mk)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CTensor(C.Structure):
@@ -41,7 +41,8 @@ class CConvDesc(C.Structure):
 class CWgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("mode", C.c_int32), ("x", CTensor), ("dy", CTensor),
                 ("sT", C.c_int32), ("sH", C.c_int32), ("sW", C.c_int32),
-                ("ntaps", C.c_int32), ("taps", C.c_void_p), ("dw", C.c_void_p), ("Kp", C.c_int32), ("pre", CAffine)]
+                ("ntaps", C.c_int32), ("taps", C.c_void_p), ("dw", C.c_void_p), ("Kp", C.c_int32), ("pre", CAffine),
+                ("tline", C.c_int32), ("tpad", C.c_int32)]
 
 
 class CPoolDesc(C.Structure):

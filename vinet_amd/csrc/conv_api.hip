@@ -133,6 +133,7 @@ int g_vinet_opt_wgrad_tr = 1;
 int g_vinet_opt_wgrad_dma = 1;
 int g_vinet_opt_pp = 1;         // 256x256x64 ping-pong kernel for large plain convs
 int g_vinet_opt_wgrad_pp = 1;   // 256x256x64 ping-pong wgrad for large layers (2 = force)
+int g_vinet_opt_wgrad_ts = 1;   // frame-streaming wgrad for temporal 64 -> 64 convs (2 = force on any eligible shape)
 int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad (0 = heuristic)
 
 extern "C" int vinet_set_option(const char* name, int32_t value) {
@@ -146,6 +147,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
   if (name && !strcmp(name, "wgrad_dma")) { g_vinet_opt_wgrad_dma = value; return 0; }
+  if (name && !strcmp(name, "wgrad_ts")) { g_vinet_opt_wgrad_ts = value; return 0; }
   if (name && !strcmp(name, "wgrad_tg")) { g_vinet_opt_wgrad_tg = value; return 0; }
   vinet_set_error("set_option: unknown option %s", name ? name : "(null)");
   return -1;

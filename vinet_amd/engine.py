@@ -906,6 +906,10 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                 wd.sT, wd.sH, wd.sW = (1, 2, 1) if folded else plan.s
                 wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), kp
                 wd.pre = x.affine()
+                # a purely temporal kernel (k,1,1): tap kt is (kt - pad, 0, 0, kt) -- the library cannot read the
+                # device-side tap table, so the geometry is promised here (include/vinet_hip.h: tline)
+                if not folded and not plan.stem and plan.k[1] == 1 and plan.k[2] == 1 and plan.p[1] == 0 and plan.p[2] == 0:
+                    wd.tline, wd.tpad = 1, plan.p[0]
                 es = ESIZE[ctx.dt]
                 ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
                          tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
