@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 4
+#define VINET_ABI_VERSION 5
 
 enum { VINET_F32 = 0, VINET_BF16 = 1 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
@@ -112,6 +112,11 @@ typedef struct VinetConvDesc {
                            vinet_conv3d_splitk_bytes(desc) bytes, contents irrelevant on entry and undefined
                            on return; NULL (or too small) = never split */
   int64_t splitk_ws_bytes;
+  int32_t tline;        /* 1 = the caller promises a purely temporal kernel: every tap is (dt, 0, 0, slice) and the
+                           dt form the contiguous range [-tpad, -tpad + ntaps - 1] in any order (the tap table is
+                           device memory, the library cannot look); lets 64 -> 64 channel layers take the
+                           frame-streaming kernel (conv_ts.hip).  0 = no promise. */
+  int32_t tpad;
 } VinetConvDesc;
 
 int vinet_conv3d(const VinetConvDesc* desc, void* stream);

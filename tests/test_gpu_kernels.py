@@ -204,6 +204,72 @@ def test_conv3d_splitk(case, min_per):
         lib.vinet_set_option(b"splitk", 1)
 
 
+# frame-streaming temporal conv (conv_ts.hip): forward with statistics / folded BN, stride 2 and 1, the two stride
+# phases of the stem partner's data gradient (taps in descending order, output frames interleaved, accumulate),
+# sliced views, windows running past the last frame
+CONV_TS_CASES = [
+    ("ts_fwd_k7s2", (2, 9, 8, 16), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), dict(pre=True, stats=True)),
+    ("ts_fwd_k7s2_eval", (1, 12, 8, 8), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), dict(epi=True, act=1)),
+    ("ts_fwd_k3s1", (2, 5, 16, 8), 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(pre=True, stats=True, in_ld=160, in_coff=32, out_ld=96, out_coff=16)),
+    ("ts_fwd_k2s2", (1, 8, 8, 8), 64, 64, (2, 1, 1), (2, 1, 1), (0, 0, 0), dict(act=1)),
+    ("ts_fwd_long", (1, 32, 8, 24), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), dict(pre=True, stats=True)),
+    ("ts_acc", (2, 6, 8, 8), 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(accumulate=True)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_TS_CASES, ids=[c[0] for c in CONV_TS_CASES])
+def test_conv3d_tstream(case):
+    lib = _lib()
+    assert lib.vinet_set_option(b"conv_ts", 2) == 0
+    try:
+        ex = dict(case[7], tline=True)
+        d0 = _run_conv_case(case[:7] + (ex,), E.BF16, forced=True)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_ts_kernel<")
+        assert lib.vinet_conv3d_tile_m(C.byref(d0)) == 64
+    finally:
+        lib.vinet_set_option(b"conv_ts", 1)
+
+
+@pytest.mark.parametrize("r", [0, 1])
+def test_conv3d_tstream_dgrad_phase(r):
+    """one stride phase of the 7x1x1 / 2 data gradient: taps (e - j, slice d0 + 2j) in descending offset order, output
+    frames r, r+2, ... of a 2x longer tensor, accumulated"""
+    lib = _lib()
+    dt = E.BF16
+    B, To, H, W, Cc = 2, 8, 8, 8, 64
+    Ti = 2 * To
+    d0_, e = (r + 3) % 2, (r + 3 - (r + 3) % 2) // 2
+    rows = [(e - j, 0, 0, d0_ + 2 * j) for j in range(4) if d0_ + 2 * j < 7]
+    xp, xmk = view_pair(B, To, H, W, Cc, dt, "tdy", 1)
+    yp, ymk = view_pair(B, Ti, H, W, Cc, dt, "tdx", 2)
+    wp = Pair((_rand("tdw", (7 * Cc * Cc,), 3, 0.05)).to(E.TORCH_DT[dt]))
+    taps = Pair(torch.tensor(rows, dtype=torch.int32))
+
+    def mk(side):
+        d = L.CConvDesc()
+        d.dtype, d.out_dtype, d.mode = dt, dt, 0
+        d.x, d.y = xmk(side).ct(), ymk(side).ct()
+        d.oT, d.oH, d.oW = To, H, W
+        d.sT = d.sH = d.sW = 1
+        d.omT, d.omH, d.omW = 2, 1, 1
+        d.ooT, d.ooH, d.ooW = r, 0, 0
+        d.ntaps, d.taps, d.w, d.Kp = len(rows), taps.ptr(side), wp.ptr(side), 64
+        d.pre = L.CAffine(None, None, 0)
+        d.accumulate = 1
+        d.tline, d.tpad = 1, -min(t[0] for t in rows)
+        return [C.byref(d), _stream() if side == "gpu" else 0]
+
+    assert lib.vinet_set_option(b"conv_ts", 2) == 0
+    try:
+        run_both("vinet_conv3d", mk)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_kernel_name(mk("gpu")[0], buf, 128) == 0 and buf.value.startswith(b"conv_ts_kernel<")
+    finally:
+        lib.vinet_set_option(b"conv_ts", 1)
+    _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "temporal dgrad phase")
+
+
 def _run_conv_case(case, dt, forced=False, want_y=False):
     name, (B, T, H, W), Cin, N, k, s, p, ex = case
     oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
@@ -241,6 +307,8 @@ def _run_conv_case(case, dt, forced=False, want_y=False):
         d.accumulate = 1 if ex.get("accumulate") else 0
         d.stats = stats.ptr(side) if ex.get("stats") else None
         d.n_valid = N if head else 0
+        if ex.get("tline"):
+            d.tline, d.tpad = 1, p[0]
         if ex.get("splitk") and side == "gpu":
             nb = _lib().vinet_conv3d_splitk_bytes(C.byref(d))
             assert nb >= 2 * M * Ny * 4, "split-K plan expected for " + name

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class CTensor(C.Structure):
@@ -35,7 +35,7 @@ class CConvDesc(C.Structure):
                 ("ntaps", C.c_int32), ("taps", C.c_void_p), ("w", C.c_void_p), ("Kp", C.c_int32),
                 ("pre", CAffine), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p),
                 ("act", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("n_valid", C.c_int32),
-                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64)]
+                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("tline", C.c_int32), ("tpad", C.c_int32)]
 
 
 class CWgradDesc(C.Structure):

@@ -1,0 +1,294 @@
+// Temporal conv (k x 1 x 1, stride (s,1,1)) with 64 input and 64 output channels as a frame-streaming kernel:
+// forward of the stem's partner, 64 -> 64 7x1x1 / 2 at 32 x 112 x 192 (model_utils.py:149), and each stride
+// phase of its data gradient (a stride-1 temporal correlation over dy with 3 or 4 taps).
+//
+//   y[b, to*om + oo, p, n] = act(scale[n] * sum_i sum_c w[slice_i][n][c] * pre(x[b, to*s + off_i, p])[c] + shift[n])
+//
+// conv_dma_kernel re-stages the input frame of every tap: k/s = 3.5 reads of x (9 GB of L2-miss traffic per launch
+// for 2.6 GB of tensors at 128 clips, 1.9 TB/s).  Here -- as in wgrad_ts.hip -- a workgroup owns 64 (h,w) positions
+// of one clip and walks the output frames with the k live input frames in an LDS ring: each input element is
+// fetched once (global -> registers -> pending BN+ReLU once -> LDS), each output element written once.
+//
+//   * 256 threads = 2 x 2 waves: wave (wm, wn) owns positions [32wm, 32wm+32) x output channels [32wn, 32wn+32);
+//     its slice of ALL k taps' weights lives in registers (k x 2 x 2 B-fragments = 112 VGPRs at k = 7), so the K
+//     loop reads only activations from LDS (ds_read_b128, rows of 128 B, chunk ^ (row & 7) swizzle);
+//   * epilogue per output frame: scale / shift / activation, BN partial sums (one row of `stats` per 64 positions:
+//     vinet_conv3d_tile_m reports 64), bf16 tile through LDS, 16-byte coalesced stores (optional read-modify-write);
+//   * the tap table is read on the device; the host only needs the caller's promise (VinetConvDesc::tline) that the
+//     taps are temporal and their offsets form the contiguous range [-tpad, -tpad + ntaps - 1].
+#include "common.h"
+
+struct ConvTsArgs {
+  const char* x;
+  char* y;
+  const char* w;
+  const int4* taps;
+  const float* in_scale;
+  const float* in_shift;
+  const float* out_scale;
+  const float* out_shift;
+  float* stats;
+  int Ti, To, HW, ldx, ldy;
+  long sBx, sBy;
+  int k, s, pad, omT, ooT, act, accumulate;
+  int items, patches;
+  FastDiv dPatches;
+};
+
+// MFMAs of this kernel: B (the weights) is read from the accumulator file -- the 112 weight registers do not fit in
+// the 128 architectural VGPRs the compiler budgets beside everything else, and gfx90a+ MFMAs read A / B from
+// either file.  Wherever the register allocator keeps a value, it may copy it (v_accvgpr_write / _read) right in
+// front of the inline-asm MFMA, a VALU-write -> MFMA-read hazard it cannot see through the asm: every MFMA
+// carries its own wait states.  (4 cycles x 56 MFMAs per output frame, against ~3000 cycles of HBM time.)
+VN_DEV void mfma_bf16_acc_bacc(f32x4_v& acc, const bf16x8_v& a, const bf16x8_v& b) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b));
+}
+// first MFMA of an output frame: C = 0 as an inline constant (early clobber: the result must not share registers
+// with B)
+VN_DEV void mfma_bf16_first_bacc(f32x4_v& acc, const bf16x8_v& a, const bf16x8_v& b) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "a"(b));
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
+  constexpr int KMAX = 7, TILE = 64 * 64 * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;                                   // KMAX frames [64 positions][64 channels]
+  char* stage = smem + KMAX * TILE;                    // output tile [64 positions][64 channels] bf16
+  float* red = (float*)(smem + (KMAX + 1) * TILE);     // [2 position halves][64 channels][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int k = a.k, s = a.s;
+
+  // load / store role: 16-byte piece (row = position, chunk = 8 channels), rows l_row and l_row + 32
+  const int l_chunk = tid & 7, l_row = tid >> 3;
+  int l_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = l_row + 32 * j;
+    l_off[j] = r * 128 + ((l_chunk ^ (r & 7)) * 16);
+  }
+  f32x2_v sc2[4], sh2[4];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc2[e] = (f32x2_v){a.in_scale[l_chunk * 8 + 2 * e], a.in_scale[l_chunk * 8 + 2 * e + 1]};
+      sh2[e] = (f32x2_v){a.in_shift[l_chunk * 8 + 2 * e], a.in_shift[l_chunk * 8 + 2 * e + 1]};
+    }
+  }
+  auto xform = [&](uint4 v) -> uint4 {
+    if constexpr (PRE) {
+      v.x = pre_relu_pair(v.x, sc2[0], sh2[0]); v.y = pre_relu_pair(v.y, sc2[1], sh2[1]);
+      v.z = pre_relu_pair(v.z, sc2[2], sh2[2]); v.w = pre_relu_pair(v.w, sc2[3], sh2[3]);
+    }
+    return v;
+  };
+
+  // ---- taps (scalar) and this wave's weights (registers) ------------------------------------------------
+  int rel[KMAX];                                       // tap i reads frame to*s - pad + rel[i]
+  bf16x8_v wr[KMAX][2][2];                             // [tap][n tile][k step]: B fragment = 8 channels of one n
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) {
+    rel[i] = 0;
+    if (i < k) {
+      const int4 tp = load_tap(a.taps, i);
+      rel[i] = tp.x + a.pad;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int n = wn * 32 + nt * 16 + (lane & 15), c = ks * 32 + (lane >> 4) * 8;
+          wr[i][nt][ks] = *(const bf16x8_v*)(a.w + (((long)tp.w * 64 + n) * 64 + c) * 2);
+        }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wr[i][nt][ks] = (bf16x8_v){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  // epilogue constants of this lane's two output channels
+  float osc[2], osh[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = wn * 32 + nt * 16 + (lane & 15);
+    osc[nt] = a.out_scale ? a.out_scale[n] : 1.f;
+    osh[nt] = a.out_shift ? a.out_shift[n] : 0.f;
+  }
+  const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;
+  const bool sigm = a.act == VINET_ACT_SIGMOID;
+
+  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const int b = (int)fdiv((uint32_t)item, a.dPatches);
+    const int patch = item - b * a.patches;
+    const int pos0 = patch * 64;
+    const char* xb = a.x + ((long)b * a.sBx + (long)(pos0 + l_row) * a.ldx + l_chunk * 8) * 2;
+    char* yb = a.y + ((long)b * a.sBy + (long)(pos0 + l_row) * a.ldy + l_chunk * 8) * 2;
+    const long x_plane = (long)a.HW * a.ldx * 2, y_plane = (long)a.HW * a.ldy * 2;
+    const long x_r32 = 32L * a.ldx * 2, y_r32 = 32L * a.ldy * 2;
+
+    // ---- prologue: the k frames of output frame 0 ----------------------------------------------------------
+    for (int g = 0; g < k; ++g) {
+      const int p = g - a.pad;
+      uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+      if ((unsigned)p < (unsigned)a.Ti) {
+        v0 = xform(*(const uint4*)(xb + p * x_plane));
+        v1 = xform(*(const uint4*)(xb + p * x_plane + x_r32));
+      }
+      char* slot = ring + ((p + 2 * KMAX) % k) * TILE;
+      *(uint4*)(slot + l_off[0]) = v0;
+      *(uint4*)(slot + l_off[1]) = v1;
+    }
+    __syncthreads();
+
+    for (int to = 0; to < a.To; ++to) {
+      // ---- loads of the next step's s new frames (named scalars, unconditional: see wgrad_ts.hip) ----------
+      const bool more = to + 1 < a.To;
+      const int pnew = (to + 1) * s - a.pad + k - s;
+      const bool in0 = more && (unsigned)pnew < (unsigned)a.Ti;
+      const bool in1 = more && s == 2 && (unsigned)(pnew + 1) < (unsigned)a.Ti;
+      const char* xs0 = xb + (in0 ? pnew : 0) * x_plane;
+      const char* xs1 = xb + (in1 ? pnew + 1 : 0) * x_plane;
+      const uint4 nx00 = *(const uint4*)xs0, nx01 = *(const uint4*)(xs0 + x_r32);
+      const uint4 nx10 = *(const uint4*)xs1, nx11 = *(const uint4*)(xs1 + x_r32);
+      char* yf = yb + (long)(to * a.omT + a.ooT) * y_plane;
+      uint4 old0 = make_uint4(0, 0, 0, 0), old1 = old0;
+      if (a.accumulate) { old0 = *(const uint4*)yf; old1 = *(const uint4*)(yf + y_r32); }
+
+      // ---- MFMAs ---------------------------------------------------------------------------------------------
+      f32x4_v acc[2][2];
+      const int s0 = (to * s - a.pad + 2 * KMAX) % k;
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        if (i < k) {
+          int si = s0 + rel[i];
+          si -= si >= k ? k : 0;
+          const char* fr = ring + si * TILE;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_v af[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const int row = wm * 32 + mt * 16 + (lane & 15), ch = ks * 4 + (lane >> 4);
+              af[mt] = *(const bf16x8_v*)(fr + row * 128 + ((ch ^ (row & 7)) * 16));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) {
+                if (i == 0 && ks == 0) mfma_bf16_first_bacc(acc[mt][nt], af[mt], wr[i][nt][ks]);
+                else mfma_bf16_acc_bacc(acc[mt][nt], af[mt], wr[i][nt][ks]);
+              }
+          }
+        }
+      }
+      mfma_drain();
+      // ---- epilogue: lane holds rows (lane>>4)*4 + r of each 16-row tile, column lane & 15 -------------------
+      float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = fmaf(acc[mt][nt][r], osc[nt], osh[nt]);
+            ssum[nt] += v; ssq[nt] += v * v;
+            float o = fmaxf(v, relu_floor);
+            if (sigm) o = 1.f / (1.f + __expf(-o));
+            const int row = wm * 32 + mt * 16 + (lane >> 4) * 4 + r, col = wn * 32 + nt * 16 + (lane & 15);
+            *(bf16_t*)(stage + row * 128 + (((col >> 3) ^ (row & 7)) * 16) + (col & 7) * 2) = f2bf(o);
+          }
+      if (a.stats) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          float ss = ssum[nt], qq = ssq[nt];
+          ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+          qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
+          if (lane < 16) {
+            const int col = wn * 32 + nt * 16 + lane;
+            red[(wm * 64 + col) * 2 + 0] = ss;
+            red[(wm * 64 + col) * 2 + 1] = qq;
+          }
+        }
+      }
+      __syncthreads();          // ring frames of this step are free, the output tile and the partial sums are complete
+      {
+        uint4 o0 = *(const uint4*)(stage + l_off[0]), o1 = *(const uint4*)(stage + l_off[1]);
+        if (a.accumulate) {
+          auto add2 = [](uint32_t p, uint32_t q) -> uint32_t {
+            return pack2bf(__uint_as_float(p << 16) + __uint_as_float(q << 16),
+                           __uint_as_float(p & 0xffff0000u) + __uint_as_float(q & 0xffff0000u));
+          };
+          o0 = make_uint4(add2(o0.x, old0.x), add2(o0.y, old0.y), add2(o0.z, old0.z), add2(o0.w, old0.w));
+          o1 = make_uint4(add2(o1.x, old1.x), add2(o1.y, old1.y), add2(o1.z, old1.z), add2(o1.w, old1.w));
+        }
+        *(uint4*)yf = o0;
+        *(uint4*)(yf + y_r32) = o1;
+      }
+      if (a.stats && tid < 64) {
+        const long row = ((long)b * a.To + to) * a.patches + patch;       // = m / 64 of the tile's first voxel
+        a.stats[(row * 2 + 0) * 64 + tid] = red[tid * 2] + red[(64 + tid) * 2];
+        a.stats[(row * 2 + 1) * 64 + tid] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+      }
+      if (more) {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        char* slot0 = ring + ((pnew + 2 * KMAX) % k) * TILE;
+        *(uint4*)(slot0 + l_off[0]) = in0 ? xform(nx00) : z;
+        *(uint4*)(slot0 + l_off[1]) = in0 ? xform(nx01) : z;
+        if (s == 2) {
+          char* slot1 = ring + ((pnew + 1 + 2 * KMAX) % k) * TILE;
+          *(uint4*)(slot1 + l_off[0]) = in1 ? xform(nx10) : z;
+          *(uint4*)(slot1 + l_off[1]) = in1 ? xform(nx11) : z;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int g_vinet_opt_conv_ts = 1;   // 0 = off, 2 = force on every eligible shape (tests)
+
+bool vinet_conv_use_ts(const VinetConvDesc* d) {
+  if (!g_vinet_opt_conv_ts || !d->tline || d->dtype != VINET_BF16 || d->out_dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
+  if (d->pre.scale && !(d->pre.relu && d->pre.shift)) return false;
+  if (d->pre.relu && !d->pre.scale) return false;
+  const long HW = (long)d->oH * d->oW;
+  const bool shape = d->x.C == 64 && d->y.C == 64 && (d->n_valid == 0 || d->n_valid == 64) && d->Kp == 64 && d->ntaps >= 2 && d->ntaps <= 7 &&
+                     (d->sT == 1 || d->sT == 2) && d->ntaps >= d->sT && d->sH == 1 && d->sW == 1 && d->omH == 1 && d->omW == 1 && d->ooH == 0 &&
+                     d->ooW == 0 && d->x.H == d->oH && d->x.W == d->oW && d->y.H == d->oH && d->y.W == d->oW && HW % 64 == 0 &&
+                     d->tpad >= 0 && d->tpad < d->ntaps && d->x.ld % 8 == 0 && d->y.ld % 8 == 0 && d->x.sB % 8 == 0 && d->y.sB % 8 == 0 &&
+                     ((uintptr_t)d->x.ptr % 16) == 0 && ((uintptr_t)d->y.ptr % 16) == 0;
+  if (!shape) return false;
+  if (g_vinet_opt_conv_ts >= 2) return true;
+  return (long)d->x.B * (HW / 64) >= 2048 && d->oT >= 4;
+}
+
+int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s) {
+  ConvTsArgs a;
+  a.x = (const char*)d->x.ptr; a.y = (char*)d->y.ptr; a.w = (const char*)d->w; a.taps = (const int4*)d->taps;
+  a.in_scale = d->pre.scale; a.in_shift = d->pre.shift;
+  a.out_scale = d->out_scale; a.out_shift = d->out_shift; a.stats = d->stats;
+  a.Ti = d->x.T; a.To = d->oT; a.HW = d->oH * d->oW; a.ldx = d->x.ld; a.ldy = d->y.ld; a.sBx = d->x.sB; a.sBy = d->y.sB;
+  a.k = d->ntaps; a.s = d->sT; a.pad = d->tpad; a.omT = d->omT; a.ooT = d->ooT; a.act = d->act; a.accumulate = d->accumulate;
+  VN_CHECK_ARG((d->oT - 1) * d->omT + d->ooT < d->y.T && d->ooT >= 0 && d->omT > 0, "conv_ts: output placement outside y");
+  a.patches = a.HW / 64;
+  a.items = d->x.B * a.patches;
+  a.dPatches = make_fastdiv((uint32_t)a.patches);
+  const int smem = 8 * 64 * 64 * 2 + 2 * 64 * 2 * 4;
+  auto kp = conv_ts_kernel<true>;
+  auto kn = conv_ts_kernel<false>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_ts): %s", hipGetErrorString(e)); return (int)e; }
+    attr_done[dev & 63] = true;
+  }
+  int grid = 512;
+  if (grid > a.items) grid = a.items;
+  if (d->pre.scale) hipLaunchKernelGGL(kp, dim3(grid), dim3(256), smem, s, a);
+  else hipLaunchKernelGGL(kn, dim3(grid), dim3(256), smem, s, a);
+  return vn_launch_status("conv_ts");
+}

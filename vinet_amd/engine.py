@@ -420,6 +420,8 @@ class ConvPlan:
         self.N, self.Cin = weight.shape[0], weight.shape[1]
         self.ntaps = self.k[0] * self.k[1] * self.k[2]
         self.stem = stem
+        # (k,1,1) kernel: tap kt is (kt - pT, 0, 0, kt)
+        self.temporal = self.k[1] == 1 and self.k[2] == 1 and self.p[1] == 0 and self.p[2] == 0 and self.s[1] == 1 and self.s[2] == 1
         if stem:
             assert self.k == (1, 7, 7) and self.Cin == 3 and self.p[2] == 3
         self._packs = {}
@@ -474,7 +476,10 @@ class ConvPlan:
                 full = False
                 continue
             key = ("dg", in_dims, rT, rH, rW)
-            phases.append(dict(taps=self._dev_taps(key, rows, device), ntaps=len(rows), Q=(QT, QH, QW), r=(rT, rH, rW)))
+            offs = sorted(r_[0] for r_ in rows)
+            tline = self.temporal and offs == list(range(offs[0], offs[0] + len(offs)))
+            phases.append(dict(taps=self._dev_taps(key, rows, device), ntaps=len(rows), Q=(QT, QH, QW), r=(rT, rH, rW),
+                               tline=1 if tline else 0, tpad=-offs[0] if tline else 0))
         covered = all(len(p_) == min(s, I) for p_, s, I in zip(per, self.s, in_dims))
         return phases, (full and covered)
 
@@ -547,6 +552,7 @@ class JointConvPlan(ConvPlan):
         self.weight, self.bias = None, None
         self.k, self.s, self.p = (1, 1, 1), (1, 1, 1), (0, 0, 0)
         self.N, self.Cin, self.ntaps, self.stem = sum(m.N for m in members), m0.Cin, 1, False
+        self.temporal = False
         self._packs, self._taps = {}, {}
 
     def _pack_stamp(self):
@@ -763,6 +769,8 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     d.pre = x.affine()
     d.accumulate = 0
     d.n_valid = plan.N if Ny != plan.N else 0
+    if not folded and not plan.stem and plan.temporal:
+        d.tline, d.tpad = 1, plan.p[0]      # promise to the library (it cannot read the device-side tap table)
     M = xv.B * oT * oH * oW
     site = plan.site(xv)
     es = ESIZE[lib_dt]
@@ -908,7 +916,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                 wd.pre = x.affine()
                 # a purely temporal kernel (k,1,1): tap kt is (kt - pad, 0, 0, kt) -- the library cannot read the
                 # device-side tap table, so the geometry is promised here (include/vinet_hip.h: tline)
-                if not folded and not plan.stem and plan.k[1] == 1 and plan.k[2] == 1 and plan.p[1] == 0 and plan.p[2] == 0:
+                if not folded and not plan.stem and plan.temporal:
                     wd.tline, wd.tpad = 1, plan.p[0]
                 es = ESIZE[ctx.dt]
                 ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
@@ -941,6 +949,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             d.out_scale = d.out_shift = None
             d.act, d.accumulate, d.stats = L.ACT_NONE, acc, None
             d.n_valid = plan.Cin if xv.C != plan.Cin else 0
+            d.tline, d.tpad = ph["tline"], ph["tpad"]
             es = ESIZE[ctx.dt]
             nph = len(phases)
             ctx.call("vinet_conv3d", C.byref(d), ctx.stream,
