@@ -149,7 +149,9 @@ typedef struct VinetWgradDesc {
   VinetAffine pre;
   int32_t tline;        /* 1 = the caller promises a purely temporal kernel: tap kt is (kt - tpad, 0, 0, slice kt),
                            kt = 0..ntaps-1 (the tap table lives in device memory, the library cannot look);
-                           lets 64 -> 64 channel layers take the frame-streaming kernel.  0 = no promise. */
+                           lets 64 -> 64 channel layers take the frame-streaming kernel.
+                           2 = the taps are (0, kh, 0, slice kh), kh = 0..6: the folded RGB stem (row-streaming strip
+                           kernel).  0 = no promise. */
   int32_t tpad;
 } VinetWgradDesc;
 

@@ -371,7 +371,7 @@ def test_conv3d_stem_mode(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("hw", [(18, 22), (17, 23), (32, 48)])
+@pytest.mark.parametrize("hw", [(18, 22), (17, 23), (32, 48), (20, 128), (16, 256)])
 def test_stem_folded(dt, hw):
     """padded import + overlapped [.., (W+8)/2, C=32] ld=8 view: the stem as a generic 7-tap conv,
     forward and weight gradient, vs the emulator and (fp32) torch's conv3d"""
@@ -450,6 +450,21 @@ def test_stem_folded(dt, hw):
         finally:
             lib.vinet_set_option(b"wgrad_tg", 0)
         _cmp(dw.get("gpu"), dw.get("cpu"), 2e-2, "folded stem wgrad (32-channel tile)")
+        if oW % 64 == 0:
+            # the row-streaming strip kernel of the real stem (wgrad_hs.hip); the caller promises the tap geometry
+            def mkw_hs(side):
+                args = mkw(side)
+                args[0]._obj.tline = 2
+                return args
+            lib.vinet_set_option(b"wgrad_hs", 2)
+            try:
+                dw.gpu.zero_()
+                dw.cpu.zero_()
+                run_both("vinet_conv3d_wgrad", mkw_hs)
+                assert lib.vinet_conv3d_wgrad_kernel_name(mkw_hs("gpu")[0], nbuf, 128) == 0 and nbuf.value == b"conv_wgrad_hs_kernel"
+            finally:
+                lib.vinet_set_option(b"wgrad_hs", 1)
+            _cmp(dw.get("gpu"), dw.get("cpu"), 2e-2, "folded stem wgrad (row-streaming strips)")
 
 
 @pytest.mark.parametrize("dt", DTS)

@@ -118,6 +118,7 @@ static bool use_pp(const VinetConvDesc* d);
 bool vinet_conv_use_ts(const VinetConvDesc* d);
 int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s);
 extern int g_vinet_opt_conv_ts;
+extern int g_vinet_opt_wgrad_hs;
 
 extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   if (!d) return -1;
@@ -152,6 +153,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
   if (name && !strcmp(name, "wgrad_dma")) { g_vinet_opt_wgrad_dma = value; return 0; }
   if (name && !strcmp(name, "conv_ts")) { g_vinet_opt_conv_ts = value; return 0; }
+  if (name && !strcmp(name, "wgrad_hs")) { g_vinet_opt_wgrad_hs = value; return 0; }
   if (name && !strcmp(name, "wgrad_ts")) { g_vinet_opt_wgrad_ts = value; return 0; }
   if (name && !strcmp(name, "wgrad_tg")) { g_vinet_opt_wgrad_tg = value; return 0; }
   vinet_set_error("set_option: unknown option %s", name ? name : "(null)");

@@ -918,6 +918,8 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                 # device-side tap table, so the geometry is promised here (include/vinet_hip.h: tline)
                 if not folded and not plan.stem and plan.temporal:
                     wd.tline, wd.tpad = 1, plan.p[0]
+                elif folded:
+                    wd.tline = 2        # taps (0, kh, 0, kh): ConvPlan.folded_taps
                 es = ESIZE[ctx.dt]
                 ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
                          tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
