@@ -115,7 +115,9 @@ typedef struct VinetConvDesc {
   int32_t tline;        /* 1 = the caller promises a purely temporal kernel: every tap is (dt, 0, 0, slice) and the
                            dt form the contiguous range [-tpad, -tpad + ntaps - 1] in any order (the tap table is
                            device memory, the library cannot look); lets 64 -> 64 channel layers take the
-                           frame-streaming kernel (conv_ts.hip).  0 = no promise. */
+                           frame-streaming kernel (conv_ts.hip).
+                           2 = the taps are (0, kh, 0, slice kh), kh = 0..6: the folded RGB stem (row-streaming strip
+                           kernel, conv_hs.hip).  0 = no promise. */
   int32_t tpad;
 } VinetConvDesc;
 

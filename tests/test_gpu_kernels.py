@@ -418,6 +418,40 @@ def test_stem_folded(dt, hw):
 
     run_both("vinet_conv3d", mk)
     _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "folded stem conv")
+    if dt == E.BF16 and oW % 64 == 0:
+        # the row-streaming strip kernel of the real stem (conv_hs.hip), with statistics and a folded-BN epilogue
+        lib = _lib()
+        os_, oh_ = fvec("sfos", N, 6, 0.5, 1.5), fvec("sfoh", N, 7)
+        M = B * T * oH * oW
+        for with_stats in (True, False):
+            stats = Pair(torch.zeros((M // 64) * 2 * N))
+
+            def mk_hs(side):
+                args = mk(side)
+                d = args[0]._obj
+                d.tline = 2
+                if with_stats:
+                    d.stats = stats.ptr(side)
+                else:
+                    d.out_scale, d.out_shift, d.act = os_.ptr(side), oh_.ptr(side), 1
+                return args
+            lib.vinet_set_option(b"conv_hs", 2)
+            try:
+                run_both("vinet_conv3d", mk_hs)
+                nbuf = C.create_string_buffer(128)
+                d0 = mk_hs("gpu")[0]._obj
+                assert lib.vinet_conv3d_kernel_name(C.byref(d0), nbuf, 128) == 0 and nbuf.value == b"conv_hs_kernel"
+                assert lib.vinet_conv3d_tile_m(C.byref(d0)) == 64
+                bm_cpu = AbiEmulator().vinet_conv3d_tile_m(d0)
+            finally:
+                lib.vinet_set_option(b"conv_hs", 1)
+            _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "folded stem conv (row-streaming strips)")
+            if with_stats:
+                sg = stats.get("gpu").view(M // 64, 2, N).double().sum(0)
+                rc = (M + bm_cpu - 1) // bm_cpu
+                sc = stats.get("cpu")[:rc * 2 * N].view(rc, 2, N).double().sum(0)
+                _cmp(sg, sc, 2e-2, "folded stem conv stats")
+        run_both("vinet_conv3d", mk)      # (restore y for the checks below)
     if dt == E.F32:
         ref = torch.nn.functional.conv3d(src.cpu, wm.view(N, 3, 1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3))
         _cmp(yp.get("gpu").view(B, T, oH, oW, N).permute(0, 4, 1, 2, 3), ref, 2e-5, "folded stem vs torch")

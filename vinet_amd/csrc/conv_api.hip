@@ -116,13 +116,16 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
 
 static bool use_pp(const VinetConvDesc* d);
 bool vinet_conv_use_ts(const VinetConvDesc* d);
+bool vinet_conv_use_hs(const VinetConvDesc* d);
+int vinet_launch_conv_hs(const VinetConvDesc* d, hipStream_t s);
+extern int g_vinet_opt_conv_hs;
 int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s);
 extern int g_vinet_opt_conv_ts;
 extern int g_vinet_opt_wgrad_hs;
 
 extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   if (!d) return -1;
-  if (vinet_conv_use_ts(d)) return 64;
+  if (vinet_conv_use_ts(d) || vinet_conv_use_hs(d)) return 64;
   if (use_pp(d)) return 256;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32)).BM();
@@ -152,6 +155,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
   if (name && !strcmp(name, "wgrad_dma")) { g_vinet_opt_wgrad_dma = value; return 0; }
+  if (name && !strcmp(name, "conv_hs")) { g_vinet_opt_conv_hs = value; return 0; }
   if (name && !strcmp(name, "conv_ts")) { g_vinet_opt_conv_ts = value; return 0; }
   if (name && !strcmp(name, "wgrad_hs")) { g_vinet_opt_wgrad_hs = value; return 0; }
   if (name && !strcmp(name, "wgrad_ts")) { g_vinet_opt_wgrad_ts = value; return 0; }
@@ -196,7 +200,7 @@ int g_vinet_opt_splitk = 1;     // 0 = off; n >= 2 = tuning: minimum K chunks (o
 struct SplitK { int splits, per; long bytes; };
 static SplitK splitk_plan(const VinetConvDesc* d) {
   SplitK p{1, 0, 0};
-  if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || vinet_conv_use_ts(d) || d->stats || d->accumulate) return p;
+  if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || vinet_conv_use_ts(d) || vinet_conv_use_hs(d) || d->stats || d->accumulate) return p;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const int nchunks = d->ntaps * (d->Kp / 32);
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, nchunks);
@@ -250,7 +254,8 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   if (!d || !buf || n <= 0) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32));
-  if (vinet_conv_use_ts(d)) snprintf(buf, n, "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
+  if (vinet_conv_use_hs(d)) snprintf(buf, n, "conv_hs_kernel");
+  else if (vinet_conv_use_ts(d)) snprintf(buf, n, "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
   else if (use_pp(d)) snprintf(buf, n, "conv_pp_kernel<%d>", pp_bn(d->y.C));
   else if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
   else snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", t.MT, t.NT, t.WM, t.WN, d->mode);
@@ -262,6 +267,7 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
   ConvTile t;
   int rc = fill_args(d, a, t);
   if (rc) return rc;
+  if (vinet_conv_use_hs(d)) return vinet_launch_conv_hs(d, (hipStream_t)stream);
   if (vinet_conv_use_ts(d)) return vinet_launch_conv_ts(d, (hipStream_t)stream);
   if (use_pp(d)) {
     const int bn = pp_bn(a.N);

@@ -1,0 +1,199 @@
+// Forward of the RGB stem (3 -> 64, 1x7x7, stride (1,2,2), model_utils.py:144) over the folded view of the zero-padded
+// 4-channel clip (see wgrad_hs.hip for the view): a persistent workgroup owns a 64-wide column strip of one frame
+// and walks the output rows with the 7 live input rows (1072 B each) in an LDS ring -- 2 new rows per step, every
+// input byte fetched once, and the overlapped view is just overlapping ds_read_b128 addresses (position v starts
+// 16 bytes after position v-1).  conv_dma_kernel staged seven 64-byte-row tiles per 256 positions (1.7 TB/s).
+//
+//   y[b,t,ho,wo,n] = act(scale[n] * sum_kh sum_j w[kh][n][j] * x[b,t,2ho+kh, 16 B * wo + j] + shift[n]),  j = kw*4 + c
+//
+//   * 2 x 2 waves, wave (wm, wn) = positions [32wm, +32) x channels [32wn, +32); its slice of all 7 rows' weights in
+//     registers (14 B-fragments, read from the accumulator file as in conv_ts.hip);
+//   * per output row: scale / shift / activation, BN partial sums (one `stats` row per 64 positions), bf16 tile
+//     through LDS, 16-byte coalesced stores;
+//   * the padded image makes every access in range: no bounds checks.
+#include "common.h"
+
+struct ConvHsArgs {
+  const char* x;
+  char* y;
+  const char* w;
+  const float* out_scale;
+  const float* out_shift;
+  float* stats;
+  long sBx, sBy;
+  int T, Hp, Wv, ldx;
+  int oH, oW, ldy, act;
+  int items, strips;
+  FastDiv dStrips, dT;
+};
+
+// MFMAs (see conv_ts.hip): B (the weights) is read from the accumulator file -- the 112 weight registers do not fit in
+// the 128 architectural VGPRs the compiler budgets beside everything else, and gfx90a+ MFMAs read A / B from
+// either file.  Wherever the register allocator keeps a value, it may copy it (v_accvgpr_write / _read) right in
+// front of the inline-asm MFMA, a VALU-write -> MFMA-read hazard it cannot see through the asm: every MFMA
+// carries its own wait states.  (4 cycles x 56 MFMAs per output frame, against ~3000 cycles of HBM time.)
+VN_DEV void mfma_hs_acc(f32x4_v& acc, const bf16x8_v& a, const bf16x8_v& b) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b));
+}
+// first MFMA of an output frame: C = 0 as an inline constant (early clobber: the result must not share registers
+// with B)
+VN_DEV void mfma_hs_first(f32x4_v& acc, const bf16x8_v& a, const bf16x8_v& b) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "a"(b));
+}
+
+__global__ __launch_bounds__(256, 2) void conv_hs_kernel(const ConvHsArgs a) {
+  constexpr int ROW = 1088, NP = 67, TILE = 64 * 64 * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* stage = smem;                                  // output tile [64 positions][64 channels] bf16
+  float* red = (float*)(smem + TILE);                  // [2 position halves][64 channels][2]
+  char* ring = smem + TILE + 1024;                     // 7 input rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l_chunk = tid & 7, l_row = tid >> 3;
+  int l_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = l_row + 32 * j;
+    l_off[j] = r * 128 + ((l_chunk ^ (r & 7)) * 16);
+  }
+  const bool xl = tid < 2 * NP;
+  const int x_r = tid >= NP ? 1 : 0, x_p = tid - x_r * NP;
+
+  bf16x8_v wr[7][2];
+#pragma unroll
+  for (int g = 0; g < 7; ++g)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = wn * 32 + nt * 16 + (lane & 15);
+      wr[g][nt] = *(const bf16x8_v*)(a.w + (((long)g * 64 + n) * 32 + (lane >> 4) * 8) * 2);
+    }
+  float osc[2], osh[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = wn * 32 + nt * 16 + (lane & 15);
+    osc[nt] = a.out_scale ? a.out_scale[n] : 1.f;
+    osh[nt] = a.out_shift ? a.out_shift[n] : 0.f;
+  }
+  const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;
+  const bool sigm = a.act == VINET_ACT_SIGMOID;
+
+  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const int bt = (int)fdiv((uint32_t)item, a.dStrips);
+    const int strip = item - bt * a.strips;
+    const int wo0 = strip * 64;
+    const int b = (int)fdiv((uint32_t)bt, a.dT);
+    const int t = bt - b * a.T;
+    const char* xrow0 = a.x + ((long)b * a.sBx + ((long)t * a.Hp * a.Wv + wo0) * (long)a.ldx) * 2;
+    const long x_rowb = (long)a.Wv * a.ldx * 2;
+    char* yb = a.y + ((long)b * a.sBy + ((long)t * a.oH * a.oW + wo0 + l_row) * (long)a.ldy + l_chunk * 8) * 2;
+    const long y_rowb = (long)a.oW * a.ldy * 2, y_r32 = 32L * a.ldy * 2;
+
+    for (int q = tid; q < 7 * NP; q += 256) {
+      const int h = q / NP, pc = q - h * NP;
+      *(uint4*)(ring + h * ROW + pc * 16) = *(const uint4*)(xrow0 + h * x_rowb + pc * 16);
+    }
+    __syncthreads();
+
+    for (int ho = 0; ho < a.oH; ++ho) {
+      const bool more = ho + 1 < a.oH;
+      const int hn = more ? 2 * ho + 7 + x_r : 0;
+      const uint4 nx = *(const uint4*)(xrow0 + hn * x_rowb + (xl ? x_p : 0) * 16);
+
+      f32x4_v acc[2][2];
+      const int s0 = (2 * ho) % 7;
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+        const int si = s0 + g - (s0 + g >= 7 ? 7 : 0);
+        const char* row = ring + si * ROW;
+        bf16x8_v af[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int v = wm * 32 + mt * 16 + (lane & 15);
+          af[mt] = *(const bf16x8_v*)(row + v * 16 + (lane >> 4) * 16);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            if (g == 0) mfma_hs_first(acc[mt][nt], af[mt], wr[g][nt]);
+            else mfma_hs_acc(acc[mt][nt], af[mt], wr[g][nt]);
+          }
+      }
+      mfma_drain();
+      float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = fmaf(acc[mt][nt][r], osc[nt], osh[nt]);
+            ssum[nt] += v; ssq[nt] += v * v;
+            float o = fmaxf(v, relu_floor);
+            if (sigm) o = 1.f / (1.f + __expf(-o));
+            const int row = wm * 32 + mt * 16 + (lane >> 4) * 4 + r, col = wn * 32 + nt * 16 + (lane & 15);
+            *(bf16_t*)(stage + row * 128 + (((col >> 3) ^ (row & 7)) * 16) + (col & 7) * 2) = f2bf(o);
+          }
+      if (a.stats) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          float ss = ssum[nt], qq = ssq[nt];
+          ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+          qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
+          if (lane < 16) {
+            const int col = wn * 32 + nt * 16 + lane;
+            red[(wm * 64 + col) * 2 + 0] = ss;
+            red[(wm * 64 + col) * 2 + 1] = qq;
+          }
+        }
+      }
+      __syncthreads();
+      {
+        char* yf = yb + ho * y_rowb;
+        *(uint4*)yf = *(const uint4*)(stage + l_off[0]);
+        *(uint4*)(yf + y_r32) = *(const uint4*)(stage + l_off[1]);
+      }
+      if (a.stats && tid < 64) {
+        const long row = ((long)bt * a.oH + ho) * a.strips + strip;      // = m / 64 of the tile's first voxel
+        a.stats[(row * 2 + 0) * 64 + tid] = red[tid * 2] + red[(64 + tid) * 2];
+        a.stats[(row * 2 + 1) * 64 + tid] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+      }
+      if (more && xl) *(uint4*)(ring + ((2 * ho + 7 + x_r) % 7) * ROW + x_p * 16) = nx;
+      __syncthreads();
+    }
+  }
+}
+
+int g_vinet_opt_conv_hs = 1;   // 0 = off, 2 = force on every eligible shape (tests)
+
+// VinetConvDesc::tline == 2: the caller promises taps (0, kh, 0, slice kh), kh = 0..6 (the folded stem)
+bool vinet_conv_use_hs(const VinetConvDesc* d) {
+  if (!g_vinet_opt_conv_hs || d->tline != 2 || d->dtype != VINET_BF16 || d->out_dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
+  if (d->pre.scale || d->pre.relu || d->accumulate) return false;
+  const bool shape = d->x.C == 32 && d->x.ld == 8 && d->Kp == 32 && d->ntaps == 7 && d->sT == 1 && d->sH == 2 && d->sW == 1 &&
+                     d->y.C == 64 && (d->n_valid == 0 || d->n_valid == 64) && d->oW % 64 == 0 && d->oT == d->x.T && d->x.W >= d->oW + 3 &&
+                     d->x.H >= 2 * d->oH + 5 && d->omT == 1 && d->omH == 1 && d->omW == 1 && d->ooT == 0 && d->ooH == 0 && d->ooW == 0 &&
+                     d->y.T == d->oT && d->y.H == d->oH && d->y.W == d->oW && d->y.ld % 8 == 0 && d->y.sB % 8 == 0 && d->x.sB % 8 == 0 &&
+                     ((uintptr_t)d->x.ptr % 16) == 0 && ((uintptr_t)d->y.ptr % 16) == 0;
+  if (!shape) return false;
+  if (g_vinet_opt_conv_hs >= 2) return true;
+  return (long)d->x.B * d->oT * (d->oW / 64) >= 2048 && d->oH >= 8;
+}
+
+int vinet_launch_conv_hs(const VinetConvDesc* d, hipStream_t s) {
+  ConvHsArgs a;
+  a.x = (const char*)d->x.ptr; a.y = (char*)d->y.ptr; a.w = (const char*)d->w;
+  a.out_scale = d->out_scale; a.out_shift = d->out_shift; a.stats = d->stats;
+  a.sBx = d->x.sB; a.sBy = d->y.sB;
+  a.T = d->x.T; a.Hp = d->x.H; a.Wv = d->x.W; a.ldx = d->x.ld;
+  a.oH = d->oH; a.oW = d->oW; a.ldy = d->y.ld; a.act = d->act;
+  a.strips = a.oW / 64;
+  a.items = d->x.B * a.T * a.strips;
+  a.dStrips = make_fastdiv((uint32_t)a.strips);
+  a.dT = make_fastdiv((uint32_t)a.T);
+  const int smem = 64 * 64 * 2 + 1024 + 7 * 1088;
+  int grid = 768;     // 3 workgroups per CU (152 registers, 17 KB of LDS)
+  if (grid > a.items) grid = a.items;
+  hipLaunchKernelGGL(conv_hs_kernel, dim3(grid), dim3(256), smem, s, a);
+  return vn_launch_status("conv_hs");
+}

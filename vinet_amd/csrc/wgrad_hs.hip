@@ -172,7 +172,7 @@ int vinet_launch_wgrad_hs(const VinetWgradDesc* d, hipStream_t s) {
   a.dStrips = make_fastdiv((uint32_t)a.strips);
   a.dT = make_fastdiv((uint32_t)a.T);
   const int smem = 2 * 64 * 64 * 2 + 7 * 1088;
-  int grid = 512;
+  int grid = 768;     // 3 workgroups per CU (130 registers, 24 KB of LDS)
   if (grid > a.items) grid = a.items;
   hipLaunchKernelGGL(conv_wgrad_hs_kernel, dim3(grid), dim3(256), smem, s, a);
   return vn_launch_status("conv_wgrad_hs");

@@ -771,6 +771,8 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     d.n_valid = plan.N if Ny != plan.N else 0
     if not folded and not plan.stem and plan.temporal:
         d.tline, d.tpad = 1, plan.p[0]      # promise to the library (it cannot read the device-side tap table)
+    elif folded:
+        d.tline = 2                         # taps (0, kh, 0, kh): ConvPlan.folded_taps
     M = xv.B * oT * oH * oW
     site = plan.site(xv)
     es = ESIZE[lib_dt]
