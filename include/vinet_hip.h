@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 5
+#define VINET_ABI_VERSION 6
 
 enum { VINET_F32 = 0, VINET_BF16 = 1 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
@@ -155,9 +155,26 @@ typedef struct VinetWgradDesc {
                            2 = the taps are (0, kh, 0, slice kh), kh = 0..6: the folded RGB stem (row-streaming strip
                            kernel).  0 = no promise. */
   int32_t tpad;
+  /* Optional fused BatchNorm(+ReLU) backward.  With bnb_z != NULL, `dy` is the gradient w.r.t. the OUTPUT of the
+   * BatchNorm that follows this conv, bnb_z the raw conv output (same B/T/H/W/C as dy), and the kernel forms
+   *   dz = scale * (dy * mask - c1 - (z - mean) * invstd * c2)        (vinet_bn_bwd_apply's arithmetic, rounded to
+   * the activation dtype) on the fly instead of reading a stored dz: for a conv whose input needs no gradient (the
+   * RGB stem) dz has no other consumer, so the apply pass (2 reads + 1 write of the layer's largest tensor) and
+   * the wgrad's own read of dz become 2 reads.  Only kernels that say so support it: ask
+   * vinet_conv3d_wgrad_fuses_bn_bwd(desc) first; vinet_conv3d_wgrad rejects the descriptor otherwise. */
+  const void* bnb_z;
+  int32_t bnb_ld;
+  int64_t bnb_sB;
+  VinetAffine bnb_fwd;           /* forward scale / shift / relu of that BatchNorm */
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_c1;
+  const float* bnb_c2;
 } VinetWgradDesc;
 
 int vinet_conv3d_wgrad(const VinetWgradDesc* desc, void* stream);
+/* 1 if vinet_conv3d_wgrad would apply desc->bnb_* itself for this problem (fill the bnb_* fields before asking). */
+int vinet_conv3d_wgrad_fuses_bn_bwd(const VinetWgradDesc* desc);
 int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* desc, char* buf, int32_t n);
 
 /* fp32 torch-layout master weights [N][Cin][ntaps] -> packed compute weights.

@@ -170,6 +170,11 @@ class AbiEmulator:
     def vinet_conv3d_wgrad_kernel_name(self, d, buf, n):
         return 0
 
+    def vinet_conv3d_wgrad_fuses_bn_bwd(self, d):
+        d = _deref(d)
+        # (as the library: only the folded-stem strip kernel; no size threshold here so that the CPU tests cover it)
+        return 1 if (d.bnb_z and d.tline == 2 and d.dtype == BF16 and not d.pre.scale) else 0
+
     def _taps(self, d):
         return np.ctypeslib.as_array((C.c_int32 * (4 * d.ntaps)).from_address(d.taps)).reshape(-1, 4)
 
@@ -233,6 +238,14 @@ class AbiEmulator:
         self.calls.append("wgrad")
         x = affine(rd(d.x, d.dtype), d.pre, d.x.C)
         dy = rd(d.dy, d.dtype)
+        if d.bnb_z:     # fused BN backward: dy is the gradient behind the BatchNorm, bnb_z the raw conv output
+            assert self.vinet_conv3d_wgrad_fuses_bn_bwd(d)
+            zt = L.CTensor(d.bnb_z, d.dy.B, d.dy.T, d.dy.H, d.dy.W, d.dy.C, d.bnb_ld, d.bnb_sB)
+            g, xhat = self._bn_bwd_terms(d.dy, zt, d.dtype, d.bnb_fwd, d.bnb_mean, d.bnb_invstd)
+            Cc = d.dy.C
+            dy = _f32(d.bnb_fwd.scale, Cc) * (g - _f32(d.bnb_c1, Cc) - xhat * _f32(d.bnb_c2, Cc))
+            if d.dtype != F32:
+                dy = _bf2f(_f2bf(dy.reshape(-1))).reshape(dy.shape)
         B, oT, oH, oW, N = dy.shape
         taps = self._taps(d)
         nsl = int(taps[:, 3].max()) + 1

@@ -499,6 +499,29 @@ def test_stem_folded(dt, hw):
             finally:
                 lib.vinet_set_option(b"wgrad_hs", 1)
             _cmp(dw.get("gpu"), dw.get("cpu"), 2e-2, "folded stem wgrad (row-streaming strips)")
+            # ... with the BatchNorm(+ReLU) backward of the stem's BN applied to the dz operand on the fly
+            zp, zmk = view_pair(B, T, oH, oW, N, dt, "sfz", 8)
+            f_sc, f_sh = fvec("sffs", N, 9, 0.5, 1.5), fvec("sffh", N, 10)
+            mu, istd = fvec("sfmu", N, 11), fvec("sfis", N, 12, 0.5, 2.0)
+            c1, c2 = fvec("sfc1", N, 13, -0.1, 0.1), fvec("sfc2", N, 14, -0.1, 0.1)
+
+            def mkw_bnb(side):
+                args = mkw_hs(side)
+                d = args[0]._obj
+                zv = zmk(side)
+                d.bnb_z, d.bnb_ld, d.bnb_sB = zv.ptr(), zv.ld, zv.sB
+                d.bnb_fwd = L.CAffine(f_sc.ptr(side), f_sh.ptr(side), 1)
+                d.bnb_mean, d.bnb_invstd, d.bnb_c1, d.bnb_c2 = mu.ptr(side), istd.ptr(side), c1.ptr(side), c2.ptr(side)
+                return args
+            lib.vinet_set_option(b"wgrad_hs", 2)
+            try:
+                assert lib.vinet_conv3d_wgrad_fuses_bn_bwd(mkw_bnb("gpu")[0]) == 1
+                dw.gpu.zero_()
+                dw.cpu.zero_()
+                run_both("vinet_conv3d_wgrad", mkw_bnb)
+            finally:
+                lib.vinet_set_option(b"wgrad_hs", 1)
+            _cmp(dw.get("gpu"), dw.get("cpu"), 2e-2, "folded stem wgrad with fused BN backward")
 
 
 @pytest.mark.parametrize("dt", DTS)

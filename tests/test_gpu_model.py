@@ -202,6 +202,34 @@ def test_mixed_joint_entry_equals_per_conv(mode, dt):
         assert float((a - b).abs().max()) <= tol * scale
 
 
+def test_stem_strip_kernels_and_fused_bn_backward():
+    """the RGB stem block with the row-streaming strip kernels forced (forward, weight gradient with the BN-backward
+    apply folded in) against the generic kernels + separate apply pass: same outputs, gradients, running statistics"""
+    from vinet_amd import model_utils as MU
+    lib = L.load()
+    res = []
+    for fast in (1, 0):
+        E.BN_BWD_FUSE = fast
+        for name in (b"conv_hs", b"wgrad_hs"):
+            assert lib.vinet_set_option(name, 2 if fast else 0) == 0
+        try:
+            torch.manual_seed(5)
+            blk = MU.SepConv3d(3, 64, kernel_size=7, stride=2, padding=3).cuda()
+            blk.compute_dtype = E.BF16
+            blk.train()
+            x = synth.uniform("stx", (2, 3, 4, 32, 128), 5, -1.0, 1.0).cuda()
+            y = blk(x)
+            (y * synth.uniform("stg", tuple(y.shape), 6, -1.0, 1.0).cuda()).sum().backward()
+            res.append([y.detach()] + [p.grad for p in blk.parameters()] + [b.float() for b in blk.buffers()])
+        finally:
+            E.BN_BWD_FUSE = 1
+            for name in (b"conv_hs", b"wgrad_hs"):
+                lib.vinet_set_option(name, 1)
+    for a, b in zip(*res):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 3e-2 * scale
+
+
 def test_graphed_inference_matches_eager():
     """hipGraph replay of the forward == eager forward, and survives new inputs"""
     from vinet_amd import model as VM

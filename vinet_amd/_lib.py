@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class CTensor(C.Structure):
@@ -42,7 +42,9 @@ class CWgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("mode", C.c_int32), ("x", CTensor), ("dy", CTensor),
                 ("sT", C.c_int32), ("sH", C.c_int32), ("sW", C.c_int32),
                 ("ntaps", C.c_int32), ("taps", C.c_void_p), ("dw", C.c_void_p), ("Kp", C.c_int32), ("pre", CAffine),
-                ("tline", C.c_int32), ("tpad", C.c_int32)]
+                ("tline", C.c_int32), ("tpad", C.c_int32),
+                ("bnb_z", C.c_void_p), ("bnb_ld", C.c_int32), ("bnb_sB", C.c_int64), ("bnb_fwd", CAffine),
+                ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p), ("bnb_c1", C.c_void_p), ("bnb_c2", C.c_void_p)]
 
 
 class CPoolDesc(C.Structure):
@@ -71,6 +73,7 @@ SIGNATURES = {
     "vinet_channel_stats": [_PT, _i32, _vp, _vp],
     "vinet_stats_rows": [_PT],
     "vinet_bn_bwd_reduce": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp],
+    "vinet_conv3d_wgrad_fuses_bn_bwd": [_PW],
     "vinet_bn_partials_fold": [_vp, _i32, _i32, _vp, _i32, _vp],
     "vinet_bn_bwd_finalize": [_vp, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "vinet_bn_bwd_apply": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp, _PT, _vp],

@@ -256,7 +256,7 @@ static bool wgrad_use_dma(const VinetWgradDesc* d) {
 
 extern "C" int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* d, char* buf, int32_t n) {
   if (!d || !buf || n <= 0) return -1;
-  if (vinet_wgrad_use_hs(d)) { snprintf(buf, n, "conv_wgrad_hs_kernel"); return 0; }
+  if (vinet_wgrad_use_hs(d)) { snprintf(buf, n, d->bnb_z ? "conv_wgrad_hs_kernel<bn_bwd>" : "conv_wgrad_hs_kernel"); return 0; }
   if (vinet_wgrad_use_ts(d)) { snprintf(buf, n, "conv_wgrad_ts_kernel<%s>", d->pre.scale ? "pre" : "plain"); return 0; }
   if (wgrad_use_dma(d) && vinet_wgrad_use_pp(d)) { snprintf(buf, n, "conv_wgrad_pp_kernel<%s,%d>", d->pre.scale ? "pre" : "plain", vinet_wgrad_pp_rows(d->dy.C)); return 0; }
   if (wgrad_use_dma(d)) return vinet_wgrad_dma_name(d, buf, n);
@@ -264,8 +264,13 @@ extern "C" int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* d, char* buf
   return 0;
 }
 
+extern "C" int vinet_conv3d_wgrad_fuses_bn_bwd(const VinetWgradDesc* d) {
+  return d && d->bnb_z && vinet_wgrad_use_hs(d) ? 1 : 0;
+}
+
 extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   VN_CHECK_ARG(d != nullptr, "wgrad: null descriptor");
+  VN_CHECK_ARG(!d->bnb_z || vinet_conv3d_wgrad_fuses_bn_bwd(d), "wgrad: fused BN backward requested for a problem whose kernel cannot apply it");
   VN_CHECK_ARG(d->dtype == VINET_F32 || d->dtype == VINET_BF16, "wgrad: bad dtype %d", d->dtype);
   const int eg = d->dtype == VINET_F32 ? 4 : 8;
   VN_CHECK_ARG(vn_tensor_ok(d->x, d->mode == VINET_CONV_STEM ? 4 : eg, true), "wgrad: bad x view");

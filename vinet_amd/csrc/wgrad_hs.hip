@@ -28,10 +28,16 @@ struct WgradHsArgs {
   int oH, oW, ldy;
   int items, strips;           // items = B * T * strips, strips = oW / 64
   FastDiv dStrips, dT;
+  // fused BatchNorm(+ReLU) backward on the dz operand (VinetWgradDesc::bnb_*): dy is the gradient behind the BN
+  const char* z;
+  long sBz;
+  int ldz, relu;
+  const float* f_scale; const float* f_shift; const float* mean; const float* invstd; const float* c1; const float* c2;
 };
 
 VN_DEV int whs_swz(int r) { return ((r >> 1) & 1) << 1; }
 
+template <bool BNB>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_hs_kernel(const WgradHsArgs a) {
   constexpr int ROW = 1088, NP = 67;                 // ring slot: 134 pixels x 8 B = 67 pieces of 16 B (+ pad)
   constexpr int DZT = 64 * 64 * 2;
@@ -47,6 +53,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_hs_kernel(const WgradHsArgs
     const int r = l_row + 32 * j;
     l_off[j] = r * 128 + ((l_chunk ^ whs_swz(r)) * 16);
   }
+  // fused BN backward: dz = A*(g*mask) + Bc*z + D with the gate from A*z + sh (elementwise.hip::bn_bwd_apply8_kernel);
+  // a thread always handles the same 8 channels
+  float cA[8], cB[8], cD[8], cS[8];
+  if constexpr (BNB) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = l_chunk * 8 + e;
+      const float sc = a.f_scale[c], k = sc * a.invstd[c] * a.c2[c];
+      cA[e] = sc; cB[e] = -k; cD[e] = fmaf(k, a.mean[c], -sc * a.c1[c]);
+      cS[e] = a.f_shift ? a.f_shift[c] : 0.f;
+    }
+  }
+  auto bnb = [&](uint4 g, uint4 z) -> uint4 {
+    if constexpr (!BNB) return g;
+    const uint32_t gu[4] = {g.x, g.y, g.z, g.w}, zu[4] = {z.x, z.y, z.z, z.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float r[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const float gv = __uint_as_float(hh ? (gu[e] & 0xffff0000u) : (gu[e] << 16));
+        const float zv = __uint_as_float(hh ? (zu[e] & 0xffff0000u) : (zu[e] << 16));
+        const int c = 2 * e + hh;
+        float gg = gv;
+        if (a.relu && !(fmaf(zv, cA[c], cS[c]) > 0.f)) gg = 0.f;
+        r[hh] = fmaf(cA[c], gg, fmaf(cB[c], zv, cD[c]));
+      }
+      o[e] = pack2bf(r[0], r[1]);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
   // x pieces of a step: 2 rows x 67 pieces = 134 over threads 0..133
   const bool xl = tid < 2 * NP;
   const int x_r = tid >= NP ? 1 : 0, x_p = tid - x_r * NP;
@@ -91,14 +129,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_hs_kernel(const WgradHsArgs
     const long x_rowb = (long)a.Wv * a.ldx * 2;
     const char* db = a.dy + ((long)b * a.sBy + ((long)t * a.oH * a.oW + wo0 + l_row) * (long)a.ldy + l_chunk * 8) * 2;
     const long d_rowb = (long)a.oW * a.ldy * 2, d_r32 = 32L * a.ldy * 2;
+    const char* zb = BNB ? a.z + ((long)b * a.sBz + ((long)t * a.oH * a.oW + wo0 + l_row) * (long)a.ldz + l_chunk * 8) * 2 : db;
+    const long z_rowb = (long)a.oW * a.ldz * 2, z_r32 = 32L * a.ldz * 2;
 
     // ---- prologue: input rows 0..6, dz row 0 --------------------------------------------------------------------
     for (int q = tid; q < 7 * NP; q += 256) {
       const int h = q / NP, pc = q - h * NP;
       *(uint4*)(ring + h * ROW + pc * 16) = *(const uint4*)(xrow0 + h * x_rowb + pc * 16);
     }
-    *(uint4*)(dzb + l_off[0]) = *(const uint4*)db;
-    *(uint4*)(dzb + l_off[1]) = *(const uint4*)(db + d_r32);
+    *(uint4*)(dzb + l_off[0]) = bnb(*(const uint4*)db, *(const uint4*)zb);
+    *(uint4*)(dzb + l_off[1]) = bnb(*(const uint4*)(db + d_r32), *(const uint4*)(zb + z_r32));
     __syncthreads();
 
     for (int ho = 0; ho < a.oH; ++ho) {
@@ -107,6 +147,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_hs_kernel(const WgradHsArgs
       const uint4 nx = *(const uint4*)(xrow0 + hn * x_rowb + (xl ? x_p : 0) * 16);
       const char* ds = db + (more ? ho + 1 : ho) * d_rowb;
       const uint4 nd0 = *(const uint4*)ds, nd1 = *(const uint4*)(ds + d_r32);
+      const char* zs = zb + (more ? ho + 1 : ho) * z_rowb;
+      uint4 nz0 = nd0, nz1 = nd1;
+      if constexpr (BNB) { nz0 = *(const uint4*)zs; nz1 = *(const uint4*)(zs + z_r32); }
 
       const char* dt = dzb + (ho & 1) * DZT;
       const int s0 = (2 * ho) % 7;                                      // ring slot of input row 2ho
@@ -127,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_hs_kernel(const WgradHsArgs
       if (more) {
         if (xl) *(uint4*)(ring + ((2 * ho + 7 + x_r) % 7) * ROW + x_p * 16) = nx;
         char* dn = dzb + ((ho + 1) & 1) * DZT;
-        *(uint4*)(dn + l_off[0]) = nd0;
-        *(uint4*)(dn + l_off[1]) = nd1;
+        *(uint4*)(dn + l_off[0]) = bnb(nd0, nz0);
+        *(uint4*)(dn + l_off[1]) = bnb(nd1, nz1);
       }
       __syncthreads();
     }
@@ -152,6 +195,8 @@ int g_vinet_opt_wgrad_hs = 1;   // 0 = off, 2 = force on every eligible shape (t
 bool vinet_wgrad_use_hs(const VinetWgradDesc* d) {
   if (!g_vinet_opt_wgrad_hs || d->tline != 2 || d->dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
   if (d->pre.scale || d->pre.relu) return false;
+  if (d->bnb_z && !(d->bnb_fwd.scale && d->bnb_mean && d->bnb_invstd && d->bnb_c1 && d->bnb_c2 && d->bnb_ld % 8 == 0 &&
+                    d->bnb_sB % 8 == 0 && ((uintptr_t)d->bnb_z % 16) == 0)) return false;
   const bool shape = d->x.C == 32 && d->x.ld == 8 && d->Kp == 32 && d->ntaps == 7 && d->sT == 1 && d->sH == 2 && d->sW == 1 &&
                      d->dy.C == 64 && d->dy.W % 64 == 0 && d->x.T == d->dy.T && d->x.W >= d->dy.W + 3 && d->x.H >= 2 * d->dy.H + 5 &&
                      d->dy.ld % 8 == 0 && d->dy.sB % 8 == 0 && d->x.sB % 8 == 0 && ((uintptr_t)d->x.ptr % 16) == 0 &&
@@ -174,6 +219,10 @@ int vinet_launch_wgrad_hs(const VinetWgradDesc* d, hipStream_t s) {
   const int smem = 2 * 64 * 64 * 2 + 7 * 1088;
   int grid = 768;     // 3 workgroups per CU (130 registers, 24 KB of LDS)
   if (grid > a.items) grid = a.items;
-  hipLaunchKernelGGL(conv_wgrad_hs_kernel, dim3(grid), dim3(256), smem, s, a);
+  a.z = (const char*)d->bnb_z; a.sBz = d->bnb_sB; a.ldz = d->bnb_ld; a.relu = d->bnb_fwd.relu;
+  a.f_scale = d->bnb_fwd.scale; a.f_shift = d->bnb_fwd.shift; a.mean = d->bnb_mean; a.invstd = d->bnb_invstd;
+  a.c1 = d->bnb_c1; a.c2 = d->bnb_c2;
+  if (d->bnb_z) hipLaunchKernelGGL(conv_wgrad_hs_kernel<true>, dim3(grid), dim3(256), smem, s, a);
+  else hipLaunchKernelGGL(conv_wgrad_hs_kernel<false>, dim3(grid), dim3(256), smem, s, a);
   return vn_launch_status("conv_wgrad_hs");
 }

@@ -90,6 +90,8 @@ class Profiler:
 PROFILER = None
 # Inception blocks run their three input-side 1x1x1 convs as one (model_utils._Mixed._fwd_joint); 0 = per conv
 JOINT_ENTRY = int(os.environ.get("VINET_JOINT_ENTRY", "1"))
+# the stem's BN-backward apply pass folded into its weight-gradient kernel (0 = separate pass)
+BN_BWD_FUSE = int(os.environ.get("VINET_BN_BWD_FUSE", "1"))
 
 
 def set_profiler(p):
@@ -852,11 +854,31 @@ class _NullCtx:
         return False
 
 
+def _wgrad_desc(ctx, plan, x, dy, dw=None):
+    folded = plan.stem and x.fold is not None
+    taps, ntaps = plan.folded_taps(ctx.device) if folded else plan.fwd_taps(ctx.device)
+    wd = L.CWgradDesc()
+    wd.dtype, wd.mode = ctx.dt, (L.CONV_STEM if (plan.stem and not folded) else L.CONV_GENERIC)
+    wd.x, wd.dy = x.v.ct(), dy.ct()
+    wd.sT, wd.sH, wd.sW = (1, 2, 1) if folded else plan.s
+    wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), (dw.data_ptr() if dw is not None else None), plan.kp(False)
+    wd.pre = x.affine()
+    # a purely temporal kernel (k,1,1): tap kt is (kt - pad, 0, 0, kt) -- the library cannot read the
+    # device-side tap table, so the geometry is promised here (include/vinet_hip.h: tline)
+    if not folded and not plan.stem and plan.temporal:
+        wd.tline, wd.tpad = 1, plan.p[0]
+    elif folded:
+        wd.tline = 2        # taps (0, kh, 0, kh): ConvPlan.folded_taps
+    wd._keep = taps
+    return wd
+
+
 def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
     out = res.v
     dz = res.grad_view()
     assert res.is_grad_ready(), "conv backward reached before any consumer produced a gradient"
     Ny = out.C
+    fused_bnb = None
     # ---- through BN / activation: dz -> dy (w.r.t. the raw conv output) --------
     if bn is not None:
         rows = ctx.lib.vinet_stats_rows(C.byref(dz.ct()))
@@ -869,10 +891,20 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                  work=dict(flops=0.0, bytes=2 * nb))
         c1, c2 = ctx.f32(Ny), ctx.f32(Ny)
         bn.bwd_finalize(ctx, ws, rows, Ny, M, res.scale, train_bn, keep["invstd"], c1, c2)
-        ctx.call("vinet_bn_bwd_apply", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
-                 keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), C.byref(dz.ct()), ctx.stream,
-                 tag=("vinet_bn_bwd_apply | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
-                 work=dict(flops=0.0, bytes=3 * nb))
+        # A conv whose input needs no gradient (the RGB stem) has one consumer of dz, its weight gradient: kernels
+        # that can form dz from (gradient behind the BN, raw conv output) on the fly spare the apply pass
+        if BN_BWD_FUSE and not x.needs_grad and plan.wants_wgrad() and plan.bias is None and out.dt == dz.dt == ctx.dt:
+            q = _wgrad_desc(ctx, plan, x, dz)
+            q.bnb_z, q.bnb_ld, q.bnb_sB, q.bnb_fwd = out.ptr(), out.ld, out.sB, fwd
+            q.bnb_mean, q.bnb_invstd = keep["mean"].data_ptr(), keep["invstd"].data_ptr()
+            q.bnb_c1, q.bnb_c2 = c1.data_ptr(), c2.data_ptr()
+            if ctx.lib.vinet_conv3d_wgrad_fuses_bn_bwd(C.byref(q)):
+                fused_bnb = (out, fwd, keep["mean"], keep["invstd"], c1, c2)
+        if fused_bnb is None:
+            ctx.call("vinet_bn_bwd_apply", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
+                     keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), C.byref(dz.ct()), ctx.stream,
+                     tag=("vinet_bn_bwd_apply | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
+                     work=dict(flops=0.0, bytes=3 * nb))
         dy = dz
     elif act != L.ACT_NONE:
         if dz.dt == ctx.dt:
@@ -905,23 +937,14 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             if side is not None:
                 ctx.stream = side.cuda_stream
             try:
-                folded = plan.stem and x.fold is not None
-                taps, ntaps = plan.folded_taps(ctx.device) if folded else plan.fwd_taps(ctx.device)
                 kp = plan.kp(False)
                 nsl = 7 if plan.stem else plan.ntaps
                 dw = ctx.f32(nsl * Ny * kp, zero=True)
-                wd = L.CWgradDesc()
-                wd.dtype, wd.mode = ctx.dt, (L.CONV_STEM if (plan.stem and not folded) else L.CONV_GENERIC)
-                wd.x, wd.dy = x.v.ct(), dy.ct()
-                wd.sT, wd.sH, wd.sW = (1, 2, 1) if folded else plan.s
-                wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), kp
-                wd.pre = x.affine()
-                # a purely temporal kernel (k,1,1): tap kt is (kt - pad, 0, 0, kt) -- the library cannot read the
-                # device-side tap table, so the geometry is promised here (include/vinet_hip.h: tline)
-                if not folded and not plan.stem and plan.temporal:
-                    wd.tline, wd.tpad = 1, plan.p[0]
-                elif folded:
-                    wd.tline = 2        # taps (0, kh, 0, kh): ConvPlan.folded_taps
+                wd = _wgrad_desc(ctx, plan, x, dy, dw)
+                if fused_bnb is not None:
+                    zv, zf, zm, zi, z1, z2 = fused_bnb
+                    wd.bnb_z, wd.bnb_ld, wd.bnb_sB, wd.bnb_fwd = zv.ptr(), zv.ld, zv.sB, zf
+                    wd.bnb_mean, wd.bnb_invstd, wd.bnb_c1, wd.bnb_c2 = zm.data_ptr(), zi.data_ptr(), z1.data_ptr(), z2.data_ptr()
                 es = ESIZE[ctx.dt]
                 ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
                          tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
