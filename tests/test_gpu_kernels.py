@@ -815,6 +815,16 @@ def test_maxpool_k3s1_twalk_backward(dt):
         lib.vinet_set_option(b"pool_lds", 1)
 
 
+def test_maxpool_k3s1_lds_forward_bf16_fp32_compare():
+    """bf16 through the fp32-compare LDS kernel (the packed-key kernel is the bf16 default)"""
+    lib = _lib()
+    assert lib.vinet_set_option(b"pool_pk", 0) == 0
+    try:
+        test_maxpool_k3s1_lds_forward(E.BF16)
+    finally:
+        lib.vinet_set_option(b"pool_pk", 1)
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_maxpool_k3s1_lds_forward(dt):
     """the LDS halo-tile 3x3x3/s1 forward (chosen for large tensors only) forced on the small test shape

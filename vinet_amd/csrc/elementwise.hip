@@ -7,6 +7,8 @@
 
 extern int g_vinet_opt_pool_twalk;
 extern int g_vinet_opt_pool_lds;
+extern int g_vinet_opt_pool_pk;
+extern int g_vinet_opt_pool_pk;
 
 // ---- 4-channel ("quad") typed access -----------------------------------------
 template <typename T> VN_DEV float4 ldq(const T* p);
@@ -809,6 +811,13 @@ static inline PoolP make_poolp(const VinetPoolDesc* d) {
   return p;
 }
 
+// Pooling semantics: a pending affine (+ReLU) is applied AND rounded to the activation dtype before the comparison --
+// what a bf16 pipeline that had stored the BN+ReLU output would pool over, and what every other consumer of a
+// pending activation sees (the conv kernels round at fragment time).  It also makes the packed 16-bit kernel below
+// agree with these fp32-compare kernels on every tie.
+template <typename T> VN_DEV float pool_round(float v) { return v; }
+template <> VN_DEV float pool_round<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
 template <typename T>
 __global__ void maxpool_fwd_kernel(PoolP p, TView x, Affine pre, TView y, uint8_t* __restrict__ argmax, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -831,6 +840,7 @@ __global__ void maxpool_fwd_kernel(PoolP p, TView x, Affine pre, TView y, uint8_
         if ((unsigned)w >= (unsigned)x.W) continue;
         float4 v = ldq<T>((const T*)x.p + vox_off(x, b, t, h, w) + q * 4);
         v = affine4(v, pre, q * 4);
+        if (pre.scale) { v.x = pool_round<T>(v.x); v.y = pool_round<T>(v.y); v.z = pool_round<T>(v.z); v.w = pool_round<T>(v.w); }
         const int tap = (kt * p.kH + kh) * p.kW + kw;
         const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -875,6 +885,8 @@ __global__ void maxpool_tslide_kernel(PoolP p, TView x, Affine pre, TView y, uin
           if ((unsigned)w >= (unsigned)x.W) continue;
           float4 v = ldq<T>((const T*)x.p + vox_off(x, b, tp, h, w) + q * 4);
           v = affine4(v, pre, q * 4);
+          if (pre.scale) { v.x = pool_round<T>(v.x); v.y = pool_round<T>(v.y); v.z = pool_round<T>(v.z); v.w = pool_round<T>(v.w); }
+        if (pre.scale) { v.x = pool_round<T>(v.x); v.y = pool_round<T>(v.y); v.z = pool_round<T>(v.z); v.w = pool_round<T>(v.w); }
           const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -951,6 +963,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd8_kernel(PoolP p, TView x, Aff
         for (int e = 0; e < 8; ++e) {
           float v = fmaf(f[e], sc[e], sh[e]);
           if (pre.relu) v = fmaxf(v, 0.f);
+          if (pre.scale) v = pool_round<T>(v);
           if (v > best[e] || (v != v && best[e] == best[e])) { best[e] = v; bi = (bi & ~(0xffull << (8 * e))) | (tap << (8 * e)); }
         }
       }
@@ -1003,6 +1016,7 @@ __global__ __launch_bounds__(256) void maxpool_tslide8_kernel(PoolP p, TView x, 
           for (int e = 0; e < 8; ++e) {
             float v = fmaf(f[e], sc[e], sh[e]);
             if (pre.relu) v = fmaxf(v, 0.f);
+            if (pre.scale) v = pool_round<T>(v);
             if (v > m_c[e] || (v != v && m_c[e] == m_c[e])) { m_c[e] = v; i_c = (i_c & ~(0xffull << (8 * e))) | (code << (8 * e)); }
           }
         }
@@ -1082,6 +1096,7 @@ __global__ __launch_bounds__(512) void maxpool_k3s1_lds_kernel(TView x, Affine p
           for (int e = 0; e < 8; ++e) {
             v[e] = fmaf(v[e], S[0][oct * 8 + e], S[1][oct * 8 + e]);
             if (pre.relu) v[e] = fmaxf(v[e], 0.f);
+            if (pre.scale) v[e] = pool_round<T>(v[e]);
           }
         } else {
 #pragma unroll
@@ -1154,6 +1169,122 @@ __global__ __launch_bounds__(512) void maxpool_k3s1_lds_kernel(TView x, Affine p
   }
 }
 
+
+// bf16 form of the kernel above on PACKED 32-bit keys.  The halo holds order-preserving 16-bit codes of the
+// (affine + ReLU'd, bf16-rounded) activations: code = bits ^ 0x8000 for non-negative values, ~bits for negative
+// ones, so unsigned integer order = numeric order and 0 is below everything (out-of-range taps).  A window
+// candidate becomes key = code << 16 | (8 - tap): v_max3_u32 over the nine keys yields the maximum AND, in its low
+// bits, the first tap that attains it (ties: the larger low field = the smaller tap) -- 1 op to build a key, half an
+// op to fold it, instead of ~20 for max-then-find-first in fp32.  The three plane keys are folded the same way with
+// +18 / +9 / +0 (earlier plane wins ties), so tap = 26 - (key & 0xff).  Half the LDS bytes per plane, 9 instead of 18
+// ds_read_b128 per lane and plane.  (A sign-bit NaN would order lowest; aten's NaN-wins only holds for positive NaNs.)
+__global__ __launch_bounds__(512) void maxpool_k3s1_pk_kernel(TView x, Affine pre, TView y, uint8_t* __restrict__ argmax,
+                                                              int tilesH, int tilesW) {
+  __shared__ __attribute__((aligned(16))) uint16_t P[2][100][64];
+  __shared__ __attribute__((aligned(16))) float S[2][64];
+  const int tid = threadIdx.x;
+  const int oct = tid & 7, pos = tid >> 3;
+  const int ph = pos >> 3, pw = pos & 7;
+  int bid = blockIdx.x;
+  const int ncg = (x.C + 63) >> 6;
+  const int cg = bid % ncg; bid /= ncg;
+  const int tw = bid % tilesW; bid /= tilesW;
+  const int th = bid % tilesH; bid /= tilesH;
+  const int b = bid;
+  const int h0 = th * 8, w0 = tw * 8, c0 = cg * 64 + oct * 8;
+  const int ho = h0 + ph, wo = w0 + pw;
+  const bool out_ok = ho < y.H && wo < y.W && c0 < x.C;
+  const bool aff = pre.scale != nullptr;
+  if (tid < 64) {
+    const bool ok = aff && cg * 64 + tid < x.C;
+    S[0][tid] = ok ? pre.scale[cg * 64 + tid] : 1.f;
+    S[1][tid] = ok ? pre.shift[cg * 64 + tid] : 0.f;
+  }
+  __syncthreads();
+  auto code2 = [](uint32_t u) -> uint32_t {          // two bf16 -> two order-preserving codes
+    const uint32_t m = ((u >> 15) & 0x00010001u) * 0x7fffu;
+    return u ^ (m | 0x80008000u);
+  };
+  auto decode2 = [](uint32_t k) -> uint32_t {        // inverse
+    const uint32_t m = (((k >> 15) & 0x00010001u) ^ 0x00010001u) * 0x7fffu;
+    return k ^ (m | 0x80008000u);
+  };
+  uint32_t m_a[8], m_b[8], m_c[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { m_a[e] = 0; m_b[e] = 0; m_c[e] = 0; }
+  const int T_ = x.T;
+  for (int tp = 0; tp <= T_; ++tp) {
+    uint16_t (*buf)[64] = P[tp & 1];
+    if (tp < T_) {
+      for (int it = tid; it < 800; it += 512) {
+        const int hp = it >> 3;                      // (it & 7) == oct
+        const int hh = h0 - 1 + hp / 10, ww = w0 - 1 + hp % 10;
+        if (cg * 64 + oct * 8 >= x.C) continue;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if ((unsigned)hh < (unsigned)x.H && (unsigned)ww < (unsigned)x.W) {
+          q = *(const uint4*)((const bf16_t*)x.p + vox_off(x, b, tp, hh, ww) + cg * 64 + oct * 8);
+          if (aff) {
+            const float2* sp = (const float2*)&S[0][oct * 8];
+            const float2* hp2 = (const float2*)&S[1][oct * 8];
+            uint32_t* w4 = (uint32_t*)&q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float2 s2 = sp[e], h2 = hp2[e];
+              if (pre.relu) w4[e] = pre_relu_pair(w4[e], (f32x2_v){s2.x, s2.y}, (f32x2_v){h2.x, h2.y});
+              else w4[e] = pack2bf(fmaf(__uint_as_float(w4[e] << 16), s2.x, h2.x), fmaf(__uint_as_float(w4[e] & 0xffff0000u), s2.y, h2.y));
+            }
+          } else if (pre.relu) {
+            uint32_t* w4 = (uint32_t*)&q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm("v_pk_max_i16 %0, %1, 0" : "=v"(w4[e]) : "v"(w4[e]));
+          }
+          q.x = code2(q.x); q.y = code2(q.y); q.z = code2(q.z); q.w = code2(q.w);
+        }
+        *(uint4*)&buf[hp][oct * 8] = q;
+      }
+    }
+    __syncthreads();     // plane tp staged; every lane finished reading the buffer staged two planes ago
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m_a[e] = m_b[e]; m_b[e] = m_c[e]; m_c[e] = 0; }
+    if (tp < T_) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const uint4 q = *(const uint4*)&buf[(ph + kh) * 10 + pw + kw][oct * 8];
+          const uint32_t ck = 8u - (uint32_t)(kh * 3 + kw);
+          const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t klo = (w4[e] << 16) | ck, khi = (w4[e] & 0xffff0000u) | ck;
+            m_c[2 * e] = m_c[2 * e] > klo ? m_c[2 * e] : klo;
+            m_c[2 * e + 1] = m_c[2 * e + 1] > khi ? m_c[2 * e + 1] : khi;
+          }
+        }
+    }
+    const int to = tp - 1;
+    if (to < 0 || !out_ok) continue;
+    uint32_t ov[4];
+    unsigned long long oi = 0;
+    const bool va = to >= 1, vc = to + 1 < T_;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t ka = va ? m_a[e] + 18u : 0u, kb = m_b[e] + 9u, kc = vc ? m_c[e] : 0u;
+      uint32_t k = ka > kb ? ka : kb;
+      k = k > kc ? k : kc;
+      if (e & 1) ov[e >> 1] |= k & 0xffff0000u; else ov[e >> 1] = k >> 16;
+      oi |= (unsigned long long)(26u - (k & 0xffu)) << (8 * e);
+    }
+    uint4 o;
+    o.x = decode2(ov[0]); o.y = decode2(ov[1]); o.z = decode2(ov[2]); o.w = decode2(ov[3]);
+    *(uint4*)((bf16_t*)y.p + vox_off(y, b, to, ho, wo) + c0) = o;
+    if (argmax) {
+      const long ovox = (((long)b * y.T + to) * y.H + ho) * y.W + wo;
+      *(unsigned long long*)(argmax + ovox * y.C + c0) = oi;
+    }
+  }
+}
+
 extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, VinetAffine pre, const VinetTensor* y,
                                uint8_t* argmax, void* stream) {
   VN_CHECK_ARG(d && x && y && quad_ok(*x, esize(d->dtype)) && quad_ok(*y, esize(d->dtype)) && x->C == y->C && x->B == y->B,
@@ -1166,6 +1297,13 @@ extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, Vin
       (g_vinet_opt_pool_lds >= 2 || (long)y->B * y->H * y->W * (y->C / 8) >= 65536)) {
     const int tilesH = (y->H + 7) / 8, tilesW = (y->W + 7) / 8;
     const long blocks = (long)y->B * tilesH * tilesW * ((y->C + 63) / 64);
+    const bool pre_ok = !pre.scale || pre.shift;
+    if (d->dtype == VINET_BF16 && g_vinet_opt_pool_pk && pre_ok && x->ld % 8 == 0 && ((uintptr_t)x->ptr % 16) == 0 && ((uintptr_t)y->ptr % 16) == 0 &&
+        x->sB % 8 == 0 && y->sB % 8 == 0) {
+      hipLaunchKernelGGL(maxpool_k3s1_pk_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, make_view(*x),
+                         make_affine(pre), make_view(*y), argmax, tilesH, tilesW);
+      return vn_launch_status("maxpool3d(k3s1 packed keys)");
+    }
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_k3s1_lds_kernel<T>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream,
                                                make_view(*x), make_affine(pre), make_view(*y), argmax, tilesH, tilesW);)
     return vn_launch_status("maxpool3d(k3s1 lds)");
