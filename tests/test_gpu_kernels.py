@@ -821,6 +821,8 @@ def test_maxpool_k3s1_lds_forward_bf16_fp32_compare():
     assert lib.vinet_set_option(b"pool_pk", 0) == 0
     try:
         test_maxpool_k3s1_lds_forward(E.BF16)
+        for ksp in POOLS[:3]:                      # the generic 8-channel kernel, fp32 compare
+            test_maxpool(E.BF16, ksp)
     finally:
         lib.vinet_set_option(b"pool_pk", 1)
 

@@ -1170,6 +1170,80 @@ __global__ __launch_bounds__(512) void maxpool_k3s1_lds_kernel(TView x, Affine p
 }
 
 
+// order-preserving 16-bit codes of two packed bf16 (see maxpool_k3s1_pk_kernel) and their inverse
+VN_DEV uint32_t pool_code2(uint32_t u) {
+  const uint32_t m = ((u >> 15) & 0x00010001u) * 0x7fffu;
+  return u ^ (m | 0x80008000u);
+}
+VN_DEV uint32_t pool_decode2(uint32_t k) {
+  const uint32_t m = (((k >> 15) & 0x00010001u) ^ 0x00010001u) * 0x7fffu;
+  return k ^ (m | 0x80008000u);
+}
+
+// Generic window (any k / stride / padding, up to 255 taps), bf16, on packed keys: one lane = one output voxel x 8
+// channels; every in-range tap is loaded (16 B), transformed, coded and folded with key = code << 16 | (ntaps-1-tap).
+// 7 VALU per element and tap instead of ~12 for affine + round + compare-and-track in fp32.
+__global__ __launch_bounds__(256) void maxpool_fwd8_pk_kernel(PoolP p, TView x, Affine pre, TView y, uint8_t* __restrict__ argmax, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = y.C >> 3;
+  const uint32_t vox_u = (uint32_t)(i / G);
+  const int g = (int)(i - (long)vox_u * G);
+  int b, to, ho, wo;
+  decode_vox(y, (long)vox_u, b, to, ho, wo);
+  f32x2_v sc2[4], sh2[4];
+  const bool aff = pre.scale != nullptr;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sc2[e] = aff ? (f32x2_v){pre.scale[g * 8 + 2 * e], pre.scale[g * 8 + 2 * e + 1]} : (f32x2_v){1.f, 1.f};
+    sh2[e] = aff ? (f32x2_v){pre.shift[g * 8 + 2 * e], pre.shift[g * 8 + 2 * e + 1]} : (f32x2_v){0.f, 0.f};
+  }
+  uint32_t best[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) best[e] = 0;
+  const uint32_t last = (uint32_t)(p.kT * p.kH * p.kW - 1);
+  for (int kt = 0; kt < p.kT; ++kt) {
+    const int t = to * p.sT - p.pT + kt;
+    if ((unsigned)t >= (unsigned)x.T) continue;
+    for (int kh = 0; kh < p.kH; ++kh) {
+      const int h = ho * p.sH - p.pH + kh;
+      if ((unsigned)h >= (unsigned)x.H) continue;
+      for (int kw = 0; kw < p.kW; ++kw) {
+        const int w = wo * p.sW - p.pW + kw;
+        if ((unsigned)w >= (unsigned)x.W) continue;
+        const uint4 q = *(const uint4*)((const bf16_t*)x.p + vox_off(x, b, t, h, w) + g * 8);
+        uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+        const uint32_t ck = last - (uint32_t)((kt * p.kH + kh) * p.kW + kw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (aff) {
+            if (pre.relu) w4[e] = pre_relu_pair(w4[e], sc2[e], sh2[e]);
+            else w4[e] = pack2bf(fmaf(__uint_as_float(w4[e] << 16), sc2[e].x, sh2[e].x), fmaf(__uint_as_float(w4[e] & 0xffff0000u), sc2[e].y, sh2[e].y));
+          } else if (pre.relu) {
+            asm("v_pk_max_i16 %0, %1, 0" : "=v"(w4[e]) : "v"(w4[e]));
+          }
+          const uint32_t c = pool_code2(w4[e]);
+          const uint32_t klo = (c << 16) | ck, khi = (c & 0xffff0000u) | ck;
+          best[2 * e] = best[2 * e] > klo ? best[2 * e] : klo;
+          best[2 * e + 1] = best[2 * e + 1] > khi ? best[2 * e + 1] : khi;
+        }
+      }
+    }
+  }
+  uint32_t ov[4];
+  unsigned long long bi = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const uint32_t k = best[e];
+    if (e & 1) ov[e >> 1] |= k & 0xffff0000u; else ov[e >> 1] = k >> 16;
+    bi |= (unsigned long long)(last - (k & 0xffu)) << (8 * e);
+  }
+  uint4 o;
+  o.x = pool_decode2(ov[0]); o.y = pool_decode2(ov[1]); o.z = pool_decode2(ov[2]); o.w = pool_decode2(ov[3]);
+  *(uint4*)((bf16_t*)y.p + vox_off(y, b, to, ho, wo) + g * 8) = o;
+  if (argmax) *(unsigned long long*)(argmax + (long)vox_u * y.C + g * 8) = bi;
+}
+
 // bf16 form of the kernel above on PACKED 32-bit keys.  The halo holds order-preserving 16-bit codes of the
 // (affine + ReLU'd, bf16-rounded) activations: code = bits ^ 0x8000 for non-negative values, ~bits for negative
 // ones, so unsigned integer order = numeric order and 0 is below everything (out-of-range taps).  A window
@@ -1201,14 +1275,6 @@ __global__ __launch_bounds__(512) void maxpool_k3s1_pk_kernel(TView x, Affine pr
     S[1][tid] = ok ? pre.shift[cg * 64 + tid] : 0.f;
   }
   __syncthreads();
-  auto code2 = [](uint32_t u) -> uint32_t {          // two bf16 -> two order-preserving codes
-    const uint32_t m = ((u >> 15) & 0x00010001u) * 0x7fffu;
-    return u ^ (m | 0x80008000u);
-  };
-  auto decode2 = [](uint32_t k) -> uint32_t {        // inverse
-    const uint32_t m = (((k >> 15) & 0x00010001u) ^ 0x00010001u) * 0x7fffu;
-    return k ^ (m | 0x80008000u);
-  };
   uint32_t m_a[8], m_b[8], m_c[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { m_a[e] = 0; m_b[e] = 0; m_c[e] = 0; }
@@ -1238,7 +1304,7 @@ __global__ __launch_bounds__(512) void maxpool_k3s1_pk_kernel(TView x, Affine pr
 #pragma unroll
             for (int e = 0; e < 4; ++e) asm("v_pk_max_i16 %0, %1, 0" : "=v"(w4[e]) : "v"(w4[e]));
           }
-          q.x = code2(q.x); q.y = code2(q.y); q.z = code2(q.z); q.w = code2(q.w);
+          q.x = pool_code2(q.x); q.y = pool_code2(q.y); q.z = pool_code2(q.z); q.w = pool_code2(q.w);
         }
         *(uint4*)&buf[hp][oct * 8] = q;
       }
@@ -1276,7 +1342,7 @@ __global__ __launch_bounds__(512) void maxpool_k3s1_pk_kernel(TView x, Affine pr
       oi |= (unsigned long long)(26u - (k & 0xffu)) << (8 * e);
     }
     uint4 o;
-    o.x = decode2(ov[0]); o.y = decode2(ov[1]); o.z = decode2(ov[2]); o.w = decode2(ov[3]);
+    o.x = pool_decode2(ov[0]); o.y = pool_decode2(ov[1]); o.z = pool_decode2(ov[2]); o.w = pool_decode2(ov[3]);
     *(uint4*)((bf16_t*)y.p + vox_off(y, b, to, ho, wo) + c0) = o;
     if (argmax) {
       const long ovox = (((long)b * y.T + to) * y.H + ho) * y.W + wo;
@@ -1326,6 +1392,12 @@ extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, Vin
   }
   if (oct_ok(*x) && oct_ok(*y) && (!argmax || ((uintptr_t)argmax % 8) == 0)) {
     const long total8 = view_voxels(*y) * (y->C / 8);
+    if (d->dtype == VINET_BF16 && g_vinet_opt_pool_pk && (!pre.scale || pre.shift) && ((uintptr_t)x->ptr % 16) == 0 && ((uintptr_t)y->ptr % 16) == 0 &&
+        x->sB % 8 == 0 && y->sB % 8 == 0) {
+      hipLaunchKernelGGL(maxpool_fwd8_pk_kernel, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, p, make_view(*x),
+                         make_affine(pre), make_view(*y), argmax, total8);
+      return vn_launch_status("maxpool3d(8, packed keys)");
+    }
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_fwd8_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0,
                                                (hipStream_t)stream, p, make_view(*x), make_affine(pre), make_view(*y), argmax, total8);)
     return vn_launch_status("maxpool3d(8)");
