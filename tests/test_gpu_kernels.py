@@ -815,6 +815,17 @@ def test_maxpool_k3s1_twalk_backward(dt):
         lib.vinet_set_option(b"pool_lds", 1)
 
 
+@pytest.mark.parametrize("dt", DTS)
+def test_maxpool_133s2_generic_backward(dt):
+    """1x3x3/s(1,2,2) through the generic gather (the 2x2-block kernel is its default)"""
+    lib = _lib()
+    assert lib.vinet_set_option(b"pool_blk", 0) == 0
+    try:
+        test_maxpool(dt, POOLS[0])
+    finally:
+        lib.vinet_set_option(b"pool_blk", 1)
+
+
 def test_maxpool_k3s1_lds_forward_bf16_fp32_compare():
     """bf16 through the fp32-compare LDS kernel (the packed-key kernel is the bf16 default)"""
     lib = _lib()

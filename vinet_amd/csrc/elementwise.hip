@@ -8,6 +8,7 @@
 extern int g_vinet_opt_pool_twalk;
 extern int g_vinet_opt_pool_lds;
 extern int g_vinet_opt_pool_pk;
+extern int g_vinet_opt_pool_blk;
 extern int g_vinet_opt_pool_pk;
 
 // ---- 4-channel ("quad") typed access -----------------------------------------
@@ -1561,6 +1562,83 @@ __global__ __launch_bounds__(256) void maxpool_bwd8_kernel(PoolP p, TView dy, co
   st8<T>(dst, gr);
 }
 
+// 1x3x3 / s(1,2,2) / p(0,1,1) backward (the two big spatial pools, model.py:696,700): one lane owns the 2 x 2 input
+// block {2ho, 2ho+1} x {2wo, 2wo+1} x 8 channels.  Only the four windows (ho..ho+1, wo..wo+1) reach it -- (ho,wo) all
+// four inputs, (ho,wo+1) and (ho+1,wo) two each, (ho+1,wo+1) one -- so 4 argmax words and at most 4 dy rows serve 4
+// outputs, and the voxel decode and window arithmetic are paid once per 64 bytes written instead of once per 16:
+// the generic gather is bound by exactly that integer work (2.1 TB/s of tensors on the 112 x 192 pool).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_k133s2_kernel(TView dy, const uint8_t* __restrict__ argmax, TView dx, int accumulate,
+                                                                 int HB, int WB, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = dx.C >> 3;
+  long r = i / G;
+  const int g = (int)(i - r * G);
+  const int wb = (int)(r % WB); r /= WB;
+  const int hb = (int)(r % HB); r /= HB;
+  const int t = (int)(r % dx.T);
+  const int b = (int)(r / dx.T);
+  const int h0 = 2 * hb, w0 = 2 * wb;
+  // windows q = dh*2 + dw at (hb + dh, wb + dw)
+  unsigned long long am[4];
+  bool wok[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ho = hb + (q >> 1), wo = wb + (q & 1);
+    wok[q] = ho < dy.H && wo < dy.W;
+    const long ovox = (((long)b * dy.T + t) * dy.H + (wok[q] ? ho : 0)) * dy.W + (wok[q] ? wo : 0);
+    am[q] = wok[q] ? *(const unsigned long long*)(argmax + ovox * dy.C + g * 8) : ~0ull;
+  }
+  float dv[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // taps of window q that land in the block: rows kh in {1,2} (dh = 0) or {0} (dh = 1); same for columns
+    bool any = false;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const bool in = ((q >> 1) ? kh == 0 : kh >= 1) && ((q & 1) ? kw == 0 : kw >= 1);
+        if (!in) continue;
+        const unsigned long long x = am[q] ^ ((unsigned long long)(kh * 3 + kw) * 0x0101010101010101ull);
+        any |= ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0;
+      }
+    if (any) ld8<T>((const T*)dy.p + vox_off(dy, b, t, hb + (q >> 1), wb + (q & 1)) + g * 8, dv[q]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv[q][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+    for (int iw = 0; iw < 2; ++iw) {
+      const int h = h0 + ih, w = w0 + iw;
+      if (h >= dx.H || w >= dx.W) continue;
+      float gr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int dh = q >> 1, dw = q & 1;
+        // input (h, w) as tap (kh, kw) of window (hb + dh, wb + dw): kh = h + 1 - 2*(hb + dh) = ih + 1 - 2*dh
+        const int kh = ih + 1 - 2 * dh, kw = iw + 1 - 2 * dw;
+        if (kh < 0 || kw < 0) continue;                       // (compile-time: the window does not reach this input)
+        const unsigned long long x = am[q] ^ ((unsigned long long)(kh * 3 + kw) * 0x0101010101010101ull);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (((x >> (8 * e)) & 0xffull) == 0) gr[e] += dv[q][e];
+      }
+      T* dst = (T*)dx.p + vox_off(dx, b, t, h, w) + g * 8;
+      if (accumulate) {
+        float o[8];
+        ld8<T>(dst, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gr[e] += o[e];
+      }
+      st8<T>(dst, gr);
+    }
+}
+
 // 3x3x3 / s1 / p1 backward, T-walking form: one lane owns an input column (b, h, w, 8 channels) and walks the
 // output planes; the argmax word of each of the 9 in-plane neighbour windows is read ONCE per plane and tested
 // against the three temporal taps it could route to, accumulating into three named accumulators (inputs
@@ -1653,6 +1731,14 @@ extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy
   }
   if (oct_ok(*dx) && oct_ok(*dy) && ((uintptr_t)argmax % 8) == 0) {
     const long total8 = view_voxels(*dx) * (dx->C / 8);
+    if (g_vinet_opt_pool_blk && d->kT == 1 && d->sT == 1 && d->pT == 0 && d->kH == 3 && d->kW == 3 && d->sH == 2 && d->sW == 2 && d->pH == 1 &&
+        d->pW == 1 && dy->T == dx->T && dy->H == (dx->H - 1) / 2 + 1 && dy->W == (dx->W - 1) / 2 + 1) {
+      const int HB = (dx->H + 1) / 2, WB = (dx->W + 1) / 2;
+      const long nthr = (long)dx->B * dx->T * HB * WB * (dx->C / 8);
+      DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_k133s2_kernel<T>, dim3(ew_grid(nthr)), dim3(256), 0, (hipStream_t)stream,
+                                                 make_view(*dy), argmax, make_view(*dx), accumulate, HB, WB, nthr);)
+      return vn_launch_status("maxpool3d_bwd(k133s2)");
+    }
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd8_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
                                                p, make_view(*dy), argmax, make_view(*dx), accumulate, total8);)
     return vn_launch_status("maxpool3d_bwd8");
