@@ -876,6 +876,17 @@ def test_maxpool(dt, ksp):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_upsample_quad_kernels(dt):
+    """the 4-channel one-output-per-lane kernels (8-channel block kernels are the default)"""
+    lib = _lib()
+    assert lib.vinet_set_option(b"up_blk", 0) == 0
+    try:
+        test_upsample(dt)
+    finally:
+        lib.vinet_set_option(b"up_blk", 1)
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_upsample(dt):
     B, T, H, W, Cc = 2, 3, 5, 7, 32
     xp, xmk = view_pair(B, T, H, W, Cc, dt, "ux", 1)
