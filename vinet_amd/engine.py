@@ -358,8 +358,13 @@ def import_grad_ncdhw(ctx, a, gt):
 
 
 def materialize(ctx, a, dst=None, out_dt=None):
-    """apply the pending affine (or just copy / convert) into `dst`; returns a plain Act."""
+    """apply the pending affine (or just copy / convert) into `dst`; returns a plain Act.
+
+    With a fresh destination of the activation dtype the result SHARES a's gradient storage: the gradient w.r.t. the
+    materialised values is the gradient w.r.t. a's post-affine output, which is what a.grad holds (the producer's BN
+    backward takes it from there), so backward needs no copy."""
     v = a.v
+    alias = dst is None and (out_dt is None or out_dt == v.dt) and v.dt == ctx.dt
     if dst is None:
         dt = ctx.dt if out_dt is None else out_dt
         dst = Act(View.alloc(v.B, v.T, v.H, v.W, v.C, dt, v.device))
@@ -367,6 +372,9 @@ def materialize(ctx, a, dst=None, out_dt=None):
     assert out.same_dims(v) and dst.plain
     ctx.call("vinet_copy_affine", C.byref(v.ct()), v.dt, a.affine(), C.byref(out.ct()), out.dt, 0, ctx.stream)
     dst.needs_grad = a.needs_grad
+    if alias:
+        dst.parent, dst.pc0, dst.pt0 = a, 0, None        # identity "slice": grad_view / readiness resolve into a's
+        return dst
     if ctx.recording and a.needs_grad:
         def bwd():
             dg = dst.grad_view()
@@ -733,6 +741,14 @@ def _splitk_scratch(ctx, d):
     return ws
 
 
+# Consumer-side BN (the pending affine applied at fragment time) costs the MFMA kernels 20-27 % in forward and weight
+# gradient, and keeps forward convs off the ping-pong kernel; writing relu(bn(x)) out once costs two passes over x.
+# Worth it when the conv does enough work per input element: N * taps above this threshold (0 = never).  Measured
+# on the whole step (128 clips): never 478 clips/s, 400: 483, 600: 491, 1000-1700: 491-493, 2500: 485 -- the 1x3x3
+# convs with >= 112 output channels pay, the 3x1x1 192->192 conv (576) does not.
+MATERIALIZE_NT = int(os.environ.get("VINET_MATERIALIZE_NT", "1000"))
+
+
 def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n_pad=None):
     """x -> conv (-> BN) (-> act).  Returns the output Act.
 
@@ -744,6 +760,9 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     `n_pad`       : store into a channel-padded output (N not a multiple of the vector width).
     """
     lib_dt = ctx.dt
+    if (MATERIALIZE_NT and x.scale is not None and ctx.dt != L.F32 and x.fold is None and not plan.stem and
+            plan.N * plan.ntaps >= MATERIALIZE_NT and x.v.dt == ctx.dt):
+        x = materialize(ctx, x)
     xv = x.v
     folded = plan.stem and x.fold is not None
     if folded:
