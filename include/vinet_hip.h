@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 6
+#define VINET_ABI_VERSION 7
 
 enum { VINET_F32 = 0, VINET_BF16 = 1 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
@@ -117,7 +117,12 @@ typedef struct VinetConvDesc {
                            device memory, the library cannot look); lets 64 -> 64 channel layers take the
                            frame-streaming kernel (conv_ts.hip).
                            2 = the taps are (0, kh, 0, slice kh), kh = 0..6: the folded RGB stem (row-streaming strip
-                           kernel, conv_hs.hip).  0 = no promise. */
+                           kernel, conv_hs.hip).
+                           3 = not a tap promise but a different problem: the WHOLE data gradient of a strided
+                           temporal conv in one launch (instead of one launch per stride phase): x = dy, y = dx,
+                           w = the transposed pack, ntaps / sT / tpad = kernel length, stride and padding of the
+                           FORWARD conv, oT = y.T; `taps` is ignored.  Only where
+                           vinet_conv3d_fuses_dgrad_phases(desc) returns 1.  0 = no promise. */
   int32_t tpad;
 } VinetConvDesc;
 
@@ -127,6 +132,8 @@ int vinet_conv3d(const VinetConvDesc* desc, void* stream);
  * result is run-to-run deterministic, and applies the epilogue); 0 when it would not split (enough tiles,
  * short K, statistics or accumulate requested). */
 int64_t vinet_conv3d_splitk_bytes(const VinetConvDesc* desc);
+/* 1 if vinet_conv3d accepts this tline == 3 descriptor (fused stride phases of a temporal data gradient). */
+int vinet_conv3d_fuses_dgrad_phases(const VinetConvDesc* desc);
 /* BM of the tile configuration vinet_conv3d will pick for this problem. */
 int vinet_conv3d_tile_m(const VinetConvDesc* desc);
 /* Name of the kernel instantiation vinet_conv3d will launch for this problem

@@ -185,9 +185,34 @@ class AbiEmulator:
         g = _gather(g, np.arange(oW) * d.sW + dw_, 3, x.shape[3])
         return g
 
+    def vinet_conv3d_fuses_dgrad_phases(self, d):
+        d = _deref(d)
+        return 1 if (d.tline == 3 and d.dtype == BF16 and d.x.C == 64 and d.y.C == 64 and d.sT >= 2) else 0
+
+    def _conv3d_tsd(self, d):
+        """tline == 3: dx[ti] (+)= sum_{kt: (ti + p - kt) % s == 0} dy[(ti + p - kt) / s] @ wt[kt]^T"""
+        assert self.vinet_conv3d_fuses_dgrad_phases(d)
+        dy = rd(d.x, d.dtype)
+        k, s, p = d.ntaps, d.sT, d.tpad
+        Cc, N = d.y.C, d.x.C
+        wraw = _raw(d.w, k * Cc * d.Kp, d.dtype)
+        w = (wraw.astype(np.float32) if d.dtype == F32 else _bf2f(wraw)).reshape(k, Cc, d.Kp)[:, :, :N]
+        B, To = dy.shape[0], dy.shape[1]
+        out = np.zeros((B, d.y.T, d.y.H, d.y.W, Cc), np.float32)
+        for ti in range(d.y.T):
+            for kt in range(k):
+                num = ti + p - kt
+                if num % s == 0 and 0 <= num // s < To:
+                    out[:, ti] += (torch.from_numpy(np.ascontiguousarray(dy[:, num // s]).reshape(-1, N)) @
+                                   torch.from_numpy(w[kt].T.copy())).numpy().reshape(B, d.y.H, d.y.W, Cc)
+        wr(d.y, d.out_dtype, out, bool(d.accumulate))
+        return 0
+
     def vinet_conv3d(self, d, stream):
         d = _deref(d)
         self.calls.append("conv3d")
+        if d.tline == 3:
+            return self._conv3d_tsd(d)
         x = affine(rd(d.x, d.dtype), d.pre, d.x.C)
         N = d.y.C
         Nw = d.n_valid if d.n_valid > 0 else N

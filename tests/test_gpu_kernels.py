@@ -231,6 +231,41 @@ def test_conv3d_tstream(case):
         lib.vinet_set_option(b"conv_ts", 1)
 
 
+@pytest.mark.parametrize("ksp", [(7, 2, 3), (3, 2, 1), (2, 2, 0), (5, 3, 2)], ids=["k7s2p3", "k3s2p1", "k2s2p0", "k5s3p2"])
+@pytest.mark.parametrize("acc", [0, 1])
+def test_conv3d_tstream_dgrad_fused(ksp, acc):
+    """the whole data gradient of a strided temporal 64 -> 64 conv in one launch (tline == 3)"""
+    lib = _lib()
+    dt = E.BF16
+    k, s, p = ksp
+    B, Ti, H, W, Cc = 2, 11, 8, 8, 64
+    To = (Ti + 2 * p - k) // s + 1
+    xp, xmk = view_pair(B, To, H, W, Cc, dt, "fdy", 1, ld=96, c_off=16)
+    yp, ymk = view_pair(B, Ti, H, W, Cc, dt, "fdx", 2, fill=0.25)
+    wp = Pair((_rand("fdw", (k * Cc * Cc,), 3, 0.05)).to(E.TORCH_DT[dt]))
+
+    def mk(side):
+        d = L.CConvDesc()
+        d.dtype, d.out_dtype, d.mode = dt, dt, 0
+        d.x, d.y = xmk(side).ct(), ymk(side).ct()
+        d.oT, d.oH, d.oW = Ti, H, W
+        d.sT, d.sH, d.sW = s, 1, 1
+        d.omT = d.omH = d.omW = 1
+        d.ntaps, d.taps, d.w, d.Kp = k, None, wp.ptr(side), 64
+        d.pre = L.CAffine(None, None, 0)
+        d.accumulate = acc
+        d.tline, d.tpad = 3, p
+        return [C.byref(d), _stream() if side == "gpu" else 0]
+
+    assert lib.vinet_set_option(b"conv_ts", 2) == 0
+    try:
+        assert lib.vinet_conv3d_fuses_dgrad_phases(mk("gpu")[0]) == 1
+        run_both("vinet_conv3d", mk)
+    finally:
+        lib.vinet_set_option(b"conv_ts", 1)
+    _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "fused temporal dgrad")
+
+
 @pytest.mark.parametrize("r", [0, 1])
 def test_conv3d_tstream_dgrad_phase(r):
     """one stride phase of the 7x1x1 / 2 data gradient: taps (e - j, slice d0 + 2j) in descending offset order, output

@@ -210,7 +210,7 @@ def test_stem_strip_kernels_and_fused_bn_backward():
     res = []
     for fast in (1, 0):
         E.BN_BWD_FUSE = fast
-        for name in (b"conv_hs", b"wgrad_hs"):
+        for name in (b"conv_hs", b"wgrad_hs", b"conv_ts", b"wgrad_ts"):
             assert lib.vinet_set_option(name, 2 if fast else 0) == 0
         try:
             torch.manual_seed(5)
@@ -223,7 +223,7 @@ def test_stem_strip_kernels_and_fused_bn_backward():
             res.append([y.detach()] + [p.grad for p in blk.parameters()] + [b.float() for b in blk.buffers()])
         finally:
             E.BN_BWD_FUSE = 1
-            for name in (b"conv_hs", b"wgrad_hs"):
+            for name in (b"conv_hs", b"wgrad_hs", b"conv_ts", b"wgrad_ts"):
                 lib.vinet_set_option(name, 1)
     for a, b in zip(*res):
         scale = max(1.0, float(b.abs().max()))

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class CTensor(C.Structure):
@@ -74,6 +74,7 @@ SIGNATURES = {
     "vinet_stats_rows": [_PT],
     "vinet_bn_bwd_reduce": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp],
     "vinet_conv3d_wgrad_fuses_bn_bwd": [_PW],
+    "vinet_conv3d_fuses_dgrad_phases": [_PC],
     "vinet_bn_partials_fold": [_vp, _i32, _i32, _vp, _i32, _vp],
     "vinet_bn_bwd_finalize": [_vp, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "vinet_bn_bwd_apply": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp, _PT, _vp],

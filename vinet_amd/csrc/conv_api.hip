@@ -117,6 +117,8 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
 static bool use_pp(const VinetConvDesc* d);
 bool vinet_conv_use_ts(const VinetConvDesc* d);
 bool vinet_conv_use_hs(const VinetConvDesc* d);
+bool vinet_conv_use_tsd(const VinetConvDesc* d);
+int vinet_launch_conv_tsd(const VinetConvDesc* d, hipStream_t s);
 int vinet_launch_conv_hs(const VinetConvDesc* d, hipStream_t s);
 extern int g_vinet_opt_conv_hs;
 int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s);
@@ -260,7 +262,8 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   if (!d || !buf || n <= 0) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32));
-  if (vinet_conv_use_hs(d)) snprintf(buf, n, "conv_hs_kernel");
+  if (d->tline == 3) snprintf(buf, n, vinet_conv_use_tsd(d) ? "conv_tsd_kernel" : "(unsupported)");
+  else if (vinet_conv_use_hs(d)) snprintf(buf, n, "conv_hs_kernel");
   else if (vinet_conv_use_ts(d)) snprintf(buf, n, "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
   else if (use_pp(d)) snprintf(buf, n, "conv_pp_kernel<%d>", pp_bn(d->y.C));
   else if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
@@ -268,7 +271,15 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   return 0;
 }
 
+extern "C" int vinet_conv3d_fuses_dgrad_phases(const VinetConvDesc* d) {
+  return d && d->tline == 3 && vinet_conv_use_tsd(d) ? 1 : 0;
+}
+
 extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
+  if (d && d->tline == 3) {     // whole data gradient of a strided temporal conv: no tap table, x = dy, y = dx
+    VN_CHECK_ARG(vinet_conv_use_tsd(d), "conv: tline == 3 (fused stride phases) is not available for this problem; ask vinet_conv3d_fuses_dgrad_phases first");
+    return vinet_launch_conv_tsd(d, (hipStream_t)stream);
+  }
   ConvArgs a;
   ConvTile t;
   int rc = fill_args(d, a, t);

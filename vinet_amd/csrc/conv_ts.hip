@@ -292,3 +292,180 @@ int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s) {
   else hipLaunchKernelGGL(kn, dim3(grid), dim3(256), smem, s, a);
   return vn_launch_status("conv_ts");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Data gradient of a STRIDED temporal conv in one launch (VinetConvDesc::tline == 3):
+//
+//   dx[b, ti, p, c] (+)= sum over kt with (ti + pad - kt) % s == 0 of  sum_n dy[b, (ti + pad - kt) / s, p, n] * wt[kt][c][n]
+//
+// The per-phase form (one conv_ts launch per stride phase, engine._phase_taps_1d) reads dy once per phase.  Here the
+// workgroup walks ALL input frames ti; the dy frames live in the LDS ring (a new one every s steps), every tap's
+// weights stay in registers, and the taps of the step's phase are picked by a uniform predicate: dy is read once.
+struct ConvTsdArgs {
+  const char* x;        // dy [B][To][HW][64]
+  char* y;              // dx [B][Ti][HW][64]
+  const char* w;        // transposed pack [k][64 c][64 n]
+  int To, Ti, HW, ldx, ldy;
+  long sBx, sBy;
+  int k, s, pad, accumulate;
+  int items, patches;
+  FastDiv dPatches;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_tsd_kernel(const ConvTsdArgs a) {
+  constexpr int KMAX = 7, TILE = 64 * 64 * 2, NSLOT = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;                                   // NSLOT dy frames, slot = frame & 7
+  char* stage = smem + NSLOT * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int k = a.k, s = a.s;
+  const int l_chunk = tid & 7, l_row = tid >> 3;
+  int l_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = l_row + 32 * j;
+    l_off[j] = r * 128 + ((l_chunk ^ (r & 7)) * 16);
+  }
+  bf16x8_v wr[KMAX][2][2];
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = wn * 32 + nt * 16 + (lane & 15), n = ks * 32 + (lane >> 4) * 8;
+        if (i < k) wr[i][nt][ks] = *(const bf16x8_v*)(a.w + (((long)i * 64 + c) * 64 + n) * 2);
+        else wr[i][nt][ks] = (bf16x8_v){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+  const bf16x8_v zero_a = (bf16x8_v){0, 0, 0, 0, 0, 0, 0, 0};
+
+  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const int b = (int)fdiv((uint32_t)item, a.dPatches);
+    const int pos0 = (item - b * a.patches) * 64;
+    const char* xb = a.x + ((long)b * a.sBx + (long)(pos0 + l_row) * a.ldx + l_chunk * 8) * 2;
+    char* yb = a.y + ((long)b * a.sBy + (long)(pos0 + l_row) * a.ldy + l_chunk * 8) * 2;
+    const long x_plane = (long)a.HW * a.ldx * 2, y_plane = (long)a.HW * a.ldy * 2;
+    const long x_r32 = 32L * a.ldx * 2, y_r32 = 32L * a.ldy * 2;
+
+    // ---- prologue: dy frames 0 .. pad / s (everything step 0 can read) -------------------------------------
+    const int q_first = a.pad / s;
+    for (int f = 0; f <= q_first && f < a.To; ++f) {
+      char* slot = ring + (f & (NSLOT - 1)) * TILE;
+      *(uint4*)(slot + l_off[0]) = *(const uint4*)(xb + f * x_plane);
+      *(uint4*)(slot + l_off[1]) = *(const uint4*)(xb + f * x_plane + x_r32);
+    }
+    __syncthreads();
+
+    for (int ti = 0; ti < a.Ti; ++ti) {
+      const int tp = ti + a.pad;
+      const int q = tp / s, r = tp - q * s;
+      // next step needs frame q + 1 iff (tp + 1) % s == 0
+      const int qn = (tp + 1) / s;
+      const bool newf = ti + 1 < a.Ti && qn != q && qn < a.To;
+      const char* xs = xb + (newf ? qn : 0) * x_plane;
+      const uint4 nx0 = *(const uint4*)xs, nx1 = *(const uint4*)(xs + x_r32);
+      char* yf = yb + (long)ti * y_plane;
+      uint4 old0 = make_uint4(0, 0, 0, 0), old1 = old0;
+      if (a.accumulate) { old0 = *(const uint4*)yf; old1 = *(const uint4*)(yf + y_r32); }
+
+      f32x4_v acc[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) mfma_bf16_first_bacc(acc[mt][nt], zero_a, wr[0][nt][0]);     // = 0
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        const int d = i - r;                                   // tap i belongs to this step's phase iff d >= 0, d % s == 0
+        if (i < k && d >= 0 && d % s == 0) {
+          const int f = q - d / s;                             // dy frame it reads
+          if (f >= 0 && f < a.To) {
+            const char* fr = ring + (f & (NSLOT - 1)) * TILE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              bf16x8_v af[2];
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) {
+                const int row = wm * 32 + mt * 16 + (lane & 15), ch = ks * 4 + (lane >> 4);
+                af[mt] = *(const bf16x8_v*)(fr + row * 128 + ((ch ^ (row & 7)) * 16));
+              }
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) mfma_bf16_acc_bacc(acc[mt][nt], af[mt], wr[i][nt][ks]);
+            }
+          }
+        }
+      }
+      mfma_drain();
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int row = wm * 32 + mt * 16 + (lane >> 4) * 4 + rr, col = wn * 32 + nt * 16 + (lane & 15);
+            *(bf16_t*)(stage + row * 128 + (((col >> 3) ^ (row & 7)) * 16) + (col & 7) * 2) = f2bf(acc[mt][nt][rr]);
+          }
+      __syncthreads();
+      {
+        uint4 o0 = *(const uint4*)(stage + l_off[0]), o1 = *(const uint4*)(stage + l_off[1]);
+        if (a.accumulate) {
+          auto add2 = [](uint32_t p, uint32_t q2) -> uint32_t {
+            return pack2bf(__uint_as_float(p << 16) + __uint_as_float(q2 << 16),
+                           __uint_as_float(p & 0xffff0000u) + __uint_as_float(q2 & 0xffff0000u));
+          };
+          o0 = make_uint4(add2(o0.x, old0.x), add2(o0.y, old0.y), add2(o0.z, old0.z), add2(o0.w, old0.w));
+          o1 = make_uint4(add2(o1.x, old1.x), add2(o1.y, old1.y), add2(o1.z, old1.z), add2(o1.w, old1.w));
+        }
+        *(uint4*)yf = o0;
+        *(uint4*)(yf + y_r32) = o1;
+      }
+      if (newf) {
+        char* slot = ring + (qn & (NSLOT - 1)) * TILE;
+        *(uint4*)(slot + l_off[0]) = nx0;
+        *(uint4*)(slot + l_off[1]) = nx1;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// tline == 3: x = dy, y = dx, ntaps = k, sT = s of the FORWARD conv, tpad = its temporal padding, w = transposed pack
+bool vinet_conv_use_tsd(const VinetConvDesc* d) {
+  if (!g_vinet_opt_conv_ts || d->tline != 3 || d->dtype != VINET_BF16 || d->out_dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
+  if (d->pre.scale || d->pre.relu || d->stats || d->out_scale || d->out_shift || d->act != VINET_ACT_NONE) return false;
+  const long HW = (long)d->oH * d->oW;
+  const int k = d->ntaps, s = d->sT, p = d->tpad;
+  const bool shape = d->x.C == 64 && d->y.C == 64 && (d->n_valid == 0 || d->n_valid == 64) && d->Kp == 64 && k >= 2 && k <= 7 && s >= 2 && s <= 4 &&
+                     k >= s && (k + s - 1) / s <= 7 && p >= 0 && p < k && d->x.H == d->oH && d->x.W == d->oW && d->y.H == d->oH && d->y.W == d->oW &&
+                     HW % 64 == 0 && d->oT == d->y.T && d->x.T == (d->y.T + 2 * p - k) / s + 1 && d->omT == 1 && d->omH == 1 && d->omW == 1 &&
+                     d->ooT == 0 && d->ooH == 0 && d->ooW == 0 && d->x.ld % 8 == 0 && d->y.ld % 8 == 0 && d->x.sB % 8 == 0 && d->y.sB % 8 == 0 &&
+                     ((uintptr_t)d->x.ptr % 16) == 0 && ((uintptr_t)d->y.ptr % 16) == 0;
+  if (!shape) return false;
+  if (g_vinet_opt_conv_ts >= 2) return true;
+  return (long)d->x.B * (HW / 64) >= 2048 && d->oT >= 4;
+}
+
+int vinet_launch_conv_tsd(const VinetConvDesc* d, hipStream_t s) {
+  ConvTsdArgs a;
+  a.x = (const char*)d->x.ptr; a.y = (char*)d->y.ptr; a.w = (const char*)d->w;
+  a.To = d->x.T; a.Ti = d->y.T; a.HW = d->oH * d->oW; a.ldx = d->x.ld; a.ldy = d->y.ld; a.sBx = d->x.sB; a.sBy = d->y.sB;
+  a.k = d->ntaps; a.s = d->sT; a.pad = d->tpad; a.accumulate = d->accumulate;
+  a.patches = a.HW / 64;
+  a.items = d->x.B * a.patches;
+  a.dPatches = make_fastdiv((uint32_t)a.patches);
+  const int smem = 9 * 64 * 64 * 2;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_tsd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_tsd): %s", hipGetErrorString(e)); return (int)e; }
+    attr_done[dev & 63] = true;
+  }
+  int grid = 512;
+  if (grid > a.items) grid = a.items;
+  hipLaunchKernelGGL(conv_tsd_kernel, dim3(grid), dim3(256), smem, s, a);
+  return vn_launch_status("conv_tsd");
+}

@@ -982,6 +982,29 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         dx = x.grad_view(zero=(not ready and not full))
         acc = 1 if x.is_grad_ready() else 0
         wt = plan.packed(ctx, True)
+        if plan.temporal and plan.s[0] > 1 and len(phases) > 1:
+            # all stride phases of a temporal data gradient in one launch where the library has a kernel for it
+            # (dy is read once instead of once per phase): include/vinet_hip.h, tline == 3
+            d = L.CConvDesc()
+            d.dtype, d.out_dtype, d.mode = ctx.dt, dx.dt, L.CONV_GENERIC
+            d.x, d.y = dy.ct(), dx.ct()
+            d.oT, d.oH, d.oW = xv.T, xv.H, xv.W
+            d.sT, d.sH, d.sW = plan.s[0], 1, 1
+            d.omT = d.omH = d.omW = 1
+            d.ooT = d.ooH = d.ooW = 0
+            d.ntaps, d.taps, d.w, d.Kp = plan.k[0], None, wt.data_ptr(), plan.kp(True)
+            d.pre = L.CAffine(None, None, 0)
+            d.out_scale = d.out_shift = None
+            d.act, d.accumulate, d.stats = L.ACT_NONE, acc, None
+            d.n_valid = plan.Cin if xv.C != plan.Cin else 0
+            d.tline, d.tpad = 3, plan.p[0]
+            if ctx.lib.vinet_conv3d_fuses_dgrad_phases(C.byref(d)):
+                es = ESIZE[ctx.dt]
+                ctx.call("vinet_conv3d", C.byref(d), ctx.stream,
+                         tag=("conv_tsd_kernel | dgrad " + plan.site(xv)) if PROFILER is not None else None,
+                         work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
+                                   bytes=float(xv.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * es)))
+                phases = []
         for ph in phases:
             d = L.CConvDesc()
             d.dtype, d.out_dtype, d.mode = ctx.dt, dx.dt, L.CONV_GENERIC
