@@ -760,6 +760,24 @@ def test_import_export_copy(dt):
         _cmp(yp.get("gpu"), yp.get("cpu"), 1e-6 if odt == E.F32 else 1e-2, "copy_affine")
 
 
+@pytest.mark.parametrize("acc", [0, 1])
+@pytest.mark.parametrize("aff", [0, 1, 2], ids=["plain", "affine_relu", "relu_only"])
+def test_copy_affine_streaming(acc, aff):
+    """the 8-channel streaming copy (bf16, >= 65536 voxels): sliced views on both sides, affine + ReLU, accumulate"""
+    B, T, H, W, Cc = 2, 2, 128, 128, 24
+    dt = E.BF16
+    sp, smk = view_pair(B, T, H, W, Cc, dt, "cas", 1, ld=40, c_off=8)
+    dp, dmk = view_pair(B, T, H, W, Cc, dt, "cad", 2, ld=56, c_off=16)
+    ps, ph = fvec("caps", Cc, 3, 0.5, 1.5), fvec("caph", Cc, 4)
+
+    def pre(side):
+        if aff == 1:
+            return L.CAffine(ps.ptr(side), ph.ptr(side), 1)
+        return L.CAffine(None, None, 1 if aff == 2 else 0)
+    run_both("vinet_copy_affine", lambda s: [C.byref(smk(s).ct()), dt, pre(s), C.byref(dmk(s).ct()), dt, acc, _stream() if s == "gpu" else 0])
+    _cmp(dp.get("gpu"), dp.get("cpu"), 1e-2, "copy_affine streaming")
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("Cc", [16, 24, 64, 208, 528, 1024])
 def test_bn_kernels(dt, Cc):

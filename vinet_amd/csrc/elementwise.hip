@@ -295,6 +295,52 @@ __global__ void copy_affine_kernel(TView src, Affine pre, TView dst, int accumul
   stq<TO>(d, v);
 }
 
+// 8-channel form (structure of bn_bwd_apply8_kernel): a lane keeps the scale / shift of its 8 channels in registers
+// and streams voxels, 16-byte loads and stores, 4 voxels in flight -- the quad kernel above pays a voxel decode and
+// two coefficient loads per 8 bytes.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void copy_affine8_kernel(TView src, Affine pre, TView dst, int accumulate, long nvox, long vb) {
+  const int G = src.C / 8;
+  const int Gb = G < 256 ? G : 256;
+  const int R = 256 / Gb;
+  const int r = threadIdx.x / Gb;
+  const int g0 = threadIdx.x % Gb;
+  if (r >= R) return;
+  const long v0 = (long)blockIdx.x * vb;
+  long v1 = v0 + vb; if (v1 > nvox) v1 = nvox;
+  for (int g = g0; g < G; g += Gb) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = pre.scale ? pre.scale[g * 8 + e] : 1.f; sh[e] = pre.scale ? pre.shift[g * 8 + e] : 0.f; }
+    constexpr int U = 4;
+    for (long vq = v0 + r; vq < v1; vq += (long)R * U) {
+      float xv[U][8], ov[U][8];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long v = vq + (long)u * R;
+        ok[u] = v < v1;
+        if (ok[u]) {
+          ld8<TI>((const TI*)src.p + vox_lin(src, v) + g * 8, xv[u]);
+          if (accumulate) ld8<TO>((const TO*)dst.p + vox_lin(dst, v) + g * 8, ov[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = pre.scale ? fmaf(xv[u][e], sc[e], sh[e]) : xv[u][e];
+          if (pre.relu) t = fmaxf(t, 0.f);
+          o[e] = accumulate ? t + ov[u][e] : t;
+        }
+        st8<TO>((TO*)dst.p + vox_lin(dst, vq + (long)u * R) + g * 8, o);
+      }
+    }
+  }
+}
+
 extern "C" int vinet_copy_affine(const VinetTensor* src, int32_t src_dtype, VinetAffine pre, const VinetTensor* dst,
                                  int32_t dst_dtype, int32_t accumulate, void* stream) {
   VN_CHECK_ARG(src && dst && quad_ok(*src, esize(src_dtype)) && quad_ok(*dst, esize(dst_dtype)) && same_dims(*src, *dst),
@@ -303,6 +349,14 @@ extern "C" int vinet_copy_affine(const VinetTensor* src, int32_t src_dtype, Vine
   hipStream_t s = (hipStream_t)stream;
   const TView sv = make_view(*src), dv = make_view(*dst);
   const Affine a = make_affine(pre);
+  if (src_dtype == VINET_BF16 && dst_dtype == VINET_BF16 && oct_ok(*src) && oct_ok(*dst) && view_voxels(*src) >= 65536) {
+    const long nvox = view_voxels(*src);
+    const int G = src->C / 8, R = 256 / (G < 256 ? G : 256);
+    long vb = R * 16;
+    while ((nvox + vb - 1) / vb > 16384) vb *= 2;
+    hipLaunchKernelGGL((copy_affine8_kernel<bf16_t, bf16_t>), dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, s, sv, a, dv, accumulate, nvox, vb);
+    return vn_launch_status("copy_affine8");
+  }
   const dim3 g(ew_grid(total)), blk(256);
   if (src_dtype == VINET_F32 && dst_dtype == VINET_F32) hipLaunchKernelGGL((copy_affine_kernel<float, float>), g, blk, 0, s, sv, a, dv, accumulate, total);
   else if (src_dtype == VINET_F32) hipLaunchKernelGGL((copy_affine_kernel<float, bf16_t>), g, blk, 0, s, sv, a, dv, accumulate, total);
