@@ -160,7 +160,10 @@ typedef struct VinetWgradDesc {
                            kt = 0..ntaps-1 (the tap table lives in device memory, the library cannot look);
                            lets 64 -> 64 channel layers take the frame-streaming kernel.
                            2 = the taps are (0, kh, 0, slice kh), kh = 0..6: the folded RGB stem (row-streaming strip
-                           kernel).  0 = no promise. */
+                           kernel).
+                           4 = the taps are (kt, kh-1, kw-1, slice (kt*3 + kh)*3 + kw), kt < ntaps / 9: a kT x 3 x 3
+                           kernel with stride (kT,1,1), padding (0,1,1) (the decoder convs; row-streaming kernel for
+                           64 output channels).  0 = no promise. */
   int32_t tpad;
   /* Optional fused BatchNorm(+ReLU) backward.  With bnb_z != NULL, `dy` is the gradient w.r.t. the OUTPUT of the
    * BatchNorm that follows this conv, bnb_z the raw conv output (same B/T/H/W/C as dy), and the kernel forms

@@ -656,6 +656,30 @@ def test_conv3d_wgrad_tstream(case):
         lib.vinet_set_option(b"wgrad_ts", 1)
 
 
+# row-streaming wgrad of kT x 3 x 3 / (kT,1,1) convs with 64 output channels (the 192 -> 64 decoder layer): one, two
+# and three K steps per row, 1 / 2 / 5 temporal taps, several channel chunks, sliced views, a 2-row image
+WGRAD_RS_CASES = [
+    ("rs_w32_k5", (2, 10, 6, 32), 128, 64, (5, 3, 3), (5, 1, 1), (0, 1, 1), False),
+    ("rs_w64_k2", (1, 4, 5, 64), 64, 64, (2, 3, 3), (2, 1, 1), (0, 1, 1), False),
+    ("rs_w96_k1", (2, 2, 4, 96), 192, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+    ("rs_slices", (1, 6, 2, 32), 64, 64, (3, 3, 3), (3, 1, 1), (0, 1, 1), False, dict(x_ld=160, x_coff=32, dy_ld=112, dy_coff=16)),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_RS_CASES, ids=[c[0] for c in WGRAD_RS_CASES])
+def test_conv3d_wgrad_rowstream(case):
+    lib = _lib()
+    assert lib.vinet_set_option(b"wgrad_rs", 2) == 0
+    try:
+        ex = dict(case[8]) if len(case) > 8 else {}
+        ex["tline"] = 4
+        d0 = _run_wgrad_case(case[:8] + (ex,), E.BF16)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_wgrad_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_wgrad_rs_kernel<")
+    finally:
+        lib.vinet_set_option(b"wgrad_rs", 1)
+
+
 def _run_wgrad_case(case, dt):
     name, (B, T, H, W), Cin, N, k, s, p, pre = case[:8]
     ex = case[8] if len(case) > 8 else {}
@@ -676,7 +700,7 @@ def _run_wgrad_case(case, dt):
         d.ntaps, d.taps, d.dw, d.Kp = ntaps, taps.ptr(side), dw.ptr(side), Kp
         d.pre = L.CAffine(ps.ptr(side), ph.ptr(side), 1) if pre else L.CAffine(None, None, 0)
         if ex.get("tline"):
-            d.tline, d.tpad = 1, p[0]
+            d.tline, d.tpad = (1 if ex["tline"] is True else ex["tline"]), p[0]
         return [C.byref(d), _stream() if side == "gpu" else 0]
 
     run_both("vinet_conv3d_wgrad", mk)

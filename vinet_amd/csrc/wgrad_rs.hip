@@ -1,0 +1,225 @@
+// Weight gradient of a kT x 3 x 3 conv with stride (kT,1,1), padding (0,1,1) and 64 output channels -- the last big
+// decoder layer, 192 -> 64, 5x3x3 / (5,1,1) at 20 x 56 x 96 (model.py:273; 3.0 TFLOP per step at 128 clips) -- as a
+// row-streaming kernel:
+//
+//   dw[kt*9 + kh*3 + kw][n][c] += sum_{b,to,h,w} dy[b,to,h,w,n] * x[b, to*kT + kt, h+kh-1, w+kw-1, c]
+//
+// conv_wgrad_dma_kernel<64,64,9> stages nine shifted copies of every x row (17 B per kFLOP: 347 TF/s, bound by the
+// CU's load path).  Temporal taps do not overlap (stride = kT), spatial ones do, so a workgroup fixes (kt, a 64-channel
+// chunk of x) and walks the image rows of its (clip, output frame) items with the THREE live x rows in an LDS ring:
+// one new x row and one dy row per step, 3.5 B per kFLOP, and the nine taps are nine fragment ADDRESSES into the
+// ring (row kh, position w + kw; the ring rows carry a zero position on either side).
+//
+//   * 512 threads = 8 waves; wave w owns input channels [16(w&3), +16) of the chunk x all 9 taps x output channels
+//     [32(w>>2), +32): 18 accumulator tiles (72 AGPRs; the whole 9 x 64 x 64 block is 144 registers per lane at 256
+//     threads, more than the accumulator file holds beside two waves per SIMD); per step 9 x 2 x (W/32) MFMAs from
+//     9 x (W/32) x-fragments and 2 x (W/32) dy-fragments (ds_read_b64_tr_b16, both operands position-major, 16-byte
+//     chunk XOR as wgrad_dma.hip);
+//   * loads of the next row are issued before the MFMAs of the current one (named registers: see wgrad_ts.hip);
+//   * the grid is (kT x Cin/64) groups x workers; a worker keeps its accumulators over all its items and flushes
+//     once with fp32 atomics (dw is zero on entry).
+#include "common.h"
+
+struct WgradRsArgs {
+  const char* x;
+  const char* dy;
+  float* dw;
+  long sBx, sBy;
+  int Ti, To, H, W, ldx, ldy;
+  int kT, cchunks, Kp;
+  int items, workers;          // items = B * To, workers per group
+  FastDiv dTo;
+};
+
+VN_DEV int wrs_swz(int r) { return ((r >> 1) & 1) << 1; }
+
+template <int KS>              // W / 32: K steps per image row (1, 2 or 3)
+__global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs a) {
+  constexpr int W = KS * 32, RP = W + 2;            // positions per ring row (zero pads at 0 and W + 1)
+  constexpr int XROW = RP * 128, DROW = W * 128;
+  constexpr int NPC = W * 8;                        // 16-byte pieces of one row (x or dy)
+  constexpr int PPT = (NPC + 511) / 512;            // ... per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;                                // 3 x rows
+  char* dyb = smem + 3 * XROW;                      // 2 dy rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int groups = a.kT * a.cchunks;
+  const int grp = blockIdx.x % groups, worker = blockIdx.x / groups;
+  const int kt = grp / a.cchunks, c0 = (grp - kt * a.cchunks) * 64;
+
+  const int ct = wave & 3, nh = wave >> 2;
+  // piece roles: piece q = tid + 512*j -> position q >> 3 (0..W-1), chunk q & 7
+  int x_off[PPT], d_off[PPT], g_pos[PPT];
+  bool p_ok[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int q = tid + 512 * j;
+    p_ok[j] = q < NPC;
+    const int pos = p_ok[j] ? q >> 3 : 0, ch = q & 7;
+    g_pos[j] = pos;
+    x_off[j] = (pos + 1) * 128 + ((ch ^ wrs_swz(pos + 1)) * 16);
+    d_off[j] = pos * 128 + ((ch ^ wrs_swz(pos)) * 16);
+  }
+  const int l_chunk = tid & 7;
+  // zero the pad positions of the three ring rows once (never written again)
+  if (tid < 3 * 2 * 8) {     // (48 threads)
+    const int row = tid / 16, side = (tid >> 3) & 1, ch = tid & 7;
+    *(uint4*)(ring + row * XROW + (side ? (W + 1) * 128 : 0) + ch * 16) = make_uint4(0, 0, 0, 0);
+  }
+
+  f32x4_v acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[t][i] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+
+  // K-major fragment: 8 positions x 1 channel per lane; `shift` moves the positions along the ring row (tap kw)
+  auto frag = [&](const char* row, int ks, int shift, int col0) -> bf16x8_v {
+    union { bf16x8_v v; s16x4_v h[2]; } u;
+    const int p = lane & 15;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pos = ks * 32 + (lane >> 4) * 8 + h * 4 + (p >> 2) + shift;
+      const int col = col0 + (p & 3) * 4;
+      const int ch = (col >> 3) ^ wrs_swz(pos);
+      u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(row + pos * 128 + ch * 16 + (col & 7) * 2));
+    }
+    return u.v;
+  };
+
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  // (a `cond ? vec : zero` on a 16-byte value is lowered to a two-entry scratch array indexed by the condition, with
+  //  a wait on the prefetch load in front of the store: mask the words instead)
+  auto keep = [](uint4 v, bool on) -> uint4 {
+    const uint32_t m = on ? 0xffffffffu : 0u;
+    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+  };
+  for (int item = worker; item < a.items; item += a.workers) {
+    const int b = (int)fdiv((uint32_t)item, a.dTo);
+    const int to = item - b * a.To;
+    const int t = to * a.kT + kt;
+    const char* xb = a.x + ((long)b * a.sBx + (long)t * a.H * a.W * a.ldx + c0 + l_chunk * 8) * 2;     // + (h*W + pos) * ldx * 2
+    const char* db = a.dy + ((long)b * a.sBy + (long)to * a.H * a.W * a.ldy + l_chunk * 8) * 2;
+    const long x_rowb = (long)a.W * a.ldx * 2, d_rowb = (long)a.W * a.ldy * 2;
+
+    // ---- prologue: x rows -1 (zeros) and 0 into slots 2 and 0, dy row 0 ---------------------------------------
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+      if (p_ok[j]) {
+        *(uint4*)(ring + 2 * XROW + x_off[j]) = z4;
+        *(uint4*)(ring + 0 * XROW + x_off[j]) = *(const uint4*)(xb + (long)g_pos[j] * a.ldx * 2);
+        *(uint4*)(dyb + d_off[j]) = *(const uint4*)(db + (long)g_pos[j] * a.ldy * 2);
+      }
+    // x row 1 (the "next row" of a virtual step -1); unconditional loads from a clamped row, zero by select
+    {
+      const char* x1 = xb + (1 < a.H ? x_rowb : 0);
+      const uint4 r0 = *(const uint4*)(x1 + (long)g_pos[0] * a.ldx * 2);
+      const uint4 r1 = *(const uint4*)(x1 + (long)g_pos[PPT > 1 ? 1 : 0] * a.ldx * 2);
+      if (p_ok[0]) *(uint4*)(ring + 1 * XROW + x_off[0]) = keep(r0, 1 < a.H);
+      if (PPT > 1 && p_ok[PPT > 1 ? 1 : 0]) *(uint4*)(ring + 1 * XROW + x_off[PPT > 1 ? 1 : 0]) = keep(r1, 1 < a.H);
+    }
+    __syncthreads();
+
+    // ring slot of image row r: (r + 3) % 3; step h reads rows h-1, h, h+1 and dy row h (buffer h & 1)
+    for (int h = 0; h < a.H; ++h) {
+      // ---- loads for step h+1: x row h+2, dy row h+1 -------------------------------------------------------------
+      const bool more = h + 1 < a.H;
+      const bool xin = more && h + 2 < a.H;
+      const char* xs = xb + (xin ? h + 2 : 0) * x_rowb;
+      const char* ds = db + (more ? h + 1 : 0) * d_rowb;
+      uint4 nx0 = z4, nx1 = z4, nx2 = z4, nd0 = z4, nd1 = z4, nd2 = z4;
+      nx0 = *(const uint4*)(xs + (long)g_pos[0] * a.ldx * 2);
+      nd0 = *(const uint4*)(ds + (long)g_pos[0] * a.ldy * 2);
+      if (PPT > 1) { nx1 = *(const uint4*)(xs + (long)g_pos[PPT > 1 ? 1 : 0] * a.ldx * 2); nd1 = *(const uint4*)(ds + (long)g_pos[PPT > 1 ? 1 : 0] * a.ldy * 2); }
+      if (PPT > 2) { nx2 = *(const uint4*)(xs + (long)g_pos[PPT > 2 ? 2 : 0] * a.ldx * 2); nd2 = *(const uint4*)(ds + (long)g_pos[PPT > 2 ? 2 : 0] * a.ldy * 2); }
+
+      // ---- MFMAs --------------------------------------------------------------------------------------------------
+      const char* dt = dyb + (h & 1) * DROW;
+      const int s_m = (h + 2) % 3, s_0 = h % 3, s_p = (h + 1) % 3;        // slots of rows h-1, h, h+1
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8_v af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = frag(dt, ks, 0, (nh * 2 + i) * 16);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const char* row = ring + (kh == 0 ? s_m : kh == 1 ? s_0 : s_p) * XROW;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const bf16x8_v bf = frag(row, ks, kw, ct * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mfma_bf16_acc(acc[kh * 3 + kw][i], af[i], bf);
+          }
+        }
+      }
+      __syncthreads();          // row h-1's slot and the other dy buffer are free
+      if (more) {
+        char* xslot = ring + ((h + 2) % 3) * XROW;          // row h+2 replaces row h-1
+        char* dn = dyb + ((h + 1) & 1) * DROW;
+        if (p_ok[0]) { *(uint4*)(xslot + x_off[0]) = keep(nx0, xin); *(uint4*)(dn + d_off[0]) = nd0; }
+        if (PPT > 1 && p_ok[PPT > 1 ? 1 : 0]) { *(uint4*)(xslot + x_off[PPT > 1 ? 1 : 0]) = keep(nx1, xin); *(uint4*)(dn + d_off[PPT > 1 ? 1 : 0]) = nd1; }
+        if (PPT > 2 && p_ok[PPT > 2 ? 2 : 0]) { *(uint4*)(xslot + x_off[PPT > 2 ? 2 : 0]) = keep(nx2, xin); *(uint4*)(dn + d_off[PPT > 2 ? 2 : 0]) = nd2; }
+      }
+      __syncthreads();
+    }
+  }
+  mfma_drain();
+  // dw[kt*9 + tap][n][c0 + c]: n = (nh*2 + i)*16 + (lane>>4)*4 + r, c = ct*16 + (lane & 15)
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (nh * 2 + i) * 16 + (lane >> 4) * 4 + r, c = c0 + ct * 16 + (lane & 15);
+        atomicAdd(a.dw + ((long)(kt * 9 + t) * 64 + n) * (long)a.Kp + c, acc[t][i][r]);
+      }
+}
+
+int g_vinet_opt_wgrad_rs = 1;   // 0 = off, 2 = force on every eligible shape (tests)
+
+// VinetWgradDesc::tline == 4: the caller promises taps (kt, kh-1, kw-1, slice (kt*3 + kh)*3 + kw), kt < ntaps / 9
+bool vinet_wgrad_use_rs(const VinetWgradDesc* d) {
+  if (!g_vinet_opt_wgrad_rs || d->tline != 4 || d->dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
+  if (d->pre.scale || d->pre.relu || d->bnb_z) return false;
+  const int kT = d->ntaps / 9;
+  const bool shape = d->ntaps % 9 == 0 && kT >= 1 && d->sT == kT && d->sH == 1 && d->sW == 1 && d->dy.C == 64 && d->x.C % 64 == 0 && d->Kp >= d->x.C &&
+                     d->x.T == kT * d->dy.T && d->x.H == d->dy.H && d->x.W == d->dy.W && d->dy.W % 32 == 0 && d->dy.W <= 96 && d->dy.H >= 2 &&
+                     d->x.ld % 8 == 0 && d->dy.ld % 8 == 0 && d->x.sB % 8 == 0 && d->dy.sB % 8 == 0 && ((uintptr_t)d->x.ptr % 16) == 0 &&
+                     ((uintptr_t)d->dy.ptr % 16) == 0;
+  if (!shape) return false;
+  if (g_vinet_opt_wgrad_rs >= 2) return true;
+  return (long)d->dy.B * d->dy.T >= 64 && d->dy.H >= 8;
+}
+
+int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
+  WgradRsArgs a;
+  a.x = (const char*)d->x.ptr; a.dy = (const char*)d->dy.ptr; a.dw = d->dw;
+  a.sBx = d->x.sB; a.sBy = d->dy.sB;
+  a.Ti = d->x.T; a.To = d->dy.T; a.H = d->dy.H; a.W = d->dy.W; a.ldx = d->x.ld; a.ldy = d->dy.ld;
+  a.kT = d->ntaps / 9; a.cchunks = d->x.C / 64; a.Kp = d->Kp;
+  a.items = d->dy.B * a.To;
+  a.dTo = make_fastdiv((uint32_t)a.To);
+  const int groups = a.kT * a.cchunks;
+  int workers = 256 / groups;       // one 512-thread workgroup per CU
+  if (workers < 1) workers = 1;
+  if (workers > a.items) workers = a.items;
+  a.workers = workers;
+  const int ks = a.W / 32;
+  const int smem = 3 * (a.W + 2) * 128 + 2 * a.W * 128;
+  auto launch = [&](auto kern) -> int {
+    static bool attr_done[3][64] = {{false}};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[ks - 1][dev & 63]) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 98 * 128);
+      if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(wgrad_rs): %s", hipGetErrorString(e)); return (int)e; }
+      attr_done[ks - 1][dev & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(groups * workers), dim3(512), smem, s, a);
+    return vn_launch_status("conv_wgrad_rs");
+  };
+  if (ks == 1) return launch(conv_wgrad_rs_kernel<1>);
+  if (ks == 2) return launch(conv_wgrad_rs_kernel<2>);
+  return launch(conv_wgrad_rs_kernel<3>);
+}

@@ -888,6 +888,8 @@ def _wgrad_desc(ctx, plan, x, dy, dw=None):
         wd.tline, wd.tpad = 1, plan.p[0]
     elif folded:
         wd.tline = 2        # taps (0, kh, 0, kh): ConvPlan.folded_taps
+    elif not plan.stem and plan.k[1:] == (3, 3) and plan.p == (0, 1, 1) and plan.s == (plan.k[0], 1, 1):
+        wd.tline = 4        # kT x 3 x 3, temporal stride = kT (the decoder): ConvPlan.fwd_taps order
     wd._keep = taps
     return wd
 
