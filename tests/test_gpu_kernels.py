@@ -663,6 +663,8 @@ WGRAD_RS_CASES = [
     ("rs_w64_k2", (1, 4, 5, 64), 64, 64, (2, 3, 3), (2, 1, 1), (0, 1, 1), False),
     ("rs_w96_k1", (2, 2, 4, 96), 192, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
     ("rs_slices", (1, 6, 2, 32), 64, 64, (3, 3, 3), (3, 1, 1), (0, 1, 1), False, dict(x_ld=160, x_coff=32, dy_ld=112, dy_coff=16)),
+    ("rs_n192", (2, 2, 5, 64), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+    ("rs_n128_k2", (1, 4, 4, 32), 128, 128, (2, 3, 3), (2, 1, 1), (0, 1, 1), False),
 ]
 
 

@@ -1,4 +1,4 @@
-// Weight gradient of a kT x 3 x 3 conv with stride (kT,1,1), padding (0,1,1) and 64 output channels -- the last big
+// Weight gradient of a kT x 3 x 3 conv with stride (kT,1,1), padding (0,1,1) (output channels in chunks of 64) -- the last big
 // decoder layer, 192 -> 64, 5x3x3 / (5,1,1) at 20 x 56 x 96 (model.py:273; 3.0 TFLOP per step at 128 clips) -- as a
 // row-streaming kernel:
 //
@@ -26,7 +26,7 @@ struct WgradRsArgs {
   float* dw;
   long sBx, sBy;
   int Ti, To, H, W, ldx, ldy;
-  int kT, cchunks, Kp;
+  int kT, cchunks, nchunks, Kp, N;
   int items, workers;          // items = B * To, workers per group
   FastDiv dTo;
 };
@@ -43,9 +43,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
   char* ring = smem;                                // 3 x rows
   char* dyb = smem + 3 * XROW;                      // 2 dy rows
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int groups = a.kT * a.cchunks;
+  const int groups = a.kT * a.cchunks * a.nchunks;
   const int grp = blockIdx.x % groups, worker = blockIdx.x / groups;
-  const int kt = grp / a.cchunks, c0 = (grp - kt * a.cchunks) * 64;
+  const int n0 = (grp % a.nchunks) * 64;                              // 64 output channels of dy ...
+  const int gc = grp / a.nchunks;
+  const int kt = gc / a.cchunks, c0 = (gc - kt * a.cchunks) * 64;     // ... one temporal tap, 64 input channels of x
 
   const int ct = wave & 3, nh = wave >> 2;
   // piece roles: piece q = tid + 512*j -> position q >> 3 (0..W-1), chunk q & 7
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
     const int to = item - b * a.To;
     const int t = to * a.kT + kt;
     const char* xb = a.x + ((long)b * a.sBx + (long)t * a.H * a.W * a.ldx + c0 + l_chunk * 8) * 2;     // + (h*W + pos) * ldx * 2
-    const char* db = a.dy + ((long)b * a.sBy + (long)to * a.H * a.W * a.ldy + l_chunk * 8) * 2;
+    const char* db = a.dy + ((long)b * a.sBy + (long)to * a.H * a.W * a.ldy + n0 + l_chunk * 8) * 2;
     const long x_rowb = (long)a.W * a.ldx * 2, d_rowb = (long)a.W * a.ldy * 2;
 
     // ---- prologue: x rows -1 (zeros) and 0 into slots 2 and 0, dy row 0 ---------------------------------------
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = (nh * 2 + i) * 16 + (lane >> 4) * 4 + r, c = c0 + ct * 16 + (lane & 15);
-        atomicAdd(a.dw + ((long)(kt * 9 + t) * 64 + n) * (long)a.Kp + c, acc[t][i][r]);
+        atomicAdd(a.dw + ((long)(kt * 9 + t) * a.N + n0 + n) * (long)a.Kp + c, acc[t][i][r]);
       }
 }
 
@@ -183,7 +185,7 @@ bool vinet_wgrad_use_rs(const VinetWgradDesc* d) {
   if (!g_vinet_opt_wgrad_rs || d->tline != 4 || d->dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
   if (d->pre.scale || d->pre.relu || d->bnb_z) return false;
   const int kT = d->ntaps / 9;
-  const bool shape = d->ntaps % 9 == 0 && kT >= 1 && d->sT == kT && d->sH == 1 && d->sW == 1 && d->dy.C == 64 && d->x.C % 64 == 0 && d->Kp >= d->x.C &&
+  const bool shape = d->ntaps % 9 == 0 && kT >= 1 && d->sT == kT && d->sH == 1 && d->sW == 1 && d->dy.C % 64 == 0 && d->x.C % 64 == 0 && d->Kp >= d->x.C &&
                      d->x.T == kT * d->dy.T && d->x.H == d->dy.H && d->x.W == d->dy.W && d->dy.W % 32 == 0 && d->dy.W <= 96 && d->dy.H >= 2 &&
                      d->x.ld % 8 == 0 && d->dy.ld % 8 == 0 && d->x.sB % 8 == 0 && d->dy.sB % 8 == 0 && ((uintptr_t)d->x.ptr % 16) == 0 &&
                      ((uintptr_t)d->dy.ptr % 16) == 0;
@@ -197,11 +199,11 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   a.x = (const char*)d->x.ptr; a.dy = (const char*)d->dy.ptr; a.dw = d->dw;
   a.sBx = d->x.sB; a.sBy = d->dy.sB;
   a.Ti = d->x.T; a.To = d->dy.T; a.H = d->dy.H; a.W = d->dy.W; a.ldx = d->x.ld; a.ldy = d->dy.ld;
-  a.kT = d->ntaps / 9; a.cchunks = d->x.C / 64; a.Kp = d->Kp;
+  a.kT = d->ntaps / 9; a.cchunks = d->x.C / 64; a.nchunks = d->dy.C / 64; a.Kp = d->Kp; a.N = d->dy.C;
   a.items = d->dy.B * a.To;
   a.dTo = make_fastdiv((uint32_t)a.To);
-  const int groups = a.kT * a.cchunks;
-  int workers = 256 / groups;       // one 512-thread workgroup per CU
+  const int groups = a.kT * a.cchunks * a.nchunks;
+  int workers = 256 / groups;       // one 512-thread workgroup per CU: never more than 256 in the grid (a second round would double the time)       // one 512-thread workgroup per CU
   if (workers < 1) workers = 1;
   if (workers > a.items) workers = a.items;
   a.workers = workers;
