@@ -665,6 +665,11 @@ WGRAD_RS_CASES = [
     ("rs_slices", (1, 6, 2, 32), 64, 64, (3, 3, 3), (3, 1, 1), (0, 1, 1), False, dict(x_ld=160, x_coff=32, dy_ld=112, dy_coff=16)),
     ("rs_n192", (2, 2, 5, 64), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
     ("rs_n128_k2", (1, 4, 4, 32), 128, 128, (2, 3, 3), (2, 1, 1), (0, 1, 1), False),
+    ("rs_partial_chunks", (1, 2, 4, 64), 96, 80, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+    # several image rows per step (W = 48 / 24), image heights that do not divide into steps, partial chunks
+    ("rs_w48", (2, 4, 7, 48), 96, 128, (2, 3, 3), (2, 1, 1), (0, 1, 1), False),
+    ("rs_w24", (1, 3, 14, 24), 160, 64, (3, 3, 3), (3, 1, 1), (0, 1, 1), False),
+    ("rs_w24_h3", (2, 1, 3, 24), 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, dict(x_ld=96, x_coff=16)),
 ]
 
 

@@ -258,7 +258,7 @@ static bool wgrad_use_dma(const VinetWgradDesc* d) {
 
 extern "C" int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* d, char* buf, int32_t n) {
   if (!d || !buf || n <= 0) return -1;
-  if (vinet_wgrad_use_rs(d)) { snprintf(buf, n, "conv_wgrad_rs_kernel<%d>", d->dy.W / 32); return 0; }
+  if (vinet_wgrad_use_rs(d)) { snprintf(buf, n, "conv_wgrad_rs_kernel<W%d>", d->dy.W); return 0; }
   if (vinet_wgrad_use_hs(d)) { snprintf(buf, n, d->bnb_z ? "conv_wgrad_hs_kernel<bn_bwd>" : "conv_wgrad_hs_kernel"); return 0; }
   if (vinet_wgrad_use_ts(d)) { snprintf(buf, n, "conv_wgrad_ts_kernel<%s>", d->pre.scale ? "pre" : "plain"); return 0; }
   if (wgrad_use_dma(d) && vinet_wgrad_use_pp(d)) { snprintf(buf, n, "conv_wgrad_pp_kernel<%s,%d>", d->pre.scale ? "pre" : "plain", vinet_wgrad_pp_rows(d->dy.C)); return 0; }

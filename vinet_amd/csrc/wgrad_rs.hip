@@ -1,4 +1,5 @@
-// Weight gradient of a kT x 3 x 3 conv with stride (kT,1,1), padding (0,1,1) (output channels in chunks of 64) -- the last big
+// Weight gradient of kT x 3 x 3 convs with stride (kT,1,1), padding (0,1,1) (input / output channels in chunks of 64;
+// image widths 32, 64, 96 one row per step, 48 and 24 two / four rows per step) -- written for the last big
 // decoder layer, 192 -> 64, 5x3x3 / (5,1,1) at 20 x 56 x 96 (model.py:273; 3.0 TFLOP per step at 128 clips) -- as a
 // row-streaming kernel:
 //
@@ -26,7 +27,7 @@ struct WgradRsArgs {
   float* dw;
   long sBx, sBy;
   int Ti, To, H, W, ldx, ldy;
-  int kT, cchunks, nchunks, Kp, N;
+  int kT, cchunks, nchunks, Kp, N, Cin;
   int items, workers;          // items = B * To, workers per group
   FastDiv dTo;
 };
@@ -63,6 +64,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
     d_off[j] = pos * 128 + ((ch ^ wrs_swz(pos)) * 16);
   }
   const int l_chunk = tid & 7;
+  // partial last chunks (Cin, N multiples of 8 only): this lane's 8 channels may lie past the end -> zeros, from a clamped address
+  const bool cx_ok = c0 + l_chunk * 8 < a.Cin, dn_ok = n0 + l_chunk * 8 < a.N;
+  const int cx_off = cx_ok ? c0 + l_chunk * 8 : 0, dn_off = dn_ok ? n0 + l_chunk * 8 : 0;
   // zero the pad positions of the three ring rows once (never written again)
   if (tid < 3 * 2 * 8) {     // (48 threads)
     const int row = tid / 16, side = (tid >> 3) & 1, ch = tid & 7;
@@ -100,8 +104,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
     const int b = (int)fdiv((uint32_t)item, a.dTo);
     const int to = item - b * a.To;
     const int t = to * a.kT + kt;
-    const char* xb = a.x + ((long)b * a.sBx + (long)t * a.H * a.W * a.ldx + c0 + l_chunk * 8) * 2;     // + (h*W + pos) * ldx * 2
-    const char* db = a.dy + ((long)b * a.sBy + (long)to * a.H * a.W * a.ldy + n0 + l_chunk * 8) * 2;
+    const char* xb = a.x + ((long)b * a.sBx + (long)t * a.H * a.W * a.ldx + cx_off) * 2;     // + (h*W + pos) * ldx * 2
+    const char* db = a.dy + ((long)b * a.sBy + (long)to * a.H * a.W * a.ldy + dn_off) * 2;
     const long x_rowb = (long)a.W * a.ldx * 2, d_rowb = (long)a.W * a.ldy * 2;
 
     // ---- prologue: x rows -1 (zeros) and 0 into slots 2 and 0, dy row 0 ---------------------------------------
@@ -109,16 +113,16 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
     for (int j = 0; j < PPT; ++j)
       if (p_ok[j]) {
         *(uint4*)(ring + 2 * XROW + x_off[j]) = z4;
-        *(uint4*)(ring + 0 * XROW + x_off[j]) = *(const uint4*)(xb + (long)g_pos[j] * a.ldx * 2);
-        *(uint4*)(dyb + d_off[j]) = *(const uint4*)(db + (long)g_pos[j] * a.ldy * 2);
+        *(uint4*)(ring + 0 * XROW + x_off[j]) = keep(*(const uint4*)(xb + (long)g_pos[j] * a.ldx * 2), cx_ok);
+        *(uint4*)(dyb + d_off[j]) = keep(*(const uint4*)(db + (long)g_pos[j] * a.ldy * 2), dn_ok);
       }
     // x row 1 (the "next row" of a virtual step -1); unconditional loads from a clamped row, zero by select
     {
       const char* x1 = xb + (1 < a.H ? x_rowb : 0);
       const uint4 r0 = *(const uint4*)(x1 + (long)g_pos[0] * a.ldx * 2);
       const uint4 r1 = *(const uint4*)(x1 + (long)g_pos[PPT > 1 ? 1 : 0] * a.ldx * 2);
-      if (p_ok[0]) *(uint4*)(ring + 1 * XROW + x_off[0]) = keep(r0, 1 < a.H);
-      if (PPT > 1 && p_ok[PPT > 1 ? 1 : 0]) *(uint4*)(ring + 1 * XROW + x_off[PPT > 1 ? 1 : 0]) = keep(r1, 1 < a.H);
+      if (p_ok[0]) *(uint4*)(ring + 1 * XROW + x_off[0]) = keep(r0, 1 < a.H && cx_ok);
+      if (PPT > 1 && p_ok[PPT > 1 ? 1 : 0]) *(uint4*)(ring + 1 * XROW + x_off[PPT > 1 ? 1 : 0]) = keep(r1, 1 < a.H && cx_ok);
     }
     __syncthreads();
 
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
     for (int h = 0; h < a.H; ++h) {
       // ---- loads for step h+1: x row h+2, dy row h+1 -------------------------------------------------------------
       const bool more = h + 1 < a.H;
-      const bool xin = more && h + 2 < a.H;
+      const bool xin = more && h + 2 < a.H && cx_ok;
       const char* xs = xb + (xin ? h + 2 : 0) * x_rowb;
       const char* ds = db + (more ? h + 1 : 0) * d_rowb;
       uint4 nx0 = z4, nx1 = z4, nx2 = z4, nd0 = z4, nd1 = z4, nd2 = z4;
@@ -158,9 +162,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
       if (more) {
         char* xslot = ring + ((h + 2) % 3) * XROW;          // row h+2 replaces row h-1
         char* dn = dyb + ((h + 1) & 1) * DROW;
-        if (p_ok[0]) { *(uint4*)(xslot + x_off[0]) = keep(nx0, xin); *(uint4*)(dn + d_off[0]) = nd0; }
-        if (PPT > 1 && p_ok[PPT > 1 ? 1 : 0]) { *(uint4*)(xslot + x_off[PPT > 1 ? 1 : 0]) = keep(nx1, xin); *(uint4*)(dn + d_off[PPT > 1 ? 1 : 0]) = nd1; }
-        if (PPT > 2 && p_ok[PPT > 2 ? 2 : 0]) { *(uint4*)(xslot + x_off[PPT > 2 ? 2 : 0]) = keep(nx2, xin); *(uint4*)(dn + d_off[PPT > 2 ? 2 : 0]) = nd2; }
+        if (p_ok[0]) { *(uint4*)(xslot + x_off[0]) = keep(nx0, xin); *(uint4*)(dn + d_off[0]) = keep(nd0, dn_ok); }
+        if (PPT > 1 && p_ok[PPT > 1 ? 1 : 0]) { *(uint4*)(xslot + x_off[PPT > 1 ? 1 : 0]) = keep(nx1, xin); *(uint4*)(dn + d_off[PPT > 1 ? 1 : 0]) = keep(nd1, dn_ok); }
+        if (PPT > 2 && p_ok[PPT > 2 ? 2 : 0]) { *(uint4*)(xslot + x_off[PPT > 2 ? 2 : 0]) = keep(nx2, xin); *(uint4*)(dn + d_off[PPT > 2 ? 2 : 0]) = keep(nd2, dn_ok); }
       }
       __syncthreads();
     }
@@ -174,7 +178,176 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = (nh * 2 + i) * 16 + (lane >> 4) * 4 + r, c = c0 + ct * 16 + (lane & 15);
-        atomicAdd(a.dw + ((long)(kt * 9 + t) * a.N + n0 + n) * (long)a.Kp + c, acc[t][i][r]);
+        if (n0 + n < a.N && c < a.Cin) atomicAdd(a.dw + ((long)(kt * 9 + t) * a.N + n0 + n) * (long)a.Kp + c, acc[t][i][r]);
+      }
+}
+
+// Several image rows per step for narrow images (W = 48, 24): P = 32*KS positions = R rows of W, so the MFMA K steps
+// stay full.  The ring holds the R + 2 live x rows; a fragment position p maps to (row p / W, column p % W), i.e. the
+// nine taps are still nine addresses.  Rows past the end of the image are zero in the ring and in the dy tile.
+template <int KS, int WW>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_rsm_kernel(const WgradRsArgs a) {
+  constexpr int P = KS * 32, R = P / WW, RING = R + 2;
+  static_assert(R * WW == P && R >= 2, "whole rows per step");
+  constexpr int XROW = (WW + 2) * 128, DROW = P * 128;
+  constexpr int NPC = P * 8, PPT = (NPC + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;                                // RING x rows
+  char* dyb = smem + RING * XROW;                   // 2 dy tiles
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int groups = a.kT * a.cchunks * a.nchunks;
+  const int grp = blockIdx.x % groups, worker = blockIdx.x / groups;
+  const int n0 = (grp % a.nchunks) * 64;
+  const int gc = grp / a.nchunks;
+  const int kt = gc / a.cchunks, c0 = (gc - kt * a.cchunks) * 64;
+  const int ct = wave & 3, nh = wave >> 2;
+  const int l_chunk = tid & 7;
+  const int H = a.H;
+  const bool cx_ok = c0 + l_chunk * 8 < a.Cin, dn_ok = n0 + l_chunk * 8 < a.N;
+  const int cx_off = cx_ok ? c0 + l_chunk * 8 : 0, dn_off = dn_ok ? n0 + l_chunk * 8 : 0;
+
+  // piece roles: piece q = tid + 512*j -> tile position q >> 3 = (row pr, column pw), chunk q & 7
+  int x_in[PPT], d_off[PPT], g_pos[PPT], p_r[PPT];
+  bool p_ok[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int q = tid + 512 * j;
+    p_ok[j] = q < NPC;
+    const int pos = p_ok[j] ? q >> 3 : 0, ch = q & 7;
+    const int pr = pos / WW, pw = pos - pr * WW;
+    g_pos[j] = pos; p_r[j] = pr;
+    x_in[j] = (pw + 1) * 128 + ((ch ^ wrs_swz(pw + 1)) * 16);
+    d_off[j] = pos * 128 + ((ch ^ wrs_swz(pos)) * 16);
+  }
+  for (int i = tid; i < RING * 2 * 8; i += 512) {            // zero pad positions of every ring row, once
+    const int row = i / 16, side = (i >> 3) & 1, ch = i & 7;
+    *(uint4*)(ring + row * XROW + (side ? (WW + 1) * 128 : 0) + ch * 16) = make_uint4(0, 0, 0, 0);
+  }
+  // fragment positions of this lane: tile position -> (row, column)
+  int f_r[KS][2], f_w[KS][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pos = ks * 32 + (lane >> 4) * 8 + h * 4 + ((lane & 15) >> 2);
+      f_r[ks][h] = pos / WW; f_w[ks][h] = pos - (pos / WW) * WW;
+    }
+
+  f32x4_v acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[t][i] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+
+  auto frag_dy = [&](const char* tile, int ks, int col0) -> bf16x8_v {
+    union { bf16x8_v v; s16x4_v h[2]; } u;
+    const int p = lane & 15;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pos = ks * 32 + (lane >> 4) * 8 + h * 4 + (p >> 2);
+      const int col = col0 + (p & 3) * 4;
+      const int ch = (col >> 3) ^ wrs_swz(pos);
+      u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(tile + pos * 128 + ch * 16 + (col & 7) * 2));
+    }
+    return u.v;
+  };
+  auto keep = [](uint4 v, bool on) -> uint4 {
+    const uint32_t m = on ? 0xffffffffu : 0u;
+    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+  };
+  const int nsteps = (H + R - 1) / R;
+
+  for (int item = worker; item < a.items; item += a.workers) {
+    const int b = (int)fdiv((uint32_t)item, a.dTo);
+    const int to = item - b * a.To;
+    const int t = to * a.kT + kt;
+    const char* xb = a.x + ((long)b * a.sBx + (long)t * H * WW * a.ldx + cx_off) * 2;      // + (y*W + w) * ldx * 2
+    const char* db = a.dy + ((long)b * a.sBy + (long)to * H * WW * a.ldy + dn_off) * 2;
+
+    // ---- prologue: image rows -1 (zero) and 0..R into slots 0..R+1 (slot of row y = (y + 1) % RING), dy rows 0..R-1
+    for (int q = tid; q < (R + 1) * WW * 8; q += 512) {
+      const int pos = q >> 3, ch = q & 7;                     // (q & 7 == l_chunk)
+      const int y = pos / WW, w = pos - y * WW;
+      uint4 v = *(const uint4*)(xb + (long)(y < H ? pos : 0) * a.ldx * 2);
+      v = keep(v, y < H && cx_ok);
+      *(uint4*)(ring + (y + 1) * XROW + (w + 1) * 128 + ((ch ^ wrs_swz(w + 1)) * 16)) = v;
+    }
+    for (int q = tid; q < WW * 8; q += 512)
+      *(uint4*)(ring + ((q >> 3) + 1) * 128 + (((q & 7) ^ wrs_swz((q >> 3) + 1)) * 16)) = make_uint4(0, 0, 0, 0);     // row -1
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+      if (p_ok[j]) {
+        const bool in = p_r[j] < H && dn_ok;
+        const uint4 v = *(const uint4*)(db + (long)(in ? g_pos[j] : 0) * a.ldy * 2);
+        *(uint4*)(dyb + d_off[j]) = keep(v, in);
+      }
+    __syncthreads();
+
+    int s_base = 0;                                          // slot of image row h0 - 1
+    for (int st = 0; st < nsteps; ++st) {
+      const int h0 = st * R;
+      // ---- loads for the next step: x rows h0+R+1 .. h0+2R, dy rows h0+R .. h0+2R-1 ---------------------------------
+      const bool more = st + 1 < nsteps;
+      const bool xi0 = more && cx_ok && h0 + R + 1 + p_r[0] < H, xi1 = more && cx_ok && h0 + R + 1 + p_r[PPT > 1 ? 1 : 0] < H;
+      const bool di0 = more && dn_ok && h0 + R + p_r[0] < H, di1 = more && dn_ok && h0 + R + p_r[PPT > 1 ? 1 : 0] < H;
+      const uint4 nx0 = *(const uint4*)(xb + (long)(xi0 ? (h0 + R + 1) * WW + g_pos[0] : 0) * a.ldx * 2);
+      const uint4 nx1 = *(const uint4*)(xb + (long)(xi1 ? (h0 + R + 1) * WW + g_pos[PPT > 1 ? 1 : 0] : 0) * a.ldx * 2);
+      const uint4 nd0 = *(const uint4*)(db + (long)(di0 ? (h0 + R) * WW + g_pos[0] : 0) * a.ldy * 2);
+      const uint4 nd1 = *(const uint4*)(db + (long)(di1 ? (h0 + R) * WW + g_pos[PPT > 1 ? 1 : 0] : 0) * a.ldy * 2);
+
+      // ---- MFMAs ------------------------------------------------------------------------------------------------------
+      const char* dt = dyb + (st & 1) * DROW;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8_v af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = frag_dy(dt, ks, (nh * 2 + i) * 16);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            union { bf16x8_v v; s16x4_v h[2]; } u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              int slot = s_base + f_r[ks][h] + kh;           // image row h0 + f_r + kh - 1
+              slot -= slot >= RING ? RING : 0;
+              const int xp = f_w[ks][h] + kw;                // ring position of image column f_w + kw - 1
+              const int col = ct * 16 + (lane & 3) * 4;
+              const int ch = (col >> 3) ^ wrs_swz(xp);
+              u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) s16x4_v*)(ring + slot * XROW + xp * 128 + ch * 16 + (col & 7) * 2));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mfma_bf16_acc(acc[kh * 3 + kw][i], af[i], u.v);
+          }
+      }
+      __syncthreads();
+      if (more) {
+        char* dn = dyb + ((st + 1) & 1) * DROW;
+        if (p_ok[0]) {
+          int sl = s_base + p_r[0]; sl -= sl >= RING ? RING : 0;       // new row h0+R+1+pr replaces row h0-1+pr
+          *(uint4*)(ring + sl * XROW + x_in[0]) = keep(nx0, xi0);
+          *(uint4*)(dn + d_off[0]) = keep(nd0, di0);
+        }
+        if (PPT > 1 && p_ok[PPT > 1 ? 1 : 0]) {
+          int sl = s_base + p_r[PPT > 1 ? 1 : 0]; sl -= sl >= RING ? RING : 0;
+          *(uint4*)(ring + sl * XROW + x_in[PPT > 1 ? 1 : 0]) = keep(nx1, xi1);
+          *(uint4*)(dn + d_off[PPT > 1 ? 1 : 0]) = keep(nd1, di1);
+        }
+      }
+      s_base += R; s_base -= s_base >= RING ? RING : 0;
+      __syncthreads();
+    }
+  }
+  mfma_drain();
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (nh * 2 + i) * 16 + (lane >> 4) * 4 + r, c = c0 + ct * 16 + (lane & 15);
+        if (n0 + n < a.N && c < a.Cin) atomicAdd(a.dw + ((long)(kt * 9 + t) * a.N + n0 + n) * (long)a.Kp + c, acc[t][i][r]);
       }
 }
 
@@ -185,8 +358,9 @@ bool vinet_wgrad_use_rs(const VinetWgradDesc* d) {
   if (!g_vinet_opt_wgrad_rs || d->tline != 4 || d->dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
   if (d->pre.scale || d->pre.relu || d->bnb_z) return false;
   const int kT = d->ntaps / 9;
-  const bool shape = d->ntaps % 9 == 0 && kT >= 1 && d->sT == kT && d->sH == 1 && d->sW == 1 && d->dy.C % 64 == 0 && d->x.C % 64 == 0 && d->Kp >= d->x.C &&
-                     d->x.T == kT * d->dy.T && d->x.H == d->dy.H && d->x.W == d->dy.W && d->dy.W % 32 == 0 && d->dy.W <= 96 && d->dy.H >= 2 &&
+  const bool shape = d->ntaps % 9 == 0 && kT >= 1 && d->sT == kT && d->sH == 1 && d->sW == 1 && d->dy.C % 8 == 0 && d->x.C % 8 == 0 && d->Kp >= d->x.C &&
+                     kT * ((d->x.C + 63) / 64) * ((d->dy.C + 63) / 64) <= 256 &&
+                     d->x.T == kT * d->dy.T && d->x.H == d->dy.H && d->x.W == d->dy.W && ((d->dy.W % 32 == 0 && d->dy.W <= 96) || d->dy.W == 48 || d->dy.W == 24) && d->dy.H >= 2 &&
                      d->x.ld % 8 == 0 && d->dy.ld % 8 == 0 && d->x.sB % 8 == 0 && d->dy.sB % 8 == 0 && ((uintptr_t)d->x.ptr % 16) == 0 &&
                      ((uintptr_t)d->dy.ptr % 16) == 0;
   if (!shape) return false;
@@ -199,7 +373,7 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   a.x = (const char*)d->x.ptr; a.dy = (const char*)d->dy.ptr; a.dw = d->dw;
   a.sBx = d->x.sB; a.sBy = d->dy.sB;
   a.Ti = d->x.T; a.To = d->dy.T; a.H = d->dy.H; a.W = d->dy.W; a.ldx = d->x.ld; a.ldy = d->dy.ld;
-  a.kT = d->ntaps / 9; a.cchunks = d->x.C / 64; a.nchunks = d->dy.C / 64; a.Kp = d->Kp; a.N = d->dy.C;
+  a.kT = d->ntaps / 9; a.cchunks = (d->x.C + 63) / 64; a.nchunks = (d->dy.C + 63) / 64; a.Kp = d->Kp; a.N = d->dy.C; a.Cin = d->x.C;
   a.items = d->dy.B * a.To;
   a.dTo = make_fastdiv((uint32_t)a.To);
   const int groups = a.kT * a.cchunks * a.nchunks;
@@ -207,20 +381,16 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   if (workers < 1) workers = 1;
   if (workers > a.items) workers = a.items;
   a.workers = workers;
-  const int ks = a.W / 32;
-  const int smem = 3 * (a.W + 2) * 128 + 2 * a.W * 128;
+  const bool multi = a.W == 48 || a.W == 24;
+  const int ks = multi ? 3 : a.W / 32;
+  const int ringrows = multi ? 96 / a.W + 2 : 3;
+  const int smem = ringrows * (a.W + 2) * 128 + 2 * ks * 32 * 128;
   auto launch = [&](auto kern) -> int {
-    static bool attr_done[3][64] = {{false}};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_done[ks - 1][dev & 63]) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 98 * 128);
-      if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(wgrad_rs): %s", hipGetErrorString(e)); return (int)e; }
-      attr_done[ks - 1][dev & 63] = true;
-    }
     hipLaunchKernelGGL(kern, dim3(groups * workers), dim3(512), smem, s, a);
     return vn_launch_status("conv_wgrad_rs");
   };
+  if (a.W == 48) return launch(conv_wgrad_rsm_kernel<3, 48>);
+  if (a.W == 24) return launch(conv_wgrad_rsm_kernel<3, 24>);
   if (ks == 1) return launch(conv_wgrad_rs_kernel<1>);
   if (ks == 2) return launch(conv_wgrad_rs_kernel<2>);
   return launch(conv_wgrad_rs_kernel<3>);
