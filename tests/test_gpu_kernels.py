@@ -687,6 +687,33 @@ def test_conv3d_wgrad_rowstream(case):
         lib.vinet_set_option(b"wgrad_rs", 1)
 
 
+# frame-streaming wgrad of wide 3x1x1 / s1 / p1 temporal convs (H*W a multiple of 96): 192 / 128 / 64 output channels
+# per workgroup, pending BN + ReLU and plain inputs, partial channel chunks, sliced views, one- and two-frame clips
+WGRAD_TF_CASES = [
+    ("tf_192_pre", (2, 5, 8, 12), 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0), True),
+    ("tf_128_plain", (1, 4, 8, 24), 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), False),
+    ("tf_96_pre", (3, 3, 4, 24), 96, 96, (3, 1, 1), (1, 1, 1), (1, 0, 0), True),
+    ("tf_208_pre", (1, 6, 8, 12), 208, 208, (3, 1, 1), (1, 1, 1), (1, 0, 0), True),
+    ("tf_32_64", (2, 2, 16, 12), 32, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), True),
+    ("tf_t1", (2, 1, 8, 12), 64, 160, (3, 1, 1), (1, 1, 1), (1, 0, 0), True),
+    ("tf_slices", (2, 7, 8, 12), 128, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0), True, dict(x_ld=160, x_coff=32, dy_ld=256, dy_coff=48)),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_TF_CASES, ids=[c[0] for c in WGRAD_TF_CASES])
+def test_conv3d_wgrad_tframes(case):
+    lib = _lib()
+    assert lib.vinet_set_option(b"wgrad_tf", 2) == 0
+    try:
+        ex = dict(case[8]) if len(case) > 8 else {}
+        ex["tline"] = True
+        d0 = _run_wgrad_case(case[:8] + (ex,), E.BF16)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_wgrad_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_wgrad_tf_kernel<")
+    finally:
+        lib.vinet_set_option(b"wgrad_tf", 1)
+
+
 def _run_wgrad_case(case, dt):
     name, (B, T, H, W), Cin, N, k, s, p, pre = case[:8]
     ex = case[8] if len(case) > 8 else {}

@@ -21,6 +21,8 @@ bool vinet_wgrad_use_ts(const VinetWgradDesc* d);
 bool vinet_wgrad_use_hs(const VinetWgradDesc* d);
 bool vinet_wgrad_use_rs(const VinetWgradDesc* d);
 int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s);
+bool vinet_wgrad_use_tf(const VinetWgradDesc* d);
+int vinet_launch_wgrad_tf(const VinetWgradDesc* d, hipStream_t s);
 int vinet_launch_wgrad_hs(const VinetWgradDesc* d, hipStream_t s);
 int vinet_launch_wgrad_ts(const VinetWgradDesc* d, hipStream_t s);
 int vinet_wgrad_pp_rows(int N);
@@ -261,6 +263,7 @@ extern "C" int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* d, char* buf
   if (vinet_wgrad_use_rs(d)) { snprintf(buf, n, "conv_wgrad_rs_kernel<W%d>", d->dy.W); return 0; }
   if (vinet_wgrad_use_hs(d)) { snprintf(buf, n, d->bnb_z ? "conv_wgrad_hs_kernel<bn_bwd>" : "conv_wgrad_hs_kernel"); return 0; }
   if (vinet_wgrad_use_ts(d)) { snprintf(buf, n, "conv_wgrad_ts_kernel<%s>", d->pre.scale ? "pre" : "plain"); return 0; }
+  if (vinet_wgrad_use_tf(d)) { snprintf(buf, n, "conv_wgrad_tf_kernel<%s>", d->pre.scale ? "pre" : "plain"); return 0; }
   if (wgrad_use_dma(d) && vinet_wgrad_use_pp(d)) { snprintf(buf, n, "conv_wgrad_pp_kernel<%s,%d>", d->pre.scale ? "pre" : "plain", vinet_wgrad_pp_rows(d->dy.C)); return 0; }
   if (wgrad_use_dma(d)) return vinet_wgrad_dma_name(d, buf, n);
   snprintf(buf, n, "conv_wgrad_kernel<%s,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", d->mode);
@@ -287,6 +290,7 @@ extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   if (vinet_wgrad_use_rs(d)) return vinet_launch_wgrad_rs(d, (hipStream_t)stream);
   if (vinet_wgrad_use_hs(d)) return vinet_launch_wgrad_hs(d, (hipStream_t)stream);
   if (vinet_wgrad_use_ts(d)) return vinet_launch_wgrad_ts(d, (hipStream_t)stream);
+  if (vinet_wgrad_use_tf(d)) return vinet_launch_wgrad_tf(d, (hipStream_t)stream);
   if (wgrad_use_dma(d) && vinet_wgrad_use_pp(d)) return vinet_launch_wgrad_pp(d, (hipStream_t)stream);
   if (wgrad_use_dma(d)) return vinet_launch_wgrad_dma(d, (hipStream_t)stream);
   WgradArgs a;
