@@ -140,6 +140,7 @@ extern int g_vinet_opt_splitk;
 int g_vinet_opt_n64_tile = 0;   // tuning: 64-wide layers on 128x64 (1) or 64x64 (2) tiles instead of 256x64
 int g_vinet_opt_pool_blk = 1;   // 1x3x3/s(1,2,2) max-pool backward per 2x2 input block
 int g_vinet_opt_up_blk = 1;     // 8-channel upsample kernels (forward per 2x2 output block)
+int g_vinet_opt_reduce_il = 1;  // channel reductions: blocks interleave rounds over one window (0 = one contiguous range per block)
 int g_vinet_opt_pool_pk = 1;    // bf16: packed 32-bit-key form of the LDS halo-tile pool (0 = the fp32-compare kernel)
 int g_vinet_opt_pool_lds = 1;   // LDS halo-tile 3x3x3/s1 max-pool forward (C % 64 == 0)
 int g_vinet_opt_pool_twalk = 1; // T-walking 3x3x3/s1 max-pool backward
@@ -155,6 +156,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
   if (name && !strcmp(name, "pool_blk")) { g_vinet_opt_pool_blk = value; return 0; }
   if (name && !strcmp(name, "up_blk")) { g_vinet_opt_up_blk = value; return 0; }
+  if (name && !strcmp(name, "reduce_il")) { g_vinet_opt_reduce_il = value; return 0; }
   if (name && !strcmp(name, "pool_pk")) { g_vinet_opt_pool_pk = value; return 0; }
   if (name && !strcmp(name, "pool_lds")) { g_vinet_opt_pool_lds = value; return 0; }
   if (name && !strcmp(name, "pool_twalk")) { g_vinet_opt_pool_twalk = value; return 0; }

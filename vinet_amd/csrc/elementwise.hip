@@ -9,6 +9,7 @@ extern int g_vinet_opt_pool_twalk;
 extern int g_vinet_opt_pool_lds;
 extern int g_vinet_opt_pool_pk;
 extern int g_vinet_opt_up_blk;
+extern int g_vinet_opt_reduce_il;
 extern int g_vinet_opt_pool_blk;
 extern int g_vinet_opt_pool_pk;
 
@@ -480,8 +481,12 @@ __global__ __launch_bounds__(256) void channel_reduce8_kernel(TView x, TView dz,
   const int r = threadIdx.x / Gb;
   const int g0 = threadIdx.x % Gb;
   __shared__ float red[256 * 16];
-  const long v0 = (long)blockIdx.x * vb;
-  long v1 = v0 + vb; if (v1 > nvox) v1 = nvox;
+  constexpr int U = 4;
+  // vb == 0: interleaved rounds -- in round i block b reads voxels [(i*gridDim.x + b)*R*U, +R*U), so the whole grid
+  // walks one contiguous window of the tensor instead of gridDim.x streams a fixed stride apart
+  const long v0 = vb ? (long)blockIdx.x * vb : (long)blockIdx.x * R * U;
+  long v1 = vb ? v0 + vb : nvox; if (v1 > nvox) v1 = nvox;
+  const long vstep = vb ? (long)R * U : (long)gridDim.x * R * U;
   for (int g = g0; g < G; g += Gb) {
     float s[8], p[8], mu[8], is[8], sc[8], sh[8];
 #pragma unroll
@@ -495,8 +500,7 @@ __global__ __launch_bounds__(256) void channel_reduce8_kernel(TView x, TView dz,
           for (int e = 0; e < 8; ++e) { sc[e] = fwd.scale ? fwd.scale[g * 8 + e] : 1.f; sh[e] = fwd.shift ? fwd.shift[g * 8 + e] : 0.f; }
         }
       }
-      constexpr int U = 4;
-      for (long vq = v0 + r; vq < v1; vq += (long)R * U) {
+      for (long vq = v0 + r; vq < v1; vq += vstep) {
         float xv[U][8], gv[U][8];
         bool ok[U];
 #pragma unroll
@@ -631,7 +635,7 @@ static int launch_channel_reduce(const VinetTensor* x, const VinetTensor* dz, in
   const TView xv = make_view(*x), dv = dz ? make_view(*dz) : xv;
   if (oct_ok(*x) && (!dz || oct_ok(*dz))) {
     DISPATCH_T(dtype, T, hipLaunchKernelGGL((channel_reduce8_kernel<T, MODE>), dim3(rows), dim3(256), 0,
-                                            (hipStream_t)stream, xv, dv, make_affine(fwd), mean, invstd, nvox, vb, partials);)
+                                            (hipStream_t)stream, xv, dv, make_affine(fwd), mean, invstd, nvox, g_vinet_opt_reduce_il ? 0 : vb, partials);)
     return vn_launch_status("channel_reduce8");
   }
   DISPATCH_T(dtype, T, hipLaunchKernelGGL((channel_reduce_kernel<T, MODE>), dim3(rows), dim3(256), 0,
