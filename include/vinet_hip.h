@@ -334,7 +334,9 @@ int vinet_bilinear_bwd(const void* x1, const void* x2, const void* dout, int32_t
  * 256- / 192-wide shape), "wgrad_pp" (ping-pong wgrad kernel, same values; 3 / 4 force the 256- / 192-row tile),
  * "wgrad_tg" (taps per group of the 64x64 wgrad kernel, 0 = heuristic), "pool_twalk" (T-walking 3x3x3/s1 pool
  * kernels: 0 off, 1 large tensors (default), 2 always), "tperm" (t-fastest tile order, default 0),
- * "n64_tile" (64-wide convs: 0 heuristic, 1 force 128-row, 2 force 64-row tiles).
+ * "n64_tile" (64-wide convs: 0 heuristic, 1 force 128-row, 2 force 64-row tiles),
+ * "conv_ts" / "conv_hs" / "wgrad_ts" / "wgrad_hs" / "wgrad_rs" / "wgrad_tf" (streaming kernels: 0 off, 1 heuristic
+ * (default), 2 every eligible shape), "reduce_il" (channel reductions walk one window, default 1).
  * None of them changes results beyond floating-point accumulation order. */
 int vinet_set_option(const char* name, int32_t value);
 int vinet_fill_f32(float* p, int64_t n, float value, void* stream);
