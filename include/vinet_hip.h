@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 7
+#define VINET_ABI_VERSION 8
 
 enum { VINET_F32 = 0, VINET_BF16 = 1 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
@@ -325,6 +325,24 @@ int vinet_bilinear_fwd(const void* x1, const void* x2, int32_t dtype, const floa
 int vinet_bilinear_bwd(const void* x1, const void* x2, const void* dout, int32_t dtype, const float* w, int32_t B,
                        int32_t C, int32_t I, int32_t J, int32_t O, void* dx1, void* dx2, float* dw, float* dbias,
                        void* stream);
+
+/* ------------------------------------------------------------------------
+ * Saliency-map post-processing: the host-side cv2 / torchvision steps of
+ * generate_result.py:95-104 process() and train.py:251-253 validate(), on device.  Maps are dense float32
+ * [B][H][W]; arithmetic follows opencv-python 3.4.3 / torchvision 0.5.0 (requirements.txt:96,178) as restated in
+ * oracle/postproc_cpu.py, float32 without contraction.
+ *
+ * vinet_resize_blur: dst[b] = cv2.GaussianBlur(cv2.resize(src[b], (oW, oH)), (11, 11), 0)   (INTER_LINEAR; sigma 2.0,
+ *   BORDER_REFLECT_101; utils.py:61-64 blur()).  `minmax` (optional, [B][2] words) receives the per-map minimum and
+ *   maximum of dst as order-preserving keys -- opaque, for vinet_normalize_u8 only.
+ * vinet_minmax: the same keys for maps that did not come out of vinet_resize_blur.
+ * vinet_normalize_u8: utils.py:66-78 img_save(tensor, normalize=True) for each map on its own:
+ *   x = (clamp(x, min, max) - min) / (max - min + 1e-5);  u8 = round_half_even(clamp(x * 255 + 0.5, 0, 255)).
+ * ---------------------------------------------------------------------- */
+int vinet_resize_blur(const float* src, int32_t B, int32_t H, int32_t W, float* dst, int32_t oH, int32_t oW,
+                      uint32_t* minmax, void* stream);
+int vinet_minmax(const float* src, int32_t B, int64_t n, uint32_t* minmax, void* stream);
+int vinet_normalize_u8(const float* src, const uint32_t* minmax, int32_t B, int64_t n, uint8_t* dst, void* stream);
 
 /* misc */
 /* Tuning / A-B switches (process-wide): "dma" (1 = use the LDS-DMA conv kernel where

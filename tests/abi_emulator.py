@@ -599,6 +599,45 @@ class AbiEmulator:
         P[:] = P - f(lr / bc1) * (M_ / denom)
         return 0
 
+    # -- saliency-map post-processing (oracle/postproc_cpu.py is the CPU statement of these) -------------
+    @staticmethod
+    def _mm_key(f):
+        u = np.asarray(f, dtype=np.float32).view(np.uint32)
+        return np.where(u & 0x80000000, ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+    @staticmethod
+    def _mm_unkey(k):
+        k = np.asarray(k, dtype=np.uint32)
+        return np.where(k & 0x80000000, k & np.uint32(0x7FFFFFFF), ~k).astype(np.uint32).view(np.float32)
+
+    def _store_minmax(self, minmax, maps):
+        mm = np.ctypeslib.as_array((C.c_uint32 * (2 * maps.shape[0])).from_address(minmax)).reshape(-1, 2)
+        flat = maps.reshape(maps.shape[0], -1)
+        mm[:, 0] = self._mm_key(flat.min(1))
+        mm[:, 1] = self._mm_key(flat.max(1))
+
+    def vinet_resize_blur(self, src, B, H, W, dst, oH, oW, minmax, stream):
+        from oracle import postproc_cpu as P
+        out = P.resize_blur(_f32(src, B * H * W).reshape(B, H, W), oH, oW)
+        _f32(dst, B * oH * oW)[:] = out.reshape(-1)
+        if minmax:
+            self._store_minmax(minmax, out)
+        return 0
+
+    def vinet_minmax(self, src, B, n, minmax, stream):
+        self._store_minmax(minmax, _f32(src, B * n).reshape(B, n))
+        return 0
+
+    def vinet_normalize_u8(self, src, minmax, B, n, dst, stream):
+        from oracle import postproc_cpu as P
+        x = _f32(src, B * n).reshape(B, n)
+        mm = self._mm_unkey(np.ctypeslib.as_array((C.c_uint32 * (2 * B)).from_address(minmax)).reshape(B, 2))
+        out = np.ctypeslib.as_array((C.c_uint8 * (B * n)).from_address(dst)).reshape(B, n)
+        for b in range(B):
+            assert mm[b, 0] == x[b].min() and mm[b, 1] == x[b].max(), "normalize_u8: stale min/max keys"
+            out[b] = P.normalize_u8(x[b].reshape(1, -1)).reshape(-1)
+        return 0
+
     # -- bilinear ----------------------------------------------------------------------
     @staticmethod
     def _rdflat(ptr, n, dt):

@@ -1169,3 +1169,67 @@ def test_pingpong_kernels_random_shapes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_pp.py"), "16", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- saliency-map post-processing: generate_result.py:95-104, train.py:251-253, utils.py:61-78 ----
+# up- and down-scaling, the harness shape (224x384 -> 360x640), a full-HD image, maps smaller than the blur radius (repeated
+# reflection), one-row / one-column maps, tile edges (sizes that are not multiples of 32 x 64), batches
+POSTPROC_CASES = [
+    ("harness", 2, 224, 384, 360, 640),
+    ("fullhd", 1, 224, 384, 1080, 1920),
+    ("down", 3, 224, 384, 100, 150),
+    ("same", 2, 96, 192, 96, 192),
+    ("tiny_up", 2, 7, 9, 20, 31),
+    ("tiny_down", 1, 8, 8, 3, 5),
+    ("row", 1, 1, 20, 1, 33),
+    ("col", 2, 17, 1, 65, 1),
+    ("tile_edges", 1, 40, 70, 33, 129),
+]
+
+
+@pytest.mark.parametrize("case", POSTPROC_CASES, ids=[c[0] for c in POSTPROC_CASES])
+def test_resize_blur_normalize_u8(case):
+    """the device maps must be the oracle's BIT FOR BIT: float32 blurred maps, min / max keys, uint8 images."""
+    from oracle import postproc_cpu as P
+    name, B, H, W, oH, oW = case
+    lib = _lib()
+    src = torch.sigmoid(_rand("pp" + name, (B, H, W), 3) * 2.0 - 1.0).contiguous()
+    ref = P.resize_blur(src.numpy(), oH, oW)
+    ref8 = P.normalize_u8(ref)
+    s = src.to(_dev())
+    out = torch.empty((B, oH, oW), dtype=torch.float32, device=_dev())
+    mm = torch.empty((B, 2), dtype=torch.int32, device=_dev())
+    assert lib.vinet_resize_blur(s.data_ptr(), B, H, W, out.data_ptr(), oH, oW, mm.data_ptr(), _stream()) == 0, lib.vinet_last_error()
+    u8 = torch.empty((B, oH, oW), dtype=torch.uint8, device=_dev())
+    assert lib.vinet_normalize_u8(out.data_ptr(), mm.data_ptr(), B, oH * oW, u8.data_ptr(), _stream()) == 0, lib.vinet_last_error()
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-6, "resize_blur %s: max abs diff %g" % (name, np.abs(got - ref).max())
+    assert np.array_equal(got, ref), "resize_blur %s: %d of %d samples differ in the last bit" % (name, (got != ref).sum(), ref.size)
+    assert np.array_equal(u8.cpu().numpy(), ref8), "normalize_u8 %s: %d bytes differ" % (name, (u8.cpu().numpy() != ref8).sum())
+    # the keys alone (maps that did not come out of resize_blur), then the bytes from them
+    mm2 = torch.empty((B, 2), dtype=torch.int32, device=_dev())
+    assert lib.vinet_minmax(out.data_ptr(), B, oH * oW, mm2.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(mm.cpu(), mm2.cpu())
+    # no keys requested
+    out2 = torch.empty_like(out)
+    assert lib.vinet_resize_blur(s.data_ptr(), B, H, W, out2.data_ptr(), oH, oW, None, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+def test_normalize_u8_negative_and_constant_maps():
+    """min / max keys order floats of either sign; a constant map divides by 1e-5 and lands on 0"""
+    from oracle import postproc_cpu as P
+    lib = _lib()
+    x = torch.stack([_rand("ppneg", (50, 70), 1), torch.full((50, 70), 0.25), -torch.rand(50, 70, generator=torch.Generator().manual_seed(1)) - 1.0])
+    ref8 = P.normalize_u8(x.numpy())
+    xd = x.to(_dev()).contiguous()
+    mm = torch.empty((3, 2), dtype=torch.int32, device=_dev())
+    u8 = torch.empty((3, 50, 70), dtype=torch.uint8, device=_dev())
+    assert lib.vinet_minmax(xd.data_ptr(), 3, 3500, mm.data_ptr(), _stream()) == 0
+    assert lib.vinet_normalize_u8(xd.data_ptr(), mm.data_ptr(), 3, 3500, u8.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(u8.cpu().numpy(), ref8)
+    assert lib.vinet_resize_blur(None, 1, 4, 4, u8.data_ptr(), 4, 4, None, _stream()) < 0       # bad arguments fail loudly

@@ -7,6 +7,8 @@ and bounded separately."""
 import json
 import os
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -245,3 +247,23 @@ def test_graphed_inference_matches_eager():
     g = GraphedInference(m, x1)
     assert torch.equal(g(x2), e2)
     assert torch.equal(g(x1), e1)
+
+
+def test_harness_postprocessed_maps_eager_graph_and_oracle():
+    """generate_result.py:48-104 on device: the sliding-window schedule with the resize + blur + uint8 step; eager ==
+    hipGraph replay, and the bytes are the oracle's post-processing of the raw maps"""
+    from oracle import postproc_cpu as P
+    from vinet_amd import generate_result as GR
+    from vinet_amd import model as VM
+    E.set_default_dtype("bf16")
+    m = VM.VideoSaliencyModel(num_clips=8).eval()
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 3))
+    m = m.to(DEV)
+    frames = synth.clip(1, 19, 96, 192, 4)[0].to(DEV)              # [N,3,H,W], N >= 2T-1
+    raw = GR.predict_video(m, frames, 8, batch=2)
+    eager = GR.predict_video(m, frames, 8, batch=2, out_size=(135, 240))
+    graph = GR.predict_video(m, frames, 8, batch=2, out_size=(135, 240), graph=True)
+    again = GR.predict_video(m, frames, 8, batch=2, out_size=(135, 240), graph=True)     # cached graph
+    assert eager.dtype == torch.uint8 and eager.shape == (19, 135, 240)
+    assert torch.equal(eager, graph) and torch.equal(graph, again)
+    assert np.array_equal(eager.cpu().numpy(), P.normalize_u8(P.resize_blur(raw.cpu().numpy(), 135, 240)))

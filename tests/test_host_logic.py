@@ -136,3 +136,37 @@ def test_product_path_refuses_cpu_without_library_double():
             MU.BasicConv3d(16, 32, 1, 1)(torch.zeros(1, 16, 1, 2, 2))
     finally:
         L._install_test_double(AbiEmulator())
+
+
+def test_postprocess_host_api_follows_process_and_validate():
+    """vinet_amd.utils.resize_blur / to_uint8 / postprocess / blur and the harness's out_size path against the
+    oracle's statement of generate_result.py:95-104 (through the ABI emulator: host logic only)"""
+    from oracle import postproc_cpu as P
+    from vinet_amd import generate_result as GR
+    from vinet_amd import utils as U
+    maps = torch.sigmoid(synth.normal("pp_host", (3, 24, 40), 5))
+    ref = P.resize_blur(maps.numpy(), 45, 80)
+    got = U.resize_blur(maps, (45, 80))
+    assert got.shape == (3, 45, 80) and np.array_equal(got.numpy(), ref)
+    assert np.array_equal(U.resize_blur(maps[0], (45, 80)).numpy(), ref[0])                       # [H,W] in -> [H,W] out
+    assert np.array_equal(U.blur(maps[1].numpy()).numpy(), P.gaussian_blur11(maps[1].numpy()))    # utils.py:61-64
+    u8 = U.postprocess(maps, (45, 80))
+    assert u8.dtype == torch.uint8 and np.array_equal(u8.numpy(), P.normalize_u8(ref))
+    assert np.array_equal(U.to_uint8(torch.from_numpy(ref[2])).numpy(), P.normalize_u8(ref[2]))
+
+    class Fake(torch.nn.Module):                      # "saliency" = mean over channels and time: checks the frame routing
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, clips):
+            return torch.sigmoid(clips.mean((1, 2)) + clips[:, 0, -1])
+
+    T, N = 3, 7
+    frames = synth.normal("pp_frames", (N, 3, 8, 12), 2)
+    raw = GR.predict_video(Fake(), frames, T, batch=2)
+    out = GR.predict_video(Fake(), frames, T, batch=2, out_size=(20, 18))
+    assert out.dtype == torch.uint8 and out.shape == (N, 20, 18)
+    assert np.array_equal(out.numpy(), P.normalize_u8(P.resize_blur(raw.numpy(), 20, 18)))
+    u8 = GR.process(Fake(), frames[:T].permute(1, 0, 2, 3)[None], None, None, None, None, (18, 20))   # img_size = (w, h)
+    assert u8.shape == (20, 18)

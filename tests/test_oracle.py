@@ -131,3 +131,49 @@ def test_train_step():
     with torch.no_grad():
         loss1 = O.kldiv(m(x), gt)
     _close(loss1, z["loss1"], 1e-5)
+
+
+# ---- oracle/postproc_cpu.py: cv2 / torchvision are absent here ("parity unpinned"); the restatement is checked against two
+# independent implementations of the same published algorithms and against closed-form properties -------------------------
+def test_postproc_resize_matches_half_pixel_bilinear():
+    from oracle import postproc_cpu as P
+    rng = np.random.default_rng(0)
+    for (H, W, oh, ow) in [(224, 384, 360, 640), (224, 384, 100, 150), (7, 9, 20, 31), (8, 8, 3, 5), (1, 20, 1, 33)]:
+        s = rng.random((2, H, W), dtype=np.float32)
+        a = P.resize_linear(s, oh, ow)
+        b = torch.nn.functional.interpolate(torch.from_numpy(s)[None], size=(oh, ow), mode="bilinear", align_corners=False)[0].numpy()
+        assert a.shape == (2, oh, ow) and a.dtype == np.float32
+        assert np.abs(a - b).max() < 1e-4          # torch forms the source index from a float32 scale, cv2 from a double
+    s = rng.random((3, 17, 23), dtype=np.float32)
+    assert np.array_equal(P.resize_linear(s, 17, 23), s)          # same size: weights (1, 0), the identity
+    assert np.allclose(P.resize_linear(np.full((5, 6), 0.375, np.float32), 11, 13), 0.375, atol=1e-7)
+
+
+def test_postproc_gaussian_blur_matches_separable_mirror_correlation():
+    import scipy.ndimage as ndi
+    from oracle import postproc_cpu as P
+    k = P.gaussian_kernel()
+    assert k.dtype == np.float32 and k.shape == (11,) and abs(float(k.sum()) - 1.0) < 2e-7 and np.array_equal(k, k[::-1])
+    assert abs(float(k[5]) / float(k[4]) - np.exp(1.0 / 8.0)) < 1e-6          # sigma = 2: k5 / k4 = exp(1 / (2 sigma^2))
+    rng = np.random.default_rng(1)
+    for (H, W) in [(360, 640), (7, 9), (3, 4), (1, 20), (11, 11)]:           # incl. maps smaller than the radius
+        s = rng.random((2, H, W), dtype=np.float32)
+        a = P.gaussian_blur11(s)
+        k64 = k.astype(np.float64)
+        b = ndi.correlate1d(ndi.correlate1d(s.astype(np.float64), k64, axis=2, mode="mirror"), k64, axis=1, mode="mirror")
+        assert np.abs(a - b).max() < 1e-6
+    assert np.allclose(P.gaussian_blur11(np.full((9, 30), 0.5, np.float32)), 0.5, atol=2e-7)
+    assert list(P.reflect101(np.array([-6, -1, 0, 3, 4, 9]), 4)) == [0, 1, 0, 3, 2, 3]
+
+
+def test_postproc_normalize_u8_known_answers():
+    from oracle import postproc_cpu as P
+    ramp = (np.arange(256, dtype=np.float32) / 255.0).reshape(16, 16)
+    u = P.normalize_u8(ramp)
+    # x*255 + 0.5 is then ROUNDED (half to even), not truncated (utils.py:71): i + 0.5 - eps -> i or i + 1
+    assert u.dtype == np.uint8 and u[0, 0] == 0 and u[-1, -1] == 255 and np.all(np.diff(u.reshape(-1).astype(int)) >= 0)
+    assert np.array_equal(P.normalize_u8(np.full((4, 5), 0.7, np.float32)), np.zeros((4, 5), np.uint8))   # 0 / 1e-5
+    two = np.array([[0.0, 1.0]], np.float32)
+    assert list(P.normalize_u8(two)[0]) == [0, 255]            # 1 / (1 + 1e-5) * 255 + 0.5 = 255.497 -> 255
+    b = P.normalize_u8(np.stack([ramp, 1.0 - ramp]))           # a batch is normalised map by map
+    assert np.array_equal(b[0], u) and b[1][0, 0] == 255

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class CTensor(C.Structure):
@@ -89,6 +89,9 @@ SIGNATURES = {
     "vinet_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "vinet_bilinear_fwd": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "vinet_bilinear_bwd": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "vinet_resize_blur": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
+    "vinet_minmax": [_vp, _i32, _i64, _vp, _vp],
+    "vinet_normalize_u8": [_vp, _vp, _i32, _i64, _vp, _vp],
     "vinet_set_option": [C.c_char_p, _i32],
     "vinet_pack_weights_multi": [_vp, _i32, _i64, _i32, _vp],
     "vinet_fill_f32": [_vp, _i64, _f32, _vp],

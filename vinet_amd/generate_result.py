@@ -5,9 +5,13 @@
 (generate_result.py:58-73): every frame i >= T-1 is predicted from the clip
 [i-T+1 .. i]; the first T-1 frames are predicted from the TIME-REVERSED clip that
 starts at them (torch.flip on dim 2).  `predict_video(model, frames)` runs that
-schedule on a [N,3,H,W] tensor of preprocessed frames and returns [N,H,W] maps.
-Image decoding / cv2.resize / Gaussian blur / PNG writing (generate_result.py:77-104)
-are host post-processing, a "next" row of SURVEY.md section 8(f).
+schedule on a [N,3,H,W] tensor of preprocessed frames that stays resident on the
+device (each call gathers its T frames from it: the reference's `snippet` list,
+without re-uploading T-1 of them) and returns [N,H,W] maps -- or, with
+`out_size=(H_img, W_img)`, the uint8 maps `process()` writes (generate_result.py:95-104:
+cv2.resize -> 11x11 Gaussian blur -> min-max normalise -> uint8), produced on
+device by vinet_amd.utils.postprocess.  `process()` keeps the reference's name and
+arguments.  Image decoding and the PNG encoder stay on the host (PIL).
 """
 import argparse
 
@@ -28,22 +32,65 @@ def sliding_window_schedule(n_frames, T):
     return out
 
 
+class _Pipeline(torch.nn.Module):
+    """model call + post-processing as one callable (what a hipGraph of the harness step captures)"""
+
+    def __init__(self, model, out_size):
+        super().__init__()
+        self.model, self.out_size = model, out_size
+
+    def forward(self, clips):
+        from .utils import postprocess
+        y = self.model(clips)
+        return y if self.out_size is None else postprocess(y, self.out_size)
+
+
 @torch.no_grad()
-def predict_video(model, frames, T, batch=1):
-    """frames [N,3,H,W] (normalised, on the model's device) -> saliency [N,H,W]."""
+def predict_video(model, frames, T, batch=1, out_size=None, graph=False):
+    """frames [N,3,H,W] (normalised, on the model's device) -> saliency [N,H,W] float32, or -- with
+    out_size=(H_img, W_img) -- the post-processed uint8 maps [N,H_img,W_img] of generate_result.py:95-104.
+    graph=True replays one captured hipGraph per full chunk of `batch` calls (vinet_amd/graph.py)."""
     N = frames.shape[0]
     sched = sliding_window_schedule(N, T)
     assert sched, "more frames are needed (N >= 2T-1)"
-    maps = torch.empty((N,) + tuple(frames.shape[2:]), dtype=torch.float32, device=frames.device)
+    if out_size is None:
+        maps = torch.empty((N,) + tuple(frames.shape[2:]), dtype=torch.float32, device=frames.device)
+    else:
+        maps = torch.empty((N, int(out_size[0]), int(out_size[1])), dtype=torch.uint8, device=frames.device)
     model.eval()
+    step = _Pipeline(model, out_size)
+    key = (batch, None if out_size is None else tuple(out_size), T) + tuple(frames.shape[1:])
+    cache = model.__dict__.setdefault("_harness_graphs", {})      # weights must not change between calls (inference)
+    graphed = cache.get(key)
     for s in range(0, len(sched), batch):
         chunk = sched[s:s + batch]
         idx = torch.tensor([c[1] for c in chunk], device=frames.device)
         clips = frames[idx].permute(0, 2, 1, 3, 4)          # [b,T,3,H,W] -> [b,3,T,H,W] (generate_result.py:65)
-        y = model(clips)
-        for j, (o, _, _) in enumerate(chunk):
-            maps[o] = y[j]
+        if graph and len(chunk) == batch:
+            if graphed is None:
+                from .graph import GraphedInference
+                graphed = cache[key] = GraphedInference(step, clips.contiguous())
+            y = graphed(clips)
+        else:
+            y = step(clips)
+        maps[torch.tensor([c[0] for c in chunk], device=frames.device)] = y
     return maps
+
+
+@torch.no_grad()
+def process(model, clip, path_inpdata, dname, frame_no, args, img_size):
+    """generate_result.py:95-104: one model call, cv2.resize to the image's size (img_size = PIL (width, height)),
+    blur, img_save(normalize=True) -- the map crosses to the host once, as uint8."""
+    import os
+    from .utils import postprocess
+    smap = model(clip.to(next(model.parameters()).device))[0]
+    u8 = postprocess(smap, (img_size[1], img_size[0]))
+    if args is not None and getattr(args, "save_path", None):
+        from PIL import Image
+        fp = os.path.join(args.save_path, dname, frame_no)
+        im = Image.fromarray(u8.cpu().numpy())
+        im.save(fp) if fp.split('.')[-1] == "png" else im.save(fp, quality=100)
+    return u8
 
 
 def build_parser():
@@ -64,6 +111,8 @@ def build_parser():
     p.add_argument('--synthetic_frames', default=0, type=int, help="run the schedule on N synthetic 224x384 frames and report fps")
     p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
     p.add_argument('--batch', default=1, type=int)
+    p.add_argument('--graph', default=0, type=int, help="1 = replay a captured hipGraph per model call (+ post-processing)")
+    p.add_argument('--image_size', default="360x640", type=str, help="HxW of the (synthetic) source images the maps are resized to; 0 = keep the raw maps")
     return p
 
 
@@ -85,10 +134,13 @@ def main(argv=None):
     m = m.to(dev).eval()
     assert args.synthetic_frames > 0, "image decoding is out of scope here; use --synthetic_frames N"
     frames = synth.clip(1, args.synthetic_frames, 224, 384, 0)[0].to(dev)
-    predict_video(m, frames[:2 * args.clip_size - 1], args.clip_size, args.batch)
+    out_size = None if args.image_size in ("0", "") else tuple(int(v) for v in args.image_size.split("x"))
+    predict_video(m, frames[:2 * args.clip_size - 1], args.clip_size, args.batch, out_size, bool(args.graph))
     torch.cuda.synchronize()
     t0 = time.time()
-    maps = predict_video(m, frames, args.clip_size, args.batch)
+    maps = predict_video(m, frames, args.clip_size, args.batch, out_size, bool(args.graph))
+    if out_size is not None:
+        maps = maps.cpu()                                    # what the PNG encoder would be handed
     torch.cuda.synchronize()
     n_calls = len(sliding_window_schedule(args.synthetic_frames, args.clip_size))
     print("%d model calls for %d frames in %.3f s -> %.1f fps" % (n_calls, args.synthetic_frames, time.time() - t0, n_calls / (time.time() - t0)))

@@ -159,10 +159,10 @@ def train_epoch(model, optimizer, loader, epoch, device, args, world=1):
 
 
 def validate(model, loader, epoch, device, args):
-    """train.py:231-272 without the host round trip (cv2.resize + blur of the prediction are a
-    'next' row): losses are taken at the network's output resolution."""
+    """train.py:231-272: the prediction is resized to the ground truth's size and blurred (cv2.resize + utils.blur,
+    train.py:251-252) before the losses -- here on device (vinet_amd.utils.resize_blur), without the host round trip."""
     from .loss import cc, similarity
-    from .utils import AverageMeter, loss_func
+    from .utils import AverageMeter, loss_func, resize_blur
     model.eval()
     tic = time.time()
     tl, tc, ts = AverageMeter(), AverageMeter(), AverageMeter()
@@ -171,6 +171,7 @@ def validate(model, loader, epoch, device, args):
             img_clips = sample[0].to(device).permute((0, 2, 1, 3, 4))
             gt_sal = sample[1].to(device)
             pred_sal = model(img_clips, sample[2].to(device)) if (args.use_sound or args.use_vox) else model(img_clips)
+            pred_sal = resize_blur(pred_sal, gt_sal.shape[-2:])
             tl.update(float(loss_func(pred_sal, gt_sal, args)))
             tc.update(float(cc(pred_sal, gt_sal)))
             ts.update(float(similarity(pred_sal, gt_sal)))

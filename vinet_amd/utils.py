@@ -1,6 +1,14 @@
-"""Loss glue and meters -- drop-in for the reference's utils.py:9-59."""
+"""Loss glue, meters and saliency-map post-processing -- drop-in for the reference's utils.py:9-78.
+
+`blur` / `img_save` keep the reference's names and meaning (utils.py:61-78) but work on device tensors:
+cv2.resize + cv2.GaussianBlur + the make_grid normalisation + uint8 conversion run as HIP kernels
+(libvinet_hip.so: vinet_resize_blur, vinet_minmax, vinet_normalize_u8), so a predicted map leaves the GPU once, as
+bytes.  `resize_blur` and `to_uint8` are the fused forms the harness uses.
+"""
 import torch
 
+from . import _lib as L
+from . import engine as E
 from .loss import cc, kldiv, similarity
 
 
@@ -64,3 +72,68 @@ class AverageMeter:
 
 def num_params(model):
     return sum(dict((p.data_ptr(), p.numel()) for p in model.parameters()).values())
+
+
+# ---- post-processing of predicted maps (generate_result.py:95-104, train.py:251-253, utils.py:61-78) ----------
+def _maps3(x):
+    assert x.dim() in (2, 3), "expected a [H,W] map or a [B,H,W] batch of maps"
+    m = x.detach()
+    if m.dtype != torch.float32 or not m.is_contiguous():
+        m = m.float().contiguous()
+    return m.view((-1,) + tuple(m.shape[-2:]))
+
+
+@torch.no_grad()
+def resize_blur(smap, size=None, return_minmax=False):
+    """cv2.GaussianBlur(cv2.resize(smap, (W_out, H_out)), (11, 11), 0) on device.  `size` = (H_out, W_out) (None: no
+    resize -- cv2.resize to the same size is the identity); [H,W] or [B,H,W] float maps in, float32 maps out."""
+    m = _maps3(smap)
+    B, H, W = m.shape
+    oH, oW = (H, W) if size is None else (int(size[0]), int(size[1]))
+    out = torch.empty((B, oH, oW), dtype=torch.float32, device=m.device)
+    mm = torch.empty((B, 2), dtype=torch.int32, device=m.device) if return_minmax else None
+    L.check(L.get().vinet_resize_blur(m.data_ptr(), B, H, W, out.data_ptr(), oH, oW, mm.data_ptr() if mm is not None else None,
+                                      E._stream_for(m.device)), "vinet_resize_blur")
+    out = out[0] if smap.dim() == 2 else out
+    return (out, mm) if return_minmax else out
+
+
+def blur(img):
+    """utils.py:61-64: cv2.GaussianBlur(img, (11, 11), 0) -> FloatTensor (numpy maps are taken to the current device)."""
+    if not torch.is_tensor(img):
+        img = torch.as_tensor(img, dtype=torch.float32, device="cpu" if L.is_test_double() else "cuda")
+    return resize_blur(img, None)
+
+
+@torch.no_grad()
+def to_uint8(maps, minmax=None):
+    """utils.py:66-78 img_save(normalize=True) up to the file write: each map is min-max normalised on its own
+    ((x - min) / (max - min + 1e-5)), scaled by 255, + 0.5, clamped, rounded half to even -> uint8 [.., H, W]."""
+    m = _maps3(maps)
+    B, n = m.shape[0], m.shape[1] * m.shape[2]
+    lib, stream = L.get(), E._stream_for(m.device)
+    if minmax is None:
+        minmax = torch.empty((B, 2), dtype=torch.int32, device=m.device)
+        L.check(lib.vinet_minmax(m.data_ptr(), B, n, minmax.data_ptr(), stream), "vinet_minmax")
+    out = torch.empty(m.shape, dtype=torch.uint8, device=m.device)
+    L.check(lib.vinet_normalize_u8(m.data_ptr(), minmax.data_ptr(), B, n, out.data_ptr(), stream), "vinet_normalize_u8")
+    return out[0] if maps.dim() == 2 else out
+
+
+def postprocess(smap, size):
+    """generate_result.py:97-100 in one go: resize to `size` = (H, W), blur, normalise -> uint8 map(s) on device."""
+    out, mm = resize_blur(smap, size, return_minmax=True)
+    return to_uint8(out, mm)
+
+
+def img_save(tensor, fp, nrow=8, padding=2, normalize=False, range=None, scale_each=False, pad_value=0, format=None):
+    """utils.py:66-78 for the harness's use: ONE [H,W] map, normalize=True.  The grid arguments are accepted for
+    signature compatibility; a single map has no grid."""
+    assert tensor.dim() == 2 and normalize and range is None, "img_save: one [H,W] map with normalize=True (generate_result.py:100)"
+    from PIL import Image
+    nd = to_uint8(tensor).cpu().numpy()
+    im = Image.fromarray(nd)
+    if fp.split('.')[-1] == "png":
+        im.save(fp, format=format)
+    else:
+        im.save(fp, format=format, quality=100)
