@@ -117,6 +117,10 @@ def load(path=LIB_PATH):
         raise VinetLibraryError(
             "libvinet_hip.so is missing (%s). Build it with `python -m vinet_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback." % path)
+    # torch first: the library depends on libamdhip64.so.7 by soname, and a process must hold ONE HIP runtime -- the
+    # one PyTorch-ROCm ships (streams and device pointers cross this boundary).  Loaded before torch, the dependency
+    # would bind to /opt/rocm's copy and every launch on a torch stream would fail ("no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         try:
