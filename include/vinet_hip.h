@@ -344,6 +344,26 @@ int vinet_resize_blur(const float* src, int32_t B, int32_t H, int32_t W, float* 
 int vinet_minmax(const float* src, int32_t B, int64_t n, uint32_t* minmax, void* stream);
 int vinet_normalize_u8(const float* src, const uint32_t* minmax, int32_t B, int64_t n, uint8_t* dst, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Input pipeline: decoded frames / ground-truth maps arrive as BYTES at their own
+ * resolution and become the network's float32 inputs on device.  Scratch is the caller's (`*_ws_bytes`, 16-byte aligned).
+ *
+ * vinet_frames_preprocess: dataloader.py:243-250 / generate_result.py:77-88 img_transform --
+ *   transforms.Resize((oH, oW)) [PIL Image.resize(BILINEAR): 22-bit fixed-point triangle filter, horizontal pass rounded
+ *   to bytes, then vertical pass; Pillow pinned by requirements.txt:106] -> ToTensor (/ 255) -> Normalize.
+ *   src uint8 [N][H][W][3] (RGB interleaved, = np.asarray(img.convert('RGB'))), dst float32 [N][3][oH][oW];
+ *   mean_std: six HOST floats (mean r,g,b, std r,g,b), read during the call.
+ * vinet_gt_preprocess: dataloader.py:283-296 -- uint8 'L' maps [N][H][W] -> float64 -> cv2.resize to (oW, oH) when the
+ *   sizes differ (train mode; INTER_LINEAR, float32 weights, double arithmetic) -> / 255 when the map's maximum
+ *   exceeds 1 -> float32 [N][oH][oW].
+ * ---------------------------------------------------------------------- */
+int64_t vinet_frames_preprocess_ws_bytes(int32_t N, int32_t H, int32_t W, int32_t oH, int32_t oW);
+int vinet_frames_preprocess(const uint8_t* src, int32_t N, int32_t H, int32_t W, float* dst, int32_t oH, int32_t oW,
+                            const float* mean_std, void* ws, void* stream);
+int64_t vinet_gt_preprocess_ws_bytes(int32_t N, int32_t oH, int32_t oW);
+int vinet_gt_preprocess(const uint8_t* src, int32_t N, int32_t H, int32_t W, float* dst, int32_t oH, int32_t oW, void* ws,
+                        void* stream);
+
 /* misc */
 /* Tuning / A-B switches (process-wide): "dma" (1 = use the LDS-DMA conv kernel where
  * legal, default 1), "wgrad_tr" (1 = hardware transpose reads in the register-staged wgrad, default 1),

@@ -638,6 +638,28 @@ class AbiEmulator:
             out[b] = P.normalize_u8(x[b].reshape(1, -1)).reshape(-1)
         return 0
 
+    # -- input pipeline (oracle/preproc_cpu.py) -----------------------------------------------------------
+    def vinet_frames_preprocess_ws_bytes(self, N, H, W, oH, oW):
+        return 256 + N * H * oW * 3
+
+    def vinet_frames_preprocess(self, src, N, H, W, dst, oH, oW, mean_std, ws, stream):
+        from oracle import preproc_cpu as Q
+        assert ws
+        frames = np.ctypeslib.as_array((C.c_uint8 * (N * H * W * 3)).from_address(src)).reshape(N, H, W, 3)
+        ms = [float(mean_std[i]) for i in range(6)]
+        _f32(dst, N * 3 * oH * oW)[:] = Q.frames_preprocess(frames, oH, oW, ms[:3], ms[3:]).reshape(-1)
+        return 0
+
+    def vinet_gt_preprocess_ws_bytes(self, N, oH, oW):
+        return 256 + N * oH * oW * 8
+
+    def vinet_gt_preprocess(self, src, N, H, W, dst, oH, oW, ws, stream):
+        from oracle import preproc_cpu as Q
+        assert ws
+        g = np.ctypeslib.as_array((C.c_uint8 * (N * H * W)).from_address(src)).reshape(N, H, W)
+        _f32(dst, N * oH * oW)[:] = Q.gt_preprocess(g, oH, oW).reshape(-1)
+        return 0
+
     # -- bilinear ----------------------------------------------------------------------
     @staticmethod
     def _rdflat(ptr, n, dt):

@@ -1233,3 +1233,35 @@ def test_normalize_u8_negative_and_constant_maps():
     torch.cuda.synchronize()
     assert np.array_equal(u8.cpu().numpy(), ref8)
     assert lib.vinet_resize_blur(None, 1, 4, 4, u8.data_ptr(), 4, 4, None, _stream()) < 0       # bad arguments fail loudly
+
+
+# ---- input pipeline: dataloader.py:243-250, 283-296; generate_result.py:77-88 --------------------------
+PREPROC_CASES = [
+    ("dhf1k", 3, 360, 640, 224, 384),
+    ("hd", 1, 720, 1280, 224, 384),
+    ("upscale", 2, 100, 150, 224, 384),
+    ("same", 2, 224, 384, 224, 384),
+    ("w_only", 1, 224, 500, 224, 384),
+    ("tiny", 2, 5, 7, 20, 31),
+    ("odd", 1, 37, 53, 20, 31),
+]
+
+
+@pytest.mark.parametrize("case", PREPROC_CASES, ids=[c[0] for c in PREPROC_CASES])
+def test_frames_and_gt_preprocess(case):
+    """device img_transform == the oracle's (which is pinned byte for byte against Pillow), bit for bit; the same for the
+    ground-truth path"""
+    from oracle import preproc_cpu as Q
+    from vinet_amd import preprocess as PR
+    name, N, H, W, oH, oW = case
+    rng = np.random.default_rng(len(name) * 100 + H)
+    u8 = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    got = PR.frames_to_tensor(torch.from_numpy(u8).to(_dev()), (oH, oW)).cpu().numpy()
+    ref = Q.frames_preprocess(u8, oH, oW)
+    assert got.shape == ref.shape and np.array_equal(got, ref), "%s: %d of %d values differ" % (name, (got != ref).sum(), ref.size)
+    g8 = rng.integers(0, 256, (N, H, W), dtype=np.uint8)
+    g8[-1] = (g8[-1] > 200).astype(np.uint8)                  # a 0/1 map: not divided by 255
+    for size in ((oH, oW), None):
+        gg = PR.gt_to_tensor(torch.from_numpy(g8).to(_dev()), size).cpu().numpy()
+        gr = Q.gt_preprocess(g8, *(size or (None, None)))
+        assert np.array_equal(gg, gr), "%s gt %s: max abs diff %g" % (name, size, np.abs(gg - gr).max())

@@ -267,3 +267,33 @@ def test_harness_postprocessed_maps_eager_graph_and_oracle():
     assert eager.dtype == torch.uint8 and eager.shape == (19, 135, 240)
     assert torch.equal(eager, graph) and torch.equal(graph, again)
     assert np.array_equal(eager.cpu().numpy(), P.normalize_u8(P.resize_blur(raw.cpu().numpy(), 135, 240)))
+
+
+def test_directory_harness_end_to_end(tmp_path):
+    """generate_result.py:17-104 on a directory of PNG frames with the real network: bytes up, bytes down; the files
+    equal the oracle's pre- and post-processing around the device's raw maps"""
+    import argparse
+    from PIL import Image
+    from oracle import postproc_cpu as P
+    from oracle import preproc_cpu as Q
+    from vinet_amd import generate_result as GR
+    from vinet_amd import model as VM
+    E.set_default_dtype("bf16")
+    m = VM.VideoSaliencyModel(num_clips=8).eval()
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 3))
+    m = m.to(DEV)
+    rng = np.random.default_rng(2)
+    N, h, w = 16, 90, 160
+    os.makedirs(tmp_path / "in" / "vid" / "images")
+    u8 = rng.integers(0, 256, (N, h, w, 3), dtype=np.uint8)
+    for i in range(N):
+        Image.fromarray(u8[i]).save(tmp_path / "in" / "vid" / "images" / ("%04d.png" % (i + 1)))
+    args = argparse.Namespace(path_indata=str(tmp_path / "in"), save_path=str(tmp_path / "out"), start_idx=-1, num_parts=4,
+                              clip_size=8, batch=3, graph=1)
+    assert GR.validate(args, m, DEV) == N
+    x = torch.from_numpy(Q.frames_preprocess(u8)).to(DEV)
+    raw = GR.predict_video(m, x, 8, batch=3).cpu().numpy()
+    want = P.normalize_u8(P.resize_blur(raw, h, w))
+    for i in range(N):
+        got = np.asarray(Image.open(tmp_path / "out" / "vid" / ("%04d.png" % (i + 1))))
+        assert np.array_equal(got, want[i])

@@ -170,3 +170,54 @@ def test_postprocess_host_api_follows_process_and_validate():
     assert np.array_equal(out.numpy(), P.normalize_u8(P.resize_blur(raw.numpy(), 20, 18)))
     u8 = GR.process(Fake(), frames[:T].permute(1, 0, 2, 3)[None], None, None, None, None, (18, 20))   # img_size = (w, h)
     assert u8.shape == (20, 18)
+
+
+def test_preprocess_host_api_and_directory_harness(tmp_path):
+    """vinet_amd.preprocess against the oracle, then generate_result.validate() on a directory of PNG frames: the saved
+    images must be what the reference's flow produces -- PIL resize + normalise, model call per the sliding-window
+    schedule, cv2.resize + blur + img_save -- here with every stage after the decoder behind the C ABI"""
+    import argparse
+    import os
+    from PIL import Image
+    from oracle import postproc_cpu as P
+    from oracle import preproc_cpu as Q
+    from vinet_amd import generate_result as GR
+    from vinet_amd import preprocess as PR
+    rng = np.random.default_rng(11)
+    u8 = rng.integers(0, 256, (3, 30, 44, 3), dtype=np.uint8)
+    assert np.array_equal(PR.frames_to_tensor(torch.from_numpy(u8), (16, 24)).numpy(), Q.frames_preprocess(u8, 16, 24))
+    assert PR.frames_to_tensor(torch.from_numpy(u8[0])).shape == (3, 224, 384)
+    g8 = rng.integers(0, 256, (2, 30, 44), dtype=np.uint8)
+    assert np.array_equal(PR.gt_to_tensor(torch.from_numpy(g8), (16, 24)).numpy(), Q.gt_preprocess(g8, 16, 24))
+    assert np.array_equal(PR.gt_to_tensor(torch.from_numpy(g8[0])).numpy(), Q.gt_preprocess(g8[:1])[0])
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, clips):
+            return torch.sigmoid(clips.mean((1, 2)) + clips[:, 0, -1])
+
+    T, N, h, w = 3, 6, 30, 44
+    src = tmp_path / "in"
+    frames = {}
+    for v in ("b_video", "a_video", "short"):
+        os.makedirs(src / v / "images")
+        n = 2 if v == "short" else N
+        frames[v] = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        for i in range(n):
+            Image.fromarray(frames[v][i]).save(src / v / "images" / ("%04d.png" % (i + 1)))
+    t, sz = PR.torch_transform(str(src / "a_video" / "images" / "0001.png"))
+    assert sz == (w, h) and np.array_equal(t.numpy(), Q.frames_preprocess(frames["a_video"][:1])[0])
+    args = argparse.Namespace(path_indata=str(src), save_path=str(tmp_path / "out"), start_idx=-1, num_parts=4, clip_size=T, batch=2, graph=0)
+    assert GR.list_videos(str(src)) == ["a_video", "b_video", "short"]
+    assert GR.validate(args, Fake(), torch.device("cpu")) == 2 * N          # "short" has fewer than 2T-1 frames: skipped
+    for v in ("a_video", "b_video"):
+        x = torch.from_numpy(Q.frames_preprocess(frames[v]))
+        raw = GR.predict_video(Fake(), x, T)
+        want = P.normalize_u8(P.resize_blur(raw.numpy(), h, w))
+        for i in range(N):
+            got = np.asarray(Image.open(tmp_path / "out" / v / ("%04d.png" % (i + 1))))
+            assert got.shape == (h, w) and np.array_equal(got, want[i])
+    assert not os.listdir(tmp_path / "out" / "short")

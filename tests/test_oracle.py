@@ -177,3 +177,36 @@ def test_postproc_normalize_u8_known_answers():
     assert list(P.normalize_u8(two)[0]) == [0, 255]            # 1 / (1 + 1e-5) * 255 + 0.5 = 255.497 -> 255
     b = P.normalize_u8(np.stack([ramp, 1.0 - ramp]))           # a batch is normalised map by map
     assert np.array_equal(b[0], u) and b[1][0, 0] == 255
+
+
+# ---- oracle/preproc_cpu.py: the frame resize is PINNED against the real Pillow resampler (present in this image) ----------
+PIL_SHAPES = [(360, 640, 224, 384), (100, 150, 224, 384), (224, 384, 224, 384), (720, 1280, 224, 384), (37, 53, 20, 31),
+              (5, 7, 224, 384), (300, 384, 224, 384), (224, 500, 224, 384), (1, 9, 4, 3)]
+
+
+@pytest.mark.parametrize("shape", PIL_SHAPES, ids=["%dx%d_to_%dx%d" % s for s in PIL_SHAPES])
+def test_preproc_resize_equals_pillow_byte_for_byte(shape):
+    from PIL import Image
+    from oracle import preproc_cpu as Q
+    H, W, oh, ow = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ours = Q.pil_resize_bilinear(img, oh, ow)
+    pil = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+    assert np.array_equal(ours, pil)
+    # img_transform as a whole: ToTensor + Normalize are plain float32 arithmetic on those bytes
+    x = Q.frames_preprocess(img[None], oh, ow)
+    want = (torch.from_numpy(pil.copy()).permute(2, 0, 1).float().div(255) - torch.tensor(Q.MEAN)[:, None, None]) / torch.tensor(Q.STD)[:, None, None]
+    assert x.shape == (1, 3, oh, ow) and np.array_equal(x[0], want.numpy())
+
+
+def test_preproc_gt_maps():
+    from oracle import preproc_cpu as Q
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 256, (2, 36, 64), dtype=np.uint8)
+    g[1] = (g[1] > 250).astype(np.uint8)                      # a 0/1 map is NOT divided (dataloader.py:294: max > 1.0)
+    same = Q.gt_preprocess(g)
+    assert np.array_equal(same[0], (g[0].astype(np.float64) / 255.0).astype(np.float32)) and np.array_equal(same[1], g[1].astype(np.float32))
+    r = Q.gt_preprocess(g, 22, 38)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(g[:1].astype(np.float64))[None], size=(22, 38), mode="bilinear", align_corners=False)[0, 0].numpy() / 255.0
+    assert r.shape == (2, 22, 38) and r.dtype == np.float32 and np.abs(r[0] - ref).max() < 1e-4

@@ -92,13 +92,18 @@ SIGNATURES = {
     "vinet_resize_blur": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
     "vinet_minmax": [_vp, _i32, _i64, _vp, _vp],
     "vinet_normalize_u8": [_vp, _vp, _i32, _i64, _vp, _vp],
+    "vinet_frames_preprocess_ws_bytes": [_i32, _i32, _i32, _i32, _i32],
+    "vinet_frames_preprocess": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, C.POINTER(C.c_float), _vp, _vp],
+    "vinet_gt_preprocess_ws_bytes": [_i32, _i32, _i32],
+    "vinet_gt_preprocess": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
     "vinet_set_option": [C.c_char_p, _i32],
     "vinet_pack_weights_multi": [_vp, _i32, _i64, _i32, _vp],
     "vinet_fill_f32": [_vp, _i64, _f32, _vp],
     "vinet_abi_version": [],
     "vinet_last_error": [],
 }
-_RESTYPE = {"vinet_last_error": C.c_char_p, "vinet_conv3d_splitk_bytes": C.c_int64}
+_RESTYPE = {"vinet_last_error": C.c_char_p, "vinet_conv3d_splitk_bytes": C.c_int64, "vinet_frames_preprocess_ws_bytes": C.c_int64,
+            "vinet_gt_preprocess_ws_bytes": C.c_int64}
 
 _LIB = None
 _TEST_DOUBLE = None

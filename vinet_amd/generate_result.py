@@ -93,6 +93,54 @@ def process(model, clip, path_inpdata, dname, frame_no, args, img_size):
     return u8
 
 
+def list_videos(path_indata, start_idx=-1, num_parts=4):
+    """generate_result.py:40-45: sorted video directories, optionally the start_idx-th of num_parts slices."""
+    import os
+    names = sorted(d for d in os.listdir(path_indata) if os.path.isdir(os.path.join(path_indata, d)))
+    if start_idx != -1:
+        _len = (1.0 / float(num_parts)) * len(names)
+        names = names[int((start_idx - 1) * _len): int(start_idx * _len)]
+    return names
+
+
+@torch.no_grad()
+def validate(args, model=None, device=None):
+    """generate_result.py:17-75 (the reference's entry point is also called `validate`): every video directory under
+    args.path_indata, frames from `<video>/images`, one saliency image per frame into args.save_path/<video>/ under the
+    frame's file name.  Decoding (PIL) and the PNG / JPEG encoder run on the host; resize + normalise of the frames, the
+    sliding-window model calls and resize + blur + uint8 of the maps run on the device."""
+    import os
+
+    import numpy as np
+    from PIL import Image
+
+    from . import preprocess
+    T = args.clip_size
+    dev = device if device is not None else torch.device('cuda')
+    n_saved = 0
+    for dname in list_videos(args.path_indata, args.start_idx, args.num_parts):
+        print('processing ' + dname, flush=True)
+        img_dir = os.path.join(args.path_indata, dname, 'images')
+        list_frames = sorted(f for f in os.listdir(img_dir) if os.path.isfile(os.path.join(img_dir, f)))
+        os.makedirs(os.path.join(args.save_path, dname), exist_ok=True)
+        if len(list_frames) < 2 * T - 1:
+            print(' more frames are needed')
+            continue
+        imgs = [Image.open(os.path.join(img_dir, f)).convert('RGB') for f in list_frames]
+        sizes = set(im.size for im in imgs)
+        assert len(sizes) == 1, "frames of one video must share a size (%s: %s)" % (dname, sorted(sizes))
+        w, h = imgs[0].size
+        u8 = torch.from_numpy(np.stack([np.asarray(im) for im in imgs])).to(dev)           # [N,h,w,3] bytes: the only upload
+        frames = preprocess.frames_to_tensor(u8)                                          # [N,3,224,384]
+        maps = predict_video(model, frames, T, getattr(args, "batch", 1), (h, w), bool(getattr(args, "graph", 0))).cpu().numpy()
+        for i, f in enumerate(list_frames):
+            fp = os.path.join(args.save_path, dname, f)
+            im = Image.fromarray(maps[i])
+            im.save(fp) if fp.split('.')[-1] == "png" else im.save(fp, quality=100)
+            n_saved += 1
+    return n_saved
+
+
 def build_parser():
     p = argparse.ArgumentParser()
     p.add_argument('--file_weight', default="./saved_models/ViNet_DHF1K.pt", type=str)
@@ -108,11 +156,11 @@ def build_parser():
     p.add_argument('--num_decoder_layers', default=-1, type=int)
     p.add_argument('--num_hier', default=3, type=int)
     p.add_argument('--clip_size', default=32, type=int)
-    p.add_argument('--synthetic_frames', default=0, type=int, help="run the schedule on N synthetic 224x384 frames and report fps")
+    p.add_argument('--synthetic_frames', default=0, type=int, help="run the schedule on N synthetic 224x384 frames and report fps (no files)")
     p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
     p.add_argument('--batch', default=1, type=int)
     p.add_argument('--graph', default=0, type=int, help="1 = replay a captured hipGraph per model call (+ post-processing)")
-    p.add_argument('--image_size', default="360x640", type=str, help="HxW of the (synthetic) source images the maps are resized to; 0 = keep the raw maps")
+    p.add_argument('--image_size', default="360x640", type=str, help="synthetic mode: HxW of the source images the maps are resized to; 0 = keep the raw maps")
     return p
 
 
@@ -132,7 +180,11 @@ def main(argv=None):
         print("weight file? using procedural weights")
         m.load_state_dict(synth.synth_state_dict(m.state_dict(), 0))
     m = m.to(dev).eval()
-    assert args.synthetic_frames > 0, "image decoding is out of scope here; use --synthetic_frames N"
+    if args.synthetic_frames <= 0:
+        t0 = time.time()
+        n = validate(args, m, dev)
+        print("%d saliency images written in %.3f s" % (n, time.time() - t0))
+        return n
     frames = synth.clip(1, args.synthetic_frames, 224, 384, 0)[0].to(dev)
     out_size = None if args.image_size in ("0", "") else tuple(int(v) for v in args.image_size.split("x"))
     predict_video(m, frames[:2 * args.clip_size - 1], args.clip_size, args.batch, out_size, bool(args.graph))
