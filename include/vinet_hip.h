@@ -360,6 +360,11 @@ int vinet_normalize_u8(const float* src, const uint32_t* minmax, int32_t B, int6
 int64_t vinet_frames_preprocess_ws_bytes(int32_t N, int32_t H, int32_t W, int32_t oH, int32_t oW);
 int vinet_frames_preprocess(const uint8_t* src, int32_t N, int32_t H, int32_t W, float* dst, int32_t oH, int32_t oW,
                             const float* mean_std, void* ws, void* stream);
+/* vinet_audio_excerpt: dataloader.py:89-122 get_audio_feature -- out (win = 70560 floats) = zeros, with
+ *   float(np.hanning(M)) * wav[start : end + 1] centred at win / 2 (offset win/2 - M/2; M = the clamped slice length;
+ *   hanning in double with numpy 1.18.5's formula, requirements.txt:91).  wav is the device-resident waveform of the video
+ *   (already scaled by 2^-23, dataloader.py:63). */
+int vinet_audio_excerpt(const float* wav, int64_t n_samples, int64_t start, int64_t end, float* out, int32_t win, void* stream);
 int64_t vinet_gt_preprocess_ws_bytes(int32_t N, int32_t oH, int32_t oW);
 int vinet_gt_preprocess(const uint8_t* src, int32_t N, int32_t H, int32_t W, float* dst, int32_t oH, int32_t oW, void* ws,
                         void* stream);

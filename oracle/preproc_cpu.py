@@ -17,6 +17,12 @@ Third-party arithmetic:
   * ToTensor: float32(byte) / 255;  Normalize: (x - mean) / std in float32 (torchvision absent: restated).
   * cv2.resize on the float64 map: INTER_LINEAR with float32 coefficients and double accumulation (resize.cpp,
     HResizeLinear<double, double, float>) -- cv2 absent: **unpinned**, shares oracle/postproc_cpu.py's coefficient code.
+
+    dataloader.py:65-75    starts / ends: the audio sample range of every video frame (host integer logic)
+    dataloader.py:89-122   get_audio_feature: zeros(1, 70560) with float(np.hanning(M)) * wav[:, start:end+1] centred
+  * np.hanning: numpy==1.18.5 is pinned (requirements.txt:91): 0.5 - 0.5*cos(2*pi*n/(M-1)) for n = 0..M-1 in double.
+    numpy 2.2 here evaluates the algebraically equal 0.5 + 0.5*cos(pi*n'/(M-1)), n' = 1-M, 3-M, ..; the restatement is
+    compared with it to float32 round-off (tests/test_oracle.py) -- pinned to that tolerance.
 """
 import math
 
@@ -96,4 +102,36 @@ def gt_preprocess(gt, oh=None, ow=None):
     for i in range(g.shape[0]):
         m = g[i]
         out[i] = (m / 255.0 if m.max() > 1.0 else m).astype(np.float32)
+    return out
+
+
+def audio_frame_bounds(n_frames, fps, Fs, n_samples_total):
+    """dataloader.py:65-75: starts[f], ends[f] (f = 1..n_frames; index 0 unused = 0) of the audio samples of video frame f."""
+    n_samples = Fs / float(fps)
+    starts = np.zeros(n_frames + 1, dtype=int)
+    ends = np.zeros(n_frames + 1, dtype=int)
+    for f in range(1, n_frames + 1):
+        starts[f] = int(max(0, ((f - 1) * (1.0 / float(fps)) * Fs) - n_samples / 2))
+        ends[f] = int(min(n_samples_total, abs(((f - 1) * (1.0 / float(fps)) * Fs) + n_samples / 2)))
+    return starts, ends
+
+
+def hanning_np118(M):
+    """numpy 1.18.5 lib/function_base.py hanning()."""
+    if M < 1:
+        return np.array([])
+    if M == 1:
+        return np.ones(1, float)
+    n = np.arange(0, M)
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * n / (M - 1))
+
+
+def audio_excerpt(wav, start, end, win=70560):
+    """dataloader.py:89-122 for one video: wav float32 [L] (already * 2**-23) -> float32 [win]."""
+    wav = np.asarray(wav, dtype=np.float32)
+    seg = wav[start:end + 1]
+    M = seg.shape[0]
+    out = np.zeros(win, np.float32)
+    lo = win // 2 - M // 2
+    out[lo:lo + M] = hanning_np118(M).astype(np.float32) * seg
     return out

@@ -650,6 +650,14 @@ class AbiEmulator:
         _f32(dst, N * 3 * oH * oW)[:] = Q.frames_preprocess(frames, oH, oW, ms[:3], ms[3:]).reshape(-1)
         return 0
 
+    def vinet_audio_excerpt(self, wav, n_samples, start, end, out, win, stream):
+        from oracle import preproc_cpu as Q
+        w = _f32(wav, n_samples) if n_samples else np.zeros(0, np.float32)
+        if min(end + 1, n_samples) - start > win:
+            return -1
+        _f32(out, win)[:] = Q.audio_excerpt(w, start, end, win)
+        return 0
+
     def vinet_gt_preprocess_ws_bytes(self, N, oH, oW):
         return 256 + N * oH * oW * 8
 

@@ -1265,3 +1265,20 @@ def test_frames_and_gt_preprocess(case):
         gg = PR.gt_to_tensor(torch.from_numpy(g8).to(_dev()), size).cpu().numpy()
         gr = Q.gt_preprocess(g8, *(size or (None, None)))
         assert np.array_equal(gg, gr), "%s gt %s: max abs diff %g" % (name, size, np.abs(gg - gr).max())
+
+
+def test_audio_excerpt():
+    """dataloader.py:89-122 on device: exact zeros outside the excerpt, float32 round-off inside (the window is a double
+    cosine evaluated by two different libms)"""
+    from oracle import preproc_cpu as Q
+    from vinet_amd import preprocess as PR
+    rng = np.random.default_rng(3)
+    wav = (rng.standard_normal(200000) * 2 ** -8).astype(np.float32)
+    wd = torch.from_numpy(wav).to(_dev())
+    for (s, e) in [(0, 999), (5000, 5000 + 70559), (1234, 1234 + 47040), (199000, 260000), (10, 10), (300, 299)]:
+        got = PR.audio_excerpt(wd, s, e).cpu().numpy()
+        ref = Q.audio_excerpt(wav, s, e)
+        assert np.array_equal(got == 0, ref == 0) or np.abs(got - ref).max() < 1e-9
+        assert np.abs(got - ref).max() <= 1e-9 + 2e-7 * np.abs(ref).max()
+    with pytest.raises(Exception):
+        PR.audio_excerpt(wd, 0, 80000)                   # longer than the window: the reference's assignment fails too

@@ -221,3 +221,21 @@ def test_preprocess_host_api_and_directory_harness(tmp_path):
             got = np.asarray(Image.open(tmp_path / "out" / v / ("%04d.png" % (i + 1))))
             assert got.shape == (h, w) and np.array_equal(got, want[i])
     assert not os.listdir(tmp_path / "out" / "short")
+
+
+def test_audio_feature_host_api():
+    """vinet_amd.preprocess.get_audio_feature keeps dataloader.py:89-122's arguments and result"""
+    from oracle import preproc_cpu as Q
+    from vinet_amd import preprocess as PR
+    rng = np.random.default_rng(4)
+    wav = (rng.standard_normal((1, 150000)) * 2 ** -8).astype(np.float32)
+    starts, ends = PR.audio_frame_bounds(160, 25.0, 22050, wav.shape[1])
+    s2, e2 = Q.audio_frame_bounds(160, 25.0, 22050, wav.shape[1])
+    assert np.array_equal(starts, s2) and np.array_equal(ends, e2)
+    data = {"vid": dict(wav=torch.from_numpy(wav), starts=starts, ends=ends)}
+    f = PR.get_audio_feature("vid", data, 32, 10)
+    assert f.shape == (1, 70560, 1) and np.array_equal(f.view(-1).numpy(), Q.audio_excerpt(wav[0], starts[11], ends[42]))
+    f = PR.get_audio_feature("vid", data, 32, 140)                         # runs past the last frame: ends[-1]
+    assert np.array_equal(f.view(-1).numpy(), Q.audio_excerpt(wav[0], starts[141], ends[-1]))
+    assert float(PR.get_audio_feature("nope", data, 32, 0).abs().sum()) == 0.0
+    assert PR.MAX_AUDIO_WIN == 70560

@@ -210,3 +210,22 @@ def test_preproc_gt_maps():
     r = Q.gt_preprocess(g, 22, 38)
     ref = torch.nn.functional.interpolate(torch.from_numpy(g[:1].astype(np.float64))[None], size=(22, 38), mode="bilinear", align_corners=False)[0, 0].numpy() / 255.0
     assert r.shape == (2, 22, 38) and r.dtype == np.float32 and np.abs(r[0] - ref).max() < 1e-4
+
+
+def test_preproc_audio_excerpt_and_frame_bounds():
+    from oracle import preproc_cpu as Q
+    for M in (1, 2, 7, 1470, 70560):
+        assert np.allclose(Q.hanning_np118(M), np.hanning(M), rtol=0, atol=1e-12)       # the two formulas are algebraically equal
+        assert np.abs(Q.hanning_np118(M).astype(np.float32) - np.hanning(M).astype(np.float32)).max() <= 6e-8
+    rng = np.random.default_rng(3)
+    wav = (rng.standard_normal(200000) * 2 ** -8).astype(np.float32)
+    for (s, e) in [(0, 999), (5000, 5000 + 70559), (1234, 1234 + 47040), (199000, 260000), (10, 10)]:
+        out = Q.audio_excerpt(wav, s, e)
+        M = min(e + 1, wav.shape[0]) - s
+        lo = 70560 // 2 - M // 2
+        assert out.shape == (70560,) and np.all(out[:lo] == 0) and np.all(out[lo + M:] == 0)
+        assert np.array_equal(out[lo:lo + M], Q.hanning_np118(M).astype(np.float32) * wav[s:s + M])
+    st, en = Q.audio_frame_bounds(5, 25.0, 22050, 4000)          # 882 samples per frame, clipped by the waveform's end
+    assert list(st) == [0, 0, 441, 1323, 2205, 3087] and list(en) == [0, 441, 1323, 2205, 3087, 3969]
+    st, en = Q.audio_frame_bounds(6, 25.0, 22050, 4000)
+    assert en[6] == 4000

@@ -94,6 +94,7 @@ SIGNATURES = {
     "vinet_normalize_u8": [_vp, _vp, _i32, _i64, _vp, _vp],
     "vinet_frames_preprocess_ws_bytes": [_i32, _i32, _i32, _i32, _i32],
     "vinet_frames_preprocess": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, C.POINTER(C.c_float), _vp, _vp],
+    "vinet_audio_excerpt": [_vp, _i64, _i64, _i64, _vp, _i32, _vp],
     "vinet_gt_preprocess_ws_bytes": [_i32, _i32, _i32],
     "vinet_gt_preprocess": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
     "vinet_set_option": [C.c_char_p, _i32],

@@ -159,6 +159,21 @@ __global__ __launch_bounds__(256) void gt_scale_kernel(const double* __restrict_
   }
 }
 
+// dataloader.py:106-121: out[off + i] = float(hanning(M)[i]) * wav[start + i], zeros elsewhere.  numpy 1.18.5 (requirements.txt:91):
+// hanning(M) = 0.5 - 0.5 * cos(2 pi n / (M - 1)), n = 0..M-1, in double; M == 1 -> [1.0]
+__global__ __launch_bounds__(256) void audio_excerpt_kernel(const float* __restrict__ wav, long start, long M, long off, long win,
+                                                            float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= win) return;
+  const long j = i - off;
+  float v = 0.f;
+  if (j >= 0 && j < M) {
+    const double h = M == 1 ? 1.0 : 0.5 - 0.5 * cos(2.0 * 3.141592653589793 * (double)j / (double)(M - 1));
+    v = (float)h * wav[start + j];
+  }
+  out[i] = v;
+}
+
 static int rs_ksize(int in_size, int out_size) {
   double fs = (double)in_size / (double)out_size;
   if (fs < 1.0) fs = 1.0;
@@ -226,4 +241,16 @@ extern "C" int vinet_gt_preprocess(const uint8_t* src, int32_t N, int32_t H, int
   hipLaunchKernelGGL(gt_resize_kernel, dim3((unsigned)blocks, N), dim3(256), 0, st, src, H, W, oH, oW, scale_y, scale_x, buf, keys);
   hipLaunchKernelGGL(gt_scale_kernel, dim3((unsigned)blocks, N), dim3(256), 0, st, buf, keys, n, dst);
   return vn_launch_status("gt_preprocess");
+}
+
+extern "C" int vinet_audio_excerpt(const float* wav, int64_t n_samples, int64_t start, int64_t end, float* out, int32_t win, void* stream) {
+  VN_CHECK_ARG(wav && out && n_samples >= 0 && win > 0 && start >= 0, "audio_excerpt: bad arguments");
+  // wav[:, start:end+1] (dataloader.py:104): Python slicing clamps to the waveform
+  long hi = end + 1 < n_samples ? end + 1 : n_samples;
+  long M = hi - start;
+  if (M < 0) M = 0;
+  VN_CHECK_ARG(M <= win, "audio_excerpt: the excerpt (%ld samples) is longer than the window (%d)", M, win);
+  const long off = win / 2 - M / 2;
+  hipLaunchKernelGGL(audio_excerpt_kernel, dim3((win + 255) / 256), dim3(256), 0, (hipStream_t)stream, wav, (long)start, M, off, (long)win, out);
+  return vn_launch_status("audio_excerpt");
 }

@@ -67,3 +67,47 @@ def torch_transform(path, device=None):
     dev = device if device is not None else ("cpu" if L.is_test_double() else "cuda")
     u8 = torch.from_numpy(np.asarray(img).copy()).to(dev)
     return frames_to_tensor(u8), sz
+
+
+# ---- audio (AViNet): dataloader.py:36-122 ----------------------------------------------------------------------------------
+MAX_AUDIO_WIN = int(22050 / 10 * 32)          # dataloader.py:91-94: max_audio_Fs / min_video_fps * 32 = 70560
+
+
+def audio_frame_bounds(n_frames, fps, Fs, n_samples_total):
+    """dataloader.py:65-75: (starts, ends) of the audio samples that belong to video frame f = 1..n_frames."""
+    import numpy as np
+    n_samples = Fs / float(fps)
+    starts = np.zeros(n_frames + 1, dtype=int)
+    ends = np.zeros(n_frames + 1, dtype=int)
+    for f in range(1, n_frames + 1):
+        starts[f] = int(max(0, ((f - 1) * (1.0 / float(fps)) * Fs) - n_samples / 2))
+        ends[f] = int(min(n_samples_total, abs(((f - 1) * (1.0 / float(fps)) * Fs) + n_samples / 2)))
+    return starts, ends
+
+
+@torch.no_grad()
+def audio_excerpt(wav, start, end, win=MAX_AUDIO_WIN):
+    """Hanning-windowed excerpt wav[start:end+1] centred in `win` zeros (dataloader.py:95-121); wav: float32 [L] or [1,L]
+    on the device (one upload per video), result float32 [win]."""
+    w = wav.reshape(-1)
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    out = torch.empty(win, dtype=torch.float32, device=w.device)
+    L.check(L.get().vinet_audio_excerpt(w.data_ptr(), w.numel(), int(start), int(end), out.data_ptr(), win, E._stream_for(w.device)),
+            "vinet_audio_excerpt")
+    return out
+
+
+def get_audio_feature(audioind, audiodata, clip_size, start_idx):
+    """dataloader.py:89-122, same arguments and result ([1, 70560, 1]); `audiodata[video]['wav']` is a device tensor."""
+    info = audiodata.get(audioind)
+    if info is None:
+        print(audioind, "not present in data")
+        dev = "cpu" if L.is_test_double() else "cuda"
+        return torch.zeros(1, MAX_AUDIO_WIN, 1, device=dev)
+    start = info['starts'][start_idx + 1]
+    if start_idx + clip_size >= len(info['ends']):
+        print("Exceeds size", audioind)
+        end = info['ends'][-1]
+    else:
+        end = info['ends'][start_idx + clip_size]
+    return audio_excerpt(info['wav'], start, end).view(1, -1, 1)
