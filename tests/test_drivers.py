@@ -43,3 +43,79 @@ def test_s3d_kinetics_key_remap():
     sd = bb.state_dict()
     for i, dst in enumerate(want.values()):
         assert torch.equal(sd[dst], torch.full_like(sd[dst], float(i + 1)))
+
+
+def _fake_dhf1k(root, n_videos=3, n_frames=9, h=20, w=30, seed=0):
+    import os
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    data = {}
+    for v in range(n_videos):
+        name = "%03d" % (v + 1)
+        os.makedirs(root / name / "images")
+        os.makedirs(root / name / "maps")
+        fr = rng.integers(0, 256, (n_frames + v, h + 2 * v, w, 3), dtype=np.uint8)      # videos differ in length and size
+        gt = rng.integers(0, 256, (n_frames + v, h + 2 * v, w), dtype=np.uint8)
+        for i in range(fr.shape[0]):
+            Image.fromarray(fr[i]).save(root / name / "images" / ("%04d.png" % (i + 1)))
+            Image.fromarray(gt[i]).save(root / name / "maps" / ("%04d.png" % (i + 1)))
+        data[name] = (fr, gt)
+    return data
+
+
+def test_dhf1k_dataset_yields_bytes_with_the_reference_selection(tmp_path):
+    """dataloader.py:236-309: lengths, clip starts and frame names per mode; items are the decoder's bytes"""
+    import numpy as np
+    from vinet_amd import dataloader as DL
+    data = _fake_dhf1k(tmp_path)
+    T = 3
+    tr = DL.DHF1KDataset(str(tmp_path), T, mode="train")
+    assert len(tr) == 3
+    np.random.seed(5)
+    clip, gt = tr[1]
+    np.random.seed(5)
+    name = tr.video_names[1]
+    start = np.random.randint(0, tr.list_num_frame[1] - T + 1)                  # dataloader.py:272
+    fr, g = data[name]
+    assert clip.dtype == torch.uint8 and np.array_equal(clip.numpy(), fr[start:start + T]) and np.array_equal(gt.numpy(), g[start + T - 1])
+    va = DL.DHF1KDataset(str(tmp_path), T, mode="val")
+    want = sorted((v, i) for v in data for i in range(0, data[v][0].shape[0] - T, 4 * T))
+    assert sorted(va.list_num_frame) == want and len(va) == len(want)
+    sv = DL.DHF1KDataset(str(tmp_path), T, mode="save")
+    want = sorted([(v, i) for v in data for i in range(0, data[v][0].shape[0] - T, T)] + [(v, data[v][0].shape[0] - T) for v in data])
+    assert sorted(sv.list_num_frame) == want
+    clip, s0, fname, sz = sv[0]
+    assert clip.shape[0] == T and sz == (data[fname][0].shape[2], data[fname][0].shape[1]) and np.array_equal(clip.numpy(), data[fname][0][s0:s0 + T])
+    alt = DL.DHF1KDataset(str(tmp_path), T, mode="val", alternate=2)
+    v, i = alt.list_num_frame[0]
+    assert np.array_equal(alt[0][0].numpy(), data[v][0][i:i + 2 * T:2])
+    mf = DL.DHF1KDataset(str(tmp_path), T, mode="val", multi_frame=1)
+    assert mf[0][1].shape[0] == T
+
+
+def test_device_batch_equals_the_reference_transforms(tmp_path):
+    """bytes -> network inputs through the C ABI (emulator here) == img_transform / gt handling restated by the oracle"""
+    import numpy as np
+    from oracle import preproc_cpu as Q
+    from tests.abi_emulator import AbiEmulator
+    from vinet_amd import _lib as L
+    from vinet_amd import dataloader as DL
+    data = _fake_dhf1k(tmp_path)
+    L._install_test_double(AbiEmulator())
+    try:
+        ds = DL.DHF1KDataset(str(tmp_path), 3, mode="train")
+        np.random.seed(1)
+        loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, collate_fn=DL.collate_bytes)
+        raw = next(iter(loader))
+        x, g = DL.DeviceBatch(torch.device("cpu"), "train")(raw)
+        assert x.shape == (3, 3, 3, 224, 384) and g.shape == (3, 224, 384)
+        for b in range(3):
+            assert np.array_equal(x[b].numpy(), Q.frames_preprocess(raw[0][b].numpy()))
+            assert np.array_equal(g[b].numpy(), Q.gt_preprocess(raw[1][b].numpy()[None], 224, 384)[0])
+        va = DL.DHF1KDataset(str(tmp_path), 3, mode="val")
+        raw = next(iter(torch.utils.data.DataLoader(va, batch_size=1, collate_fn=DL.collate_bytes)))
+        x, g = DL.DeviceBatch(torch.device("cpu"), "val")(raw)
+        assert g.shape == (1,) + tuple(raw[1][0].shape) and np.array_equal(g[0].numpy(), Q.gt_preprocess(raw[1][0].numpy()[None])[0])
+    finally:
+        L._install_test_double(None)

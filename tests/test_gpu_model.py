@@ -297,3 +297,22 @@ def test_directory_harness_end_to_end(tmp_path):
     for i in range(N):
         got = np.asarray(Image.open(tmp_path / "out" / "vid" / ("%04d.png" % (i + 1))))
         assert np.array_equal(got, want[i])
+
+
+def test_train_driver_on_a_dhf1k_directory(tmp_path, capsys):
+    """train.py's flow on PNG files: DHF1KDataset (bytes) -> device preprocessing -> train epoch -> validate (resize + blur on
+    device) -> best-val checkpoint, with the reference's flags"""
+    from tests.test_drivers import _fake_dhf1k
+    from vinet_amd import train as TR
+    _fake_dhf1k(tmp_path / "train", n_videos=4, n_frames=10, h=45, w=80)
+    _fake_dhf1k(tmp_path / "val", n_videos=2, n_frames=10, h=45, w=80, seed=1)
+    ckpt = tmp_path / "best.pt"
+    args = TR.build_parser().parse_args(["--dataset", "DHF1KDataset", "--train_path_data", str(tmp_path / "train"), "--val_path_data",
+                                         str(tmp_path / "val"), "--clip_size", "8", "--batch_size", "2", "--no_epochs", "2",
+                                         "--no_workers", "0", "--log_interval", "1", "--model_val_path", str(ckpt)])
+    m = TR.run(args)
+    out = capsys.readouterr().out
+    assert "[ 0, train] avg_loss" in out and "[ 1, val] avg_loss" in out and "save" in out
+    sd = torch.load(ckpt, map_location="cpu")
+    assert set(sd.keys()) == set(m.state_dict().keys())
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())

@@ -133,7 +133,10 @@ def train_epoch(model, optimizer, loader, epoch, device, args, world=1):
     model.train()
     tic = time.time()
     total_loss, cur_loss = AverageMeter(), AverageMeter()
+    prepare = getattr(loader, "device_batch", None)        # byte batches (vinet_amd.dataloader): preprocess on the device
     for idx, sample in enumerate(loader):
+        if prepare is not None:
+            sample = prepare(sample)
         img_clips = sample[0].to(device).permute((0, 2, 1, 3, 4))
         gt_sal = sample[1].to(device)
         optimizer.zero_grad()
@@ -166,8 +169,11 @@ def validate(model, loader, epoch, device, args):
     model.eval()
     tic = time.time()
     tl, tc, ts = AverageMeter(), AverageMeter(), AverageMeter()
+    prepare = getattr(loader, "device_batch", None)
     with torch.no_grad():
         for sample in loader:
+            if prepare is not None:
+                sample = prepare(sample)
             img_clips = sample[0].to(device).permute((0, 2, 1, 3, 4))
             gt_sal = sample[1].to(device)
             pred_sal = model(img_clips, sample[2].to(device)) if (args.use_sound or args.use_vox) else model(img_clips)
@@ -194,14 +200,24 @@ def run(args, train_dataset=None, val_dataset=None):
     model.to(device)
     assert args.batch_size % world == 0, "--batch_size is the global batch and must divide over the ranks"
     local_bs = args.batch_size // world
+    collate = None
+    if train_dataset is None and args.dataset == "DHF1KDataset":           # train.py:97-99
+        from . import dataloader
+        train_dataset = dataloader.DHF1KDataset(args.train_path_data, args.clip_size, mode="train", alternate=args.alternate)
+        val_dataset = dataloader.DHF1KDataset(args.val_path_data, args.clip_size, mode="val", alternate=args.alternate)
+        collate = dataloader.collate_bytes
     if train_dataset is None:
-        assert args.dataset == "synthetic", "pass datasets to run() or use --dataset synthetic (loaders are out of scope)"
+        assert args.dataset == "synthetic", "--dataset: synthetic | DHF1KDataset (or pass datasets to run()); the other loaders are out of scope"
         train_dataset = SyntheticClips(args.synthetic_steps * args.batch_size, args.clip_size, args.height, args.width, args.use_sound)
         val_dataset = SyntheticClips(2 * world, args.clip_size, args.height, args.width, args.use_sound)
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True) if world > 1 else None
     train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=local_bs, shuffle=(sampler is None), sampler=sampler,
-                                               num_workers=args.no_workers, drop_last=True)
-    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=1, shuffle=False, num_workers=0)
+                                               num_workers=args.no_workers, drop_last=True, collate_fn=collate)
+    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=1, shuffle=False, num_workers=0, collate_fn=collate)
+    if collate is not None:
+        from . import dataloader
+        train_loader.device_batch = dataloader.DeviceBatch(device, "train")
+        val_loader.device_batch = dataloader.DeviceBatch(device, "val")
     params = [p for p in model.parameters() if p.requires_grad]
     optimizer = optim.Adam(params, lr=args.lr)
     parallel.broadcast_parameters(optimizer)
