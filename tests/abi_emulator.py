@@ -102,10 +102,12 @@ def _tile_m(dtype, mode, M, N, kchunks=0):
             break
     if dtype == F32:
         return 128
-    if nt == 4 and 0 < kchunks <= 32 and M >= (1 << 20):
+    if nt == 4 and 0 < kchunks <= 64 and M >= (1 << 20):
         return 128
     if nt == 6 and ((M + 255) // 256) * ((N + 95) // 96) < 64:
         nt = 8
+    if nt == 6 and N % 192 == 0 and ((M + 127) // 128) * (N // 192) >= 512:
+        return 128
     bm = 256
     if nt in (8, 4):
         bn = nt * 16

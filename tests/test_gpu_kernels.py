@@ -162,6 +162,30 @@ PP_CASES = [c for c in CONV_CASES if not c[7].get("pre")] + [
 ]
 
 
+# the 128 x 192 tile of conv_dma (waves 2 x 2) on shapes it is not normally chosen for: partial row tiles, pending BN + ReLU,
+# statistics, epilogues, sliced views, two column tiles (N = 384 pads to nothing here because 384 % 192 == 0)
+N192_CASES = [
+    ("n192_s", (2, 3, 10, 12), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(stats=True)),
+    ("n192_t_pre", (1, 5, 9, 10), 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(pre=True, stats=True, act=1)),
+    ("n192_pw_slices", (2, 2, 7, 9), 96, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(epi=True, act=1, in_ld=160, in_coff=32, out_ld=256, out_coff=32)),
+    ("n192_acc", (1, 4, 8, 8), 128, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(accumulate=True)),
+]
+
+
+@pytest.mark.parametrize("case", N192_CASES, ids=[c[0] for c in N192_CASES])
+def test_conv3d_n192_tile(case):
+    lib = _lib()
+    assert lib.vinet_set_option(b"n192_tile", 2) == 0 and lib.vinet_set_option(b"pp", 0) == 0
+    try:
+        d0 = _run_conv_case(case, E.BF16, forced=True)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_dma_kernel<4,6,2,2"), buf.value
+        assert lib.vinet_conv3d_tile_m(C.byref(d0)) == 128
+    finally:
+        lib.vinet_set_option(b"n192_tile", 1)
+        lib.vinet_set_option(b"pp", 1)
+
+
 @pytest.mark.parametrize("shape", [3, 4], ids=["bn256", "bn192"])
 @pytest.mark.parametrize("case", PP_CASES, ids=[c[0] for c in PP_CASES])
 def test_conv3d_pingpong(case, shape):

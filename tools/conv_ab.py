@@ -77,12 +77,14 @@ def main():
             variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), True))
         libs = []
     for ln, lib in libs:
-        variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=0, n64_tile=0), False))
-        variants.append((ln + ":pp192", lib, dict(dma=1, pp=4, tperm=0, n64_tile=0), False))
-        variants.append((ln + ":dma", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0), False))
-        variants.append((ln + ":dma-bm128", lib, dict(dma=1, pp=0, tperm=0, n64_tile=1), False))
-        variants.append((ln + ":dma-bm64", lib, dict(dma=1, pp=0, tperm=0, n64_tile=2), False))
-        variants.append((ln + ":dma+pre", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0), True))
+        variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=0, n64_tile=0, n192_tile=0), False))
+        variants.append((ln + ":pp192", lib, dict(dma=1, pp=4, tperm=0, n64_tile=0, n192_tile=0), False))
+        variants.append((ln + ":dma", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=0), False))
+        variants.append((ln + ":dma-n192", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=1), False))
+        variants.append((ln + ":dma-n192+pre", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=1), True))
+        variants.append((ln + ":dma-bm128", lib, dict(dma=1, pp=0, tperm=0, n64_tile=1, n192_tile=0), False))
+        variants.append((ln + ":dma-bm64", lib, dict(dma=1, pp=0, tperm=0, n64_tile=2, n192_tile=0), False))
+        variants.append((ln + ":dma+pre", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=0), True))
 
     print("%-26s" % "site" + "".join("%22s" % (v[0][-21:].replace("libvinet_hip", "")) for v in variants) + "   (ms | TF/s)")
     for (name, B, T, H, W, Cin, N, k, s, p) in SITES:

@@ -9,7 +9,7 @@
 int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s) {
   if (mode == VINET_CONV_STEM) return launch_conv_cfg<bf16_t, 4, 4, 4, 1, VINET_CONV_STEM>(a, s);
   CASE(4, 8, 4, 1) CASE(4, 6, 4, 1) CASE(4, 4, 4, 1) CASE(4, 3, 4, 1) CASE(4, 2, 4, 1) CASE(4, 1, 4, 1)
-  CASE(4, 4, 2, 2) CASE(4, 2, 2, 2) CASE(2, 4, 2, 2) CASE(2, 2, 2, 2)
+  CASE(4, 4, 2, 2) CASE(4, 2, 2, 2) CASE(2, 4, 2, 2) CASE(2, 2, 2, 2) CASE(4, 6, 2, 2)
   vinet_set_error("conv bf16: no kernel for tile MT=%d NT=%d WM=%d WN=%d", t.MT, t.NT, t.WM, t.WN);
   return -1;
 }
@@ -22,7 +22,7 @@ int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipSt
 // LDS-DMA pipelined kernel (conv_dma.h); a pending affine+ReLU is applied at fragment-read time
 int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t s) {
   DMA_CASE(4, 8, 4, 1) DMA_CASE(4, 6, 4, 1) DMA_CASE(4, 4, 4, 1) DMA_CASE(4, 3, 4, 1) DMA_CASE(4, 2, 4, 1) DMA_CASE(4, 1, 4, 1)
-  DMA_CASE(4, 4, 2, 2) DMA_CASE(4, 2, 2, 2) DMA_CASE(2, 4, 2, 2) DMA_CASE(2, 2, 2, 2)
+  DMA_CASE(4, 4, 2, 2) DMA_CASE(4, 2, 2, 2) DMA_CASE(2, 4, 2, 2) DMA_CASE(2, 2, 2, 2) DMA_CASE(4, 6, 2, 2)
   vinet_set_error("conv dma bf16: no kernel for tile MT=%d NT=%d WM=%d WN=%d", t.MT, t.NT, t.WM, t.WN);
   return -1;
 }

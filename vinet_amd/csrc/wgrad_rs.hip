@@ -377,7 +377,7 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   a.items = d->dy.B * a.To;
   a.dTo = make_fastdiv((uint32_t)a.To);
   const int groups = a.kT * a.cchunks * a.nchunks;
-  int workers = 256 / groups;       // one 512-thread workgroup per CU: never more than 256 in the grid (a second round would double the time)       // one 512-thread workgroup per CU
+  int workers = 256 / groups;       // one 512-thread workgroup per CU: never more than 256 in the grid (a second round would double the time)
   if (workers < 1) workers = 1;
   if (workers > a.items) workers = a.items;
   a.workers = workers;
