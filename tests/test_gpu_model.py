@@ -316,3 +316,49 @@ def test_train_driver_on_a_dhf1k_directory(tmp_path, capsys):
     sd = torch.load(ckpt, map_location="cpu")
     assert set(sd.keys()) == set(m.state_dict().keys())
     assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+
+
+def test_audio_visual_harness_with_avinet(tmp_path):
+    """generate_result_audio_visual.py's flow with the real AViNet (32 x 224 x 384 is fixed by the model): files for every
+    frame; a forward and a time-flipped call re-computed by hand (oracle excerpt, oracle post-processing)"""
+    import argparse
+    import wave
+    from PIL import Image
+    from oracle import postproc_cpu as P
+    from oracle import preproc_cpu as Q
+    from vinet_amd import generate_result_audio_visual as AV
+    from vinet_amd import model as VM
+    E.set_default_dtype("bf16")
+    m = VM.VideoAudioSaliencyModel(num_clips=32).eval()
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 5))
+    m = m.to(DEV)
+    rng = np.random.default_rng(8)
+    T, N, h, w, fps, Fs = 32, 63, 45, 80, 25, 22050
+    root = tmp_path / "data"
+    for d in ("fold_lists", "video_frames/DIEM/v1", "video_audio/DIEM/v1", "annotations/DIEM/v1/maps"):
+        os.makedirs(root / d)
+    (root / "fold_lists" / "DIEM_list_test_fps.txt").write_text("v1 %d %d\n" % (N, fps))
+    u8 = rng.integers(0, 256, (N, h, w, 3), dtype=np.uint8)
+    for i in range(N):
+        Image.fromarray(u8[i]).save(root / "video_frames" / "DIEM" / "v1" / ("%04d.png" % (i + 1)))
+        Image.fromarray(u8[i, :, :, 0]).save(root / "annotations" / "DIEM" / "v1" / "maps" / ("%04d.png" % (i + 1)))
+    pcm = rng.integers(-20000, 20000, int(Fs * N / fps), dtype=np.int16)
+    with wave.open(str(root / "video_audio" / "DIEM" / "v1" / "v1.wav"), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(Fs); f.writeframes(pcm.tobytes())
+    args = argparse.Namespace(path_indata=str(root), save_path=str(tmp_path / "out"), dataset="DIEM", split=1, start_idx=-1, num_parts=4,
+                              clip_size=T, use_sound=True, batch=2)
+    assert AV.validate(args, m, DEV) == N
+    x = torch.from_numpy(Q.frames_preprocess(u8)).to(DEV)
+    wav_s = (pcm.astype(np.float32) * np.float32(65536.0) * np.float32(2 ** -23)).astype(np.float32)
+    st, en = Q.audio_frame_bounds(N, float(fps), Fs, pcm.shape[0])
+    for (o, s0, flipped) in ((40, 9, False), (5, 5, True)):
+        idx = list(range(s0, s0 + T))
+        e_idx = en[-1] if s0 + T >= len(en) else en[s0 + T]
+        a = torch.from_numpy(Q.audio_excerpt(wav_s, st[s0 + 1], e_idx)).view(1, 1, -1, 1).to(DEV)
+        clip = x[idx[::-1] if flipped else idx].permute(1, 0, 2, 3)[None]
+        with torch.no_grad():
+            y = m(clip, torch.flip(a, [2]) if flipped else a).cpu().numpy()
+        want = P.normalize_u8(P.resize_blur(y, h, w))[0]
+        got = np.asarray(Image.open(tmp_path / "out" / "v1" / ("%04d.png" % (o + 1)))).astype(int)
+        # batch-2 calls in the harness vs batch 1 here: BN is in eval mode, so only bf16 accumulation order can differ
+        assert np.abs(got - want.astype(int)).max() <= 2, (o, np.abs(got - want.astype(int)).max())

@@ -239,3 +239,79 @@ def test_audio_feature_host_api():
     assert np.array_equal(f.view(-1).numpy(), Q.audio_excerpt(wav[0], starts[141], ends[-1]))
     assert float(PR.get_audio_feature("nope", data, 32, 0).abs().sum()) == 0.0
     assert PR.MAX_AUDIO_WIN == 70560
+
+
+def test_audio_visual_directory_harness(tmp_path):
+    """generate_result_audio_visual.py:115-192 on a synthetic DIEM-like tree: frames as PNG, 16-bit WAV, fold list; the
+    flipped clips must get the time-flipped excerpt"""
+    import argparse
+    import os
+    import wave
+    from PIL import Image
+    from oracle import postproc_cpu as P
+    from oracle import preproc_cpu as Q
+    from vinet_amd import generate_result as GR
+    from vinet_amd import generate_result_audio_visual as AV
+    rng = np.random.default_rng(21)
+    T, N, h, w, fps, Fs = 3, 7, 24, 36, 25, 8000
+    root = tmp_path / "data"
+    os.makedirs(root / "fold_lists")
+    os.makedirs(root / "video_frames" / "DIEM" / "clipA")
+    os.makedirs(root / "video_audio" / "DIEM" / "clipA")
+    os.makedirs(root / "annotations" / "DIEM" / "clipA" / "maps")
+    (root / "fold_lists" / "DIEM_list_test_fps.txt").write_text("clipA %d %d\n" % (N, fps))
+    u8 = rng.integers(0, 256, (N, h, w, 3), dtype=np.uint8)
+    for i in range(N):
+        Image.fromarray(u8[i]).save(root / "video_frames" / "DIEM" / "clipA" / ("img_%05d.png" % (i + 1)))
+        Image.fromarray(u8[i, :, :, 0]).save(root / "annotations" / "DIEM" / "clipA" / "maps" / ("eyeMap_%05d.png" % (i + 1)))
+    pcm = rng.integers(-20000, 20000, 4000, dtype=np.int16)
+    with wave.open(str(root / "video_audio" / "DIEM" / "clipA" / "clipA.wav"), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(Fs); f.writeframes(pcm.tobytes())
+    wav, fs = AV.load_wav(str(root / "video_audio" / "DIEM" / "clipA" / "clipA.wav"))
+    assert fs == Fs and wav.shape == (1, 4000) and np.array_equal(wav[0].numpy(), pcm.astype(np.float32) * 65536.0)
+
+    ramp = torch.linspace(-1.0, 1.0, 70560)
+
+    class FakeAV(torch.nn.Module):                    # the audio term is odd under a time flip of the excerpt
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, clips, audio):
+            assert audio.shape[1:] == (1, 70560, 1)
+            a = (audio.reshape(audio.shape[0], -1) * ramp).sum(1) * 1e-3
+            return torch.sigmoid(clips.mean((1, 2)) + clips[:, 0, -1] + a[:, None, None])
+
+    args = argparse.Namespace(path_indata=str(root), save_path=str(tmp_path / "out"), dataset="DIEM", split=1, start_idx=-1, num_parts=4,
+                              clip_size=T, use_sound=True, batch=2)
+    assert AV.validate(args, FakeAV(), torch.device("cpu")) == N
+    # the same thing by hand: oracle pre-processing, the reference's schedule call by call, oracle post-processing
+    x = torch.from_numpy(Q.frames_preprocess(u8))
+    wav_s = (pcm.astype(np.float32) * np.float32(65536.0) * np.float32(2 ** -23)).astype(np.float32)
+    st, en = Q.audio_frame_bounds(N, float(fps), Fs, 4000)
+    raw = np.zeros((N, 224, 384), np.float32)
+    m = FakeAV()
+    for (o, clip, flipped) in GR.sliding_window_schedule(N, T):
+        s0 = min(clip)
+        e_idx = en[-1] if s0 + T >= len(en) else en[s0 + T]
+        a = torch.from_numpy(Q.audio_excerpt(wav_s, st[s0 + 1], e_idx)).view(1, 1, -1, 1)
+        if flipped:
+            a = torch.flip(a, [2])
+        raw[o] = m(x[clip].permute(1, 0, 2, 3)[None], a)[0].detach().numpy()
+    want = P.normalize_u8(P.resize_blur(raw, h, w))
+    for i in range(N):
+        got = np.asarray(Image.open(tmp_path / "out" / "clipA" / ("img_%05d.png" % (i + 1))))
+        assert np.array_equal(got, want[i]), i
+    # without sound the visual harness is used as is
+    args.use_sound = False
+    args.save_path = str(tmp_path / "out2")
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, clips):
+            return torch.sigmoid(clips.mean((1, 2)))
+
+    assert AV.validate(args, Fake(), torch.device("cpu")) == N

@@ -8,6 +8,7 @@ static thread_local char g_err[512] = "";
 extern int g_vinet_opt_tperm;
 extern int g_vinet_opt_n64_tile;
 extern int g_vinet_opt_n192_tile;
+extern int g_vinet_opt_n64_kmax;
 
 void vinet_set_error(const char* fmt, ...) {
   va_list ap;
@@ -43,7 +44,7 @@ ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks) 
   // 10-20 M voxels) are prologue / epilogue bound: 128-row tiles put 4-6 workgroups on a CU instead of 2-3
   // (+5...17 % measured, tools/conv_ab.py; still +7 % at 54 K steps -- the data gradient of 64 -> 192 1x3x3 -- and
   // neutral at 270)
-  if (nt == 4 && kchunks > 0 && kchunks <= 64 && M >= (1L << 20)) return ConvTile{4, 2, 2, 2};
+  if (nt == 4 && kchunks > 0 && kchunks <= g_vinet_opt_n64_kmax && M >= (1L << 20)) return ConvTile{4, 2, 2, 2};
   // 192-wide tile (128 x 192, waves 2 x 2): one column tile covers N = 192, so x is staged once per row tile instead of
   // twice and the B rows need no padding to whole wave-instructions (96 -> 128): +7...10 % on the 192-channel layers
   // at 56 x 96 and 28 x 48 (tools/conv_ab.py, 64 clips)
@@ -147,6 +148,7 @@ extern int g_vinet_opt_splitk;
 int g_vinet_opt_n64_tile = 0;   // tuning: 64-wide layers on 128x64 (1) or 64x64 (2) tiles instead of 256x64
 int g_vinet_opt_pool_blk = 1;   // 1x3x3/s(1,2,2) max-pool backward per 2x2 input block
 int g_vinet_opt_up_blk = 1;     // 8-channel upsample kernels (forward per 2x2 output block)
+int g_vinet_opt_n64_kmax = 64;   // 64-wide outputs: 128-row tiles up to this many K steps of 32
 int g_vinet_opt_n192_tile = 1;   // 128 x 192 tiles (waves 2 x 2) for N % 192 == 0 instead of 256 x 96 (0 = off, 2 = also on small grids: tests)
 int g_vinet_opt_reduce_il = 1;  // channel reductions: blocks interleave rounds over one window (0 = one contiguous range per block)
 int g_vinet_opt_pool_pk = 1;    // bf16: packed 32-bit-key form of the LDS halo-tile pool (0 = the fp32-compare kernel)
@@ -164,6 +166,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
   if (name && !strcmp(name, "pool_blk")) { g_vinet_opt_pool_blk = value; return 0; }
   if (name && !strcmp(name, "up_blk")) { g_vinet_opt_up_blk = value; return 0; }
+  if (name && !strcmp(name, "n64_kmax")) { g_vinet_opt_n64_kmax = value; return 0; }
   if (name && !strcmp(name, "n192_tile")) { g_vinet_opt_n192_tile = value; return 0; }
   if (name && !strcmp(name, "reduce_il")) { g_vinet_opt_reduce_il = value; return 0; }
   if (name && !strcmp(name, "pool_pk")) { g_vinet_opt_pool_pk = value; return 0; }
