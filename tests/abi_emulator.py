@@ -108,6 +108,8 @@ def _tile_m(dtype, mode, M, N, kchunks=0):
         nt = 8
     if nt == 6 and N % 192 == 0 and ((M + 127) // 128) * (N // 192) >= 512:
         return 128
+    if nt == 8 and 0 < kchunks <= 20 and ((M + 127) // 128) * ((N + 127) // 128) >= 1024:
+        return 128
     bm = 256
     if nt in (8, 4):
         bn = nt * 16

@@ -25,6 +25,9 @@ SITES = [
     ("b1.3s 64->192 1x3x3", 8, 16, 56, 96, 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("b1.3t 192->192 3x1x1", 8, 16, 56, 96, 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     ("3c pw 256->128", 8, 16, 28, 48, 256, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("3c entry 256->288 pw", 8, 16, 28, 48, 256, 288, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("3c dg 288->256 pw", 8, 16, 28, 48, 288, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("4x entry 512->256 pw", 8, 8, 14, 24, 512, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("3c s 128->192 1x3x3", 8, 16, 28, 48, 128, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("4f pw 528->256", 8, 8, 14, 24, 528, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("5c s 192->384 1x3x3", 8, 4, 7, 12, 192, 384, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
@@ -77,14 +80,16 @@ def main():
             variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), True))
         libs = []
     for ln, lib in libs:
-        variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=0, n64_tile=0, n192_tile=0), False))
-        variants.append((ln + ":pp192", lib, dict(dma=1, pp=4, tperm=0, n64_tile=0, n192_tile=0), False))
-        variants.append((ln + ":dma", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=0), False))
-        variants.append((ln + ":dma-n192", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=1), False))
-        variants.append((ln + ":dma-n192+pre", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=1), True))
-        variants.append((ln + ":dma-bm128", lib, dict(dma=1, pp=0, tperm=0, n64_tile=1, n192_tile=0), False))
-        variants.append((ln + ":dma-bm64", lib, dict(dma=1, pp=0, tperm=0, n64_tile=2, n192_tile=0), False))
-        variants.append((ln + ":dma+pre", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=0), True))
+        variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=0, n64_tile=0, n192_tile=0, n128_tile=0), False))
+        variants.append((ln + ":pp192", lib, dict(dma=1, pp=4, tperm=0, n64_tile=0, n192_tile=0, n128_tile=0), False))
+        variants.append((ln + ":dma", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=0, n128_tile=0), False))
+        variants.append((ln + ":dma-n128a", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=1, n128_tile=1), False))
+        variants.append((ln + ":dma-n128b", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=1, n128_tile=2), False))
+        variants.append((ln + ":dma-n192", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=1, n128_tile=0), False))
+        variants.append((ln + ":dma-n192+pre", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=1, n128_tile=0), True))
+        variants.append((ln + ":dma-bm128", lib, dict(dma=1, pp=0, tperm=0, n64_tile=1, n192_tile=0, n128_tile=0), False))
+        variants.append((ln + ":dma-bm64", lib, dict(dma=1, pp=0, tperm=0, n64_tile=2, n192_tile=0, n128_tile=0), False))
+        variants.append((ln + ":dma+pre", lib, dict(dma=1, pp=0, tperm=0, n64_tile=0, n192_tile=0, n128_tile=0), True))
 
     print("%-26s" % "site" + "".join("%22s" % (v[0][-21:].replace("libvinet_hip", "")) for v in variants) + "   (ms | TF/s)")
     for (name, B, T, H, W, Cin, N, k, s, p) in SITES:

@@ -9,6 +9,8 @@ extern int g_vinet_opt_tperm;
 extern int g_vinet_opt_n64_tile;
 extern int g_vinet_opt_n192_tile;
 extern int g_vinet_opt_n64_kmax;
+extern int g_vinet_opt_n128_kmax;
+extern int g_vinet_opt_n128_tile;
 
 void vinet_set_error(const char* fmt, ...) {
   va_list ap;
@@ -53,6 +55,11 @@ ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks) 
   // the 96-wide shape has no small-M variants: a grid that covers under a quarter of the CUs (batch-1 decoder
   // convs) moves to the 128-wide family, which does
   if (nt == 6 && ((M + 255) / 256) * ((N + 95) / 96) < 64) nt = 8;
+  if (g_vinet_opt_n128_tile && nt == 8) return g_vinet_opt_n128_tile == 1 ? ConvTile{4, 4, 2, 2} : ConvTile{2, 4, 2, 2};   // tuning
+  // 128-wide outputs with a short K loop (the pointwise convs and their data gradients: 6-20 K steps) are prologue /
+  // epilogue bound like the 64-wide ones: 128 x 128 tiles put twice the workgroups on a CU (+13 % at 8-9 K steps, +5...10 % at
+  // 16-17, but -14 % at 54: tools/conv_ab.py)
+  if (nt == 8 && kchunks > 0 && kchunks <= g_vinet_opt_n128_kmax && ((M + 127) / 128) * ((N + 127) / 128) >= 1024) return ConvTile{4, 4, 2, 2};
   if (nt == 8 || nt == 4) {
     const int bn = nt * 16;
     const long tilesN = (N + bn - 1) / bn;
@@ -148,6 +155,8 @@ extern int g_vinet_opt_splitk;
 int g_vinet_opt_n64_tile = 0;   // tuning: 64-wide layers on 128x64 (1) or 64x64 (2) tiles instead of 256x64
 int g_vinet_opt_pool_blk = 1;   // 1x3x3/s(1,2,2) max-pool backward per 2x2 input block
 int g_vinet_opt_up_blk = 1;     // 8-channel upsample kernels (forward per 2x2 output block)
+int g_vinet_opt_n128_tile = 0;   // tuning: 128-wide layers on 128x128 (1) or 64x128 (2) tiles instead of 256x128
+int g_vinet_opt_n128_kmax = 20;  // 128-wide outputs: 128-row tiles up to this many K steps of 32 (0 = never)
 int g_vinet_opt_n64_kmax = 64;   // 64-wide outputs: 128-row tiles up to this many K steps of 32
 int g_vinet_opt_n192_tile = 1;   // 128 x 192 tiles (waves 2 x 2) for N % 192 == 0 instead of 256 x 96 (0 = off, 2 = also on small grids: tests)
 int g_vinet_opt_reduce_il = 1;  // channel reductions: blocks interleave rounds over one window (0 = one contiguous range per block)
@@ -166,6 +175,8 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
   if (name && !strcmp(name, "pool_blk")) { g_vinet_opt_pool_blk = value; return 0; }
   if (name && !strcmp(name, "up_blk")) { g_vinet_opt_up_blk = value; return 0; }
+  if (name && !strcmp(name, "n128_tile")) { g_vinet_opt_n128_tile = value; return 0; }
+  if (name && !strcmp(name, "n128_kmax")) { g_vinet_opt_n128_kmax = value; return 0; }
   if (name && !strcmp(name, "n64_kmax")) { g_vinet_opt_n64_kmax = value; return 0; }
   if (name && !strcmp(name, "n192_tile")) { g_vinet_opt_n192_tile = value; return 0; }
   if (name && !strcmp(name, "reduce_il")) { g_vinet_opt_reduce_il = value; return 0; }
