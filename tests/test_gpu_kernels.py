@@ -1306,3 +1306,22 @@ def test_audio_excerpt():
         assert np.abs(got - ref).max() <= 1e-9 + 2e-7 * np.abs(ref).max()
     with pytest.raises(Exception):
         PR.audio_excerpt(wd, 0, 80000)                   # longer than the window: the reference's assignment fails too
+
+
+def test_io_pipeline_kernels_match_committed_fixtures():
+    """the device pre- / post-processing against tests/golden/io_frames.npz (real Pillow outputs) and io_maps.npz"""
+    from tests import goldens as G
+    from vinet_amd import preprocess as PR
+    from vinet_amd import utils as U
+    z, meta = G.load("io_frames")
+    for name, (n, h, w, oh, ow) in meta["cases"].items():
+        got = PR.frames_to_tensor(torch.from_numpy(z[name + "_in"]).to(_dev()), (oh, ow)).cpu().numpy()
+        assert np.array_equal(got, z[name + "_out"]), name
+    gt = torch.from_numpy(z["gt_in"]).to(_dev())
+    assert np.array_equal(PR.gt_to_tensor(gt, meta["gt_train_size"]).cpu().numpy(), z["gt_train"])
+    assert np.array_equal(PR.gt_to_tensor(gt).cpu().numpy(), z["gt_val"])
+    m, _ = G.load("io_maps")
+    src = torch.from_numpy(m["src"]).to(_dev())
+    for name, size in {"up_45x80": (45, 80), "same": (28, 48), "down_9x13": (9, 13)}.items():
+        assert np.array_equal(U.resize_blur(src, size).cpu().numpy(), m[name + "_blur"]), name
+        assert np.array_equal(U.postprocess(src, size).cpu().numpy(), m[name + "_u8"]), name

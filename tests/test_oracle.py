@@ -229,3 +229,20 @@ def test_preproc_audio_excerpt_and_frame_bounds():
     assert list(st) == [0, 0, 441, 1323, 2205, 3087] and list(en) == [0, 441, 1323, 2205, 3087, 3969]
     st, en = Q.audio_frame_bounds(6, 25.0, 22050, 4000)
     assert en[6] == 4000
+
+
+def test_io_pipeline_oracle_matches_committed_fixtures():
+    """tests/golden/io_frames.npz holds outputs of the real Pillow resampler (+ ToTensor / Normalize); io_maps.npz regression
+    vectors of the post-processing restatement (tests/golden/make_io_goldens.py)"""
+    from oracle import postproc_cpu as P
+    from oracle import preproc_cpu as Q
+    z, meta = G.load("io_frames")
+    for name, (n, h, w, oh, ow) in meta["cases"].items():
+        assert np.array_equal(Q.pil_resize_bilinear(z[name + "_in"], oh, ow), z[name + "_resized"])
+        assert np.array_equal(Q.frames_preprocess(z[name + "_in"], oh, ow), z[name + "_out"])
+    assert np.array_equal(Q.gt_preprocess(z["gt_in"], *meta["gt_train_size"]), z["gt_train"])
+    assert np.array_equal(Q.gt_preprocess(z["gt_in"]), z["gt_val"])
+    m, _ = G.load("io_maps")
+    for name, (oh, ow) in {"up_45x80": (45, 80), "same": (28, 48), "down_9x13": (9, 13)}.items():
+        b = P.resize_blur(m["src"], oh, ow)
+        assert np.array_equal(b, m[name + "_blur"]) and np.array_equal(P.normalize_u8(b), m[name + "_u8"])
