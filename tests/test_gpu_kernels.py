@@ -694,6 +694,10 @@ WGRAD_RS_CASES = [
     ("rs_w48", (2, 4, 7, 48), 96, 128, (2, 3, 3), (2, 1, 1), (0, 1, 1), False),
     ("rs_w24", (1, 3, 14, 24), 160, 64, (3, 3, 3), (3, 1, 1), (0, 1, 1), False),
     ("rs_w24_h3", (2, 1, 3, 24), 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), False, dict(x_ld=96, x_coff=16)),
+    # rows of 128 / 160 / 192 positions (4 - 6 K steps, > 64 KB of LDS), a 32-channel output (64 -> 32 k2x3x3 of the decoder)
+    ("rs_w192_n32", (1, 4, 5, 192), 64, 32, (2, 3, 3), (2, 1, 1), (0, 1, 1), False),
+    ("rs_w128", (2, 1, 4, 128), 96, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+    ("rs_w160", (1, 3, 3, 160), 64, 72, (3, 3, 3), (3, 1, 1), (0, 1, 1), False),
 ]
 
 

@@ -123,6 +123,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rs_kernel(const WgradRsArgs
       const uint4 r1 = *(const uint4*)(x1 + (long)g_pos[PPT > 1 ? 1 : 0] * a.ldx * 2);
       if (p_ok[0]) *(uint4*)(ring + 1 * XROW + x_off[0]) = keep(r0, 1 < a.H && cx_ok);
       if (PPT > 1 && p_ok[PPT > 1 ? 1 : 0]) *(uint4*)(ring + 1 * XROW + x_off[PPT > 1 ? 1 : 0]) = keep(r1, 1 < a.H && cx_ok);
+      if (PPT > 2) {
+        const uint4 r2 = *(const uint4*)(x1 + (long)g_pos[PPT > 2 ? 2 : 0] * a.ldx * 2);
+        if (p_ok[PPT > 2 ? 2 : 0]) *(uint4*)(ring + 1 * XROW + x_off[PPT > 2 ? 2 : 0]) = keep(r2, 1 < a.H && cx_ok);
+      }
     }
     __syncthreads();
 
@@ -360,7 +364,7 @@ bool vinet_wgrad_use_rs(const VinetWgradDesc* d) {
   const int kT = d->ntaps / 9;
   const bool shape = d->ntaps % 9 == 0 && kT >= 1 && d->sT == kT && d->sH == 1 && d->sW == 1 && d->dy.C % 8 == 0 && d->x.C % 8 == 0 && d->Kp >= d->x.C &&
                      kT * ((d->x.C + 63) / 64) * ((d->dy.C + 63) / 64) <= 256 &&
-                     d->x.T == kT * d->dy.T && d->x.H == d->dy.H && d->x.W == d->dy.W && ((d->dy.W % 32 == 0 && d->dy.W <= 96) || d->dy.W == 48 || d->dy.W == 24) && d->dy.H >= 2 &&
+                     d->x.T == kT * d->dy.T && d->x.H == d->dy.H && d->x.W == d->dy.W && ((d->dy.W % 32 == 0 && d->dy.W <= 192) || d->dy.W == 48 || d->dy.W == 24) && d->dy.H >= 2 &&
                      d->x.ld % 8 == 0 && d->dy.ld % 8 == 0 && d->x.sB % 8 == 0 && d->dy.sB % 8 == 0 && ((uintptr_t)d->x.ptr % 16) == 0 &&
                      ((uintptr_t)d->dy.ptr % 16) == 0;
   if (!shape) return false;
@@ -386,6 +390,16 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   const int ringrows = multi ? 96 / a.W + 2 : 3;
   const int smem = ringrows * (a.W + 2) * 128 + 2 * ks * 32 * 128;
   auto launch = [&](auto kern) -> int {
+    if (smem > 64 * 1024) {                     // rows of 128 ... 192 positions: 82 ... 124 KB of ring + dy buffers
+      static bool attr_done[64] = {false};      // one per kernel instantiation (generic lambda)
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (!attr_done[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(wgrad_rs): %s", hipGetErrorString(e)); return (int)e; }
+        attr_done[dev & 63] = true;
+      }
+    }
     hipLaunchKernelGGL(kern, dim3(groups * workers), dim3(512), smem, s, a);
     return vn_launch_status("conv_wgrad_rs");
   };
@@ -393,5 +407,8 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   if (a.W == 24) return launch(conv_wgrad_rsm_kernel<3, 24>);
   if (ks == 1) return launch(conv_wgrad_rs_kernel<1>);
   if (ks == 2) return launch(conv_wgrad_rs_kernel<2>);
-  return launch(conv_wgrad_rs_kernel<3>);
+  if (ks == 3) return launch(conv_wgrad_rs_kernel<3>);
+  if (ks == 4) return launch(conv_wgrad_rs_kernel<4>);
+  if (ks == 5) return launch(conv_wgrad_rs_kernel<5>);
+  return launch(conv_wgrad_rs_kernel<6>);
 }
