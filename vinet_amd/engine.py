@@ -746,7 +746,7 @@ def _splitk_scratch(ctx, d):
 # Worth it when the conv does enough work per input element: N * taps above this threshold (0 = never).  Measured
 # on the whole step (128 clips): never 478 clips/s, 400: 483, 600: 491, 1000-1700: 491-493, 2500: 485 -- the 1x3x3
 # convs with >= 112 output channels pay, the 3x1x1 192->192 conv (576) does not.
-MATERIALIZE_NT = int(os.environ.get("VINET_MATERIALIZE_NT", "1000"))
+MATERIALIZE_NT = int(os.environ.get("VINET_MATERIALIZE_NT", "800"))
 
 
 def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n_pad=None):
