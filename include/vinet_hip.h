@@ -299,6 +299,12 @@ int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy, const uin
 int vinet_upsample2x(const VinetTensor* x, const VinetTensor* y, int32_t dtype, void* stream);
 int vinet_upsample2x_bwd(const VinetTensor* dy, const VinetTensor* dx, int32_t dtype, int32_t accumulate, void* stream);
 
+/* SoundNet's first conv (model.py:751: Conv2d(1, 16, (64,1), stride (2,1), padding (32,0))) as a pointwise conv over the
+ * unfolded waveform: y[b, m, 0, 0, c] = x[b, stride*m - pad + c, 0, 0, channel 0], zero outside; x = [B][L][1][1][C>=1],
+ * y = [B][(L + 2 pad - k)/stride + 1][1][1][k], k = y.C (a multiple of 8).  The conv's weight [N][1][k][1] is, flat, the
+ * pointwise weight [N][k]. */
+int vinet_unfold1d(const VinetTensor* x, const VinetTensor* y, int32_t dtype, int32_t stride, int32_t pad, void* stream);
+
 /* ------------------------------------------------------------------------
  * Losses (loss.py:13-99): per-sample reductions in fp64, maps fp32 (or fp64
  * ground truth).  `which`: 0 kldiv, 1 cc, 2 similarity, 3 nss (loss.py:101-120, the

@@ -533,6 +533,16 @@ class AbiEmulator:
         wr(dx, d.dtype, out, bool(accumulate))
         return 0
 
+    def vinet_unfold1d(self, x, y, dtype, stride, pad, stream):
+        x, y = _deref(x), _deref(y)
+        src = rd(x, dtype)[..., 0].reshape(x.B, x.T)                       # channel 0 of [B,T,1,1,C]
+        k = y.C
+        padded = np.zeros((x.B, x.T + 2 * pad), np.float32)
+        padded[:, pad:pad + x.T] = src
+        idx = np.arange(y.T)[:, None] * stride + np.arange(k)[None, :]
+        wr(y, dtype, padded[:, idx].reshape(y.B, y.T, 1, 1, k))
+        return 0
+
     def vinet_upsample2x(self, x, y, dtype, stream):
         x, y = _deref(x), _deref(y)
         xv = torch.from_numpy(np.ascontiguousarray(rd(x, dtype))).permute(0, 4, 1, 2, 3)

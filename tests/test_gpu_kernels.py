@@ -1329,3 +1329,23 @@ def test_io_pipeline_kernels_match_committed_fixtures():
     for name, size in {"up_45x80": (45, 80), "same": (28, 48), "down_9x13": (9, 13)}.items():
         assert np.array_equal(U.resize_blur(src, size).cpu().numpy(), m[name + "_blur"]), name
         assert np.array_equal(U.postprocess(src, size).cpu().numpy(), m[name + "_u8"]), name
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_unfold1d(dt):
+    """SoundNet conv1's im2col along the waveform: windows of k samples every `stride`, zero padding at both ends, channel 0
+    of a channel-padded input"""
+    B, L, Cpad, k, stride, pad = 3, 501, 8, 64, 2, 32
+    Lo = (L + 2 * pad - k) // stride + 1
+    xp, xmk = view_pair(B, L, 1, 1, Cpad, dt, "unf_x", 1)
+    yp, ymk = view_pair(B, Lo, 1, 1, k, dt, "unf_y", 2, ld=72, c_off=8)       # a channel slice of a wider buffer
+
+    def mk(side):
+        return [C.byref(xmk(side).ct()), C.byref(ymk(side).ct()), dt, stride, pad, _stream() if side == "gpu" else 0]
+
+    run_both("vinet_unfold1d", mk)
+    assert torch.equal(yp.get("gpu"), yp.get("cpu"))
+    lib = _lib()
+    bad = ymk("gpu").ct()
+    bad.T += 1
+    assert lib.vinet_unfold1d(C.byref(xmk("gpu").ct()), C.byref(bad), dt, stride, pad, _stream()) < 0

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vinet_maxpool3d": [_PP, _PT, CAffine, _PT, _vp, _vp],
     "vinet_maxpool3d_bwd": [_PP, _PT, _vp, _PT, _i32, _vp],
     "vinet_upsample2x": [_PT, _PT, _i32, _vp],
+    "vinet_unfold1d": [_PT, _PT, _i32, _i32, _i32, _vp],
     "vinet_upsample2x_bwd": [_PT, _PT, _i32, _i32, _vp],
     "vinet_loss_fwd": [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "vinet_loss_bwd": [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp],

@@ -1883,6 +1883,40 @@ __global__ __launch_bounds__(256) void upsample2x_blk8_kernel(TView x, TView y, 
     }
 }
 
+// ---- 1-D unfold (im2col along T) of a single-channel signal: SoundNet's first conv (model.py:751: Conv2d(1, 16, (64, 1),
+// stride 2, padding 32)) has one input channel and 64 taps -- as a (k,1,1) conv its K axis would be 64 taps x 32 padded
+// channels with one real column in 32.  Unfolded, y[b, m, c] = x[b, s*m - p + c, channel 0] (zero outside), it is a pointwise
+// conv with 64 input channels: 0.58 GB written once per step instead of a 32x padded K loop in forward and weight gradient.
+template <typename T>
+__global__ __launch_bounds__(256) void unfold1d_kernel(TView x, TView y, int stride, int pad, long total8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total8) return;
+  const int G = y.C >> 3;
+  const long row = i / G;                          // b * To + m
+  const int g = (int)(i - row * G);
+  const long b = row / y.T;
+  const int m = (int)(row - b * y.T);
+  const T* src = (const T*)x.p + b * x.sB;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const long pos = (long)m * stride - pad + g * 8 + e;
+    v[e] = (pos >= 0 && pos < x.T) ? load1<T>(src + pos * x.ld) : 0.f;
+  }
+  st8<T>((T*)y.p + b * y.sB + (long)m * y.ld + g * 8, v);
+}
+
+extern "C" int vinet_unfold1d(const VinetTensor* x, const VinetTensor* y, int32_t dtype, int32_t stride, int32_t pad, void* stream) {
+  VN_CHECK_ARG(x && y && (dtype == VINET_F32 || dtype == VINET_BF16) && x->ptr && y->ptr && x->B == y->B && x->H == 1 && x->W == 1 &&
+                   y->H == 1 && y->W == 1 && x->C >= 1 && y->C % 8 == 0 && y->ld % 8 == 0 && y->sB % 8 == 0 &&
+                   ((uintptr_t)y->ptr % 16) == 0 && stride >= 1 && pad >= 0 && y->T == (x->T + 2 * pad - y->C) / stride + 1,
+               "unfold1d: bad views");
+  const long total8 = (long)y->B * y->T * (y->C / 8);
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL(unfold1d_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, make_view(*x),
+                                          make_view(*y), stride, pad, total8);)
+  return vn_launch_status("unfold1d");
+}
+
 extern "C" int vinet_upsample2x(const VinetTensor* x, const VinetTensor* y, int32_t dtype, void* stream) {
   VN_CHECK_ARG(x && y && quad_ok(*x, esize(dtype)) && quad_ok(*y, esize(dtype)) && x->C == y->C && x->B == y->B &&
                    x->T == y->T && y->H == 2 * x->H && y->W == 2 * x->W, "upsample2x: bad views");

@@ -1080,6 +1080,19 @@ def upsample2x_forward(ctx, x, dst=None):
     return dst
 
 
+def unfold1d_forward(ctx, x, k, stride, pad):
+    """[B,L,1,1,C] signal (channel 0) -> [B,(L+2p-k)/s+1,1,1,k] windows (vinet_unfold1d): the input of SoundNet's first conv
+    as a pointwise conv.  The waveform needs no gradient, so there is no backward."""
+    assert x.plain and not x.needs_grad, "unfold1d: raw input signals only"
+    xv = x.v
+    assert xv.H == 1 and xv.W == 1
+    To = (xv.T + 2 * pad - k) // stride + 1
+    dst = Act(View.alloc(xv.B, To, 1, 1, k, xv.dt, xv.device))
+    ctx.call("vinet_unfold1d", C.byref(xv.ct()), C.byref(dst.v.ct()), xv.dt, stride, pad, ctx.stream)
+    dst.needs_grad = False
+    return dst
+
+
 # ----------------------------------------------------------------------------
 # autograd entry point: one node per root module call
 # ----------------------------------------------------------------------------

@@ -247,6 +247,14 @@ class _Conv2dPlan(E.ConvPlan):
     def __init__(self, conv):
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         super().__init__(conv.weight, conv.bias, (k, 1, 1), (s, 1, 1), (p, 0, 0))
+        # one input channel and many taps (SoundNet conv1: 1 -> 16, k = 64): run as a pointwise conv over the unfolded
+        # signal -- [N][1][k][1] is, flat, [N][k]: the taps become the input channels (engine.unfold1d_forward)
+        self.unfold = None
+        if conv.in_channels == 1 and k % 8 == 0 and k >= 16:
+            self.unfold = (k, s, p)
+            self.k, self.s, self.p = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+            self.Cin, self.ntaps = k, 1
+            self.temporal = False
 
 
 class SoundNet(nn.Module):
@@ -269,7 +277,10 @@ class SoundNet(nn.Module):
     def _fwd(self, ctx, x):
         for i, (_, _, _, _, pool) in enumerate(SOUNDNET_LAYERS, 1):
             conv, bn = getattr(self, "conv%d" % i), getattr(self, "batchnorm%d" % i)
-            x = E.conv_forward(ctx, conv.plan(), x, bn=bn.state(), act=L.ACT_RELU)
+            plan = conv.plan()
+            if plan.unfold is not None:
+                x = E.unfold1d_forward(ctx, x, *plan.unfold)
+            x = E.conv_forward(ctx, plan, x, bn=bn.state(), act=L.ACT_RELU)
             if ctx.training:
                 bn.note_training_step()
             if pool:
