@@ -25,6 +25,7 @@ SITES = [
     ("b1.3s 64->192 1x3x3", 8, 16, 56, 96, 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("b1.3t 192->192 3x1x1", 8, 16, 56, 96, 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     ("3c pw 256->128", 8, 16, 28, 48, 256, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("snd1 pw 64->16 (B x2)", 8, 35281, 1, 1, 64, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("3c entry 256->288 pw", 8, 16, 28, 48, 256, 288, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("3c dg 288->256 pw", 8, 16, 28, 48, 288, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("4x entry 512->256 pw", 8, 8, 14, 24, 512, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
@@ -65,6 +66,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--stats", action="store_true", help="forward convs also write BN statistics partials (training epilogue)")
+    ap.add_argument("--only", default="", help="substring filter on site names")
     args = ap.parse_args()
     libs = [(os.path.basename(p), bind(p)) for p in (args.lib or [L.LIB_PATH])]
     dev = torch.device("cuda:0")
@@ -93,6 +96,8 @@ def main():
 
     print("%-26s" % "site" + "".join("%22s" % (v[0][-21:].replace("libvinet_hip", "")) for v in variants) + "   (ms | TF/s)")
     for (name, B, T, H, W, Cin, N, k, s, p) in SITES:
+        if args.only and args.only not in name:
+            continue
         B = args.batch
         oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
         x = torch.randn(B * T * H * W * Cin, device=dev).bfloat16()
@@ -105,6 +110,7 @@ def main():
         sc, sh = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev)
         dw = torch.zeros(ntaps * N * Kp, device=dev)
         flops = 2.0 * B * oT * oH * oW * N * Cin * ntaps
+        stats = torch.zeros(((B * oT * oH * oW + 63) // 64) * 2 * N, device=dev)
 
         def desc(pre):
             d = L.CConvDesc()
@@ -117,6 +123,8 @@ def main():
             d.omT = d.omH = d.omW = 1
             d.ntaps, d.taps, d.w, d.Kp = ntaps, taps.data_ptr(), w.data_ptr(), Kp
             d.pre = L.CAffine(sc.data_ptr(), sh.data_ptr(), 1) if pre else L.CAffine(None, None, 0)
+            if args.stats:
+                d.stats = stats.data_ptr()
             return d
 
         def wdesc(pre):
