@@ -159,7 +159,7 @@ def build_parser():
     p.add_argument('--synthetic_frames', default=0, type=int, help="run the schedule on N synthetic 224x384 frames and report fps (no files)")
     p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
     p.add_argument('--batch', default=1, type=int)
-    p.add_argument('--graph', default=0, type=int, help="1 = replay a captured hipGraph per model call (+ post-processing)")
+    p.add_argument('--graph', default=1, type=int, help="1 (default) = replay a captured hipGraph per model call (+ post-processing); 0 = eager launches")
     p.add_argument('--image_size', default="360x640", type=str, help="synthetic mode: HxW of the source images the maps are resized to; 0 = keep the raw maps")
     return p
 
