@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
+    ap.add_argument("--batch", type=int, default=192, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
     ap.add_argument("--model", choices=["vinet", "avinet"], default="vinet",
                     help="avinet = BASELINE config 4: VideoAudioSaliencyModel with the SoundNet branch + bilinear fusion (32x224x384 only)")
     ap.add_argument("--clip", type=int, default=32)
@@ -281,7 +281,9 @@ def main():
                                       args.width, args.dtype, B,
                                       "1xMI355X" if world == 1 else "%dxMI355X RCCL all-reduce" % world),
                        "global_batch": world * B, "local_batch": B, "clip": [args.clip, args.height, args.width],
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                       "reserved_hbm_gb": round(torch.cuda.memory_reserved(dev) / 1e9, 1)},
             "roofline": roof,
             "whole_step": {
                 "hbm_frac_of_8TBs": per_gpu * (TRAIN_MB_PER_CLIP + STEP_MB_PER_GPU / B) * 1e6 / (HBM_PEAK_GBS * 1e9),
