@@ -15,54 +15,48 @@ from torch.utils.data import Dataset
 
 
 class DHF1KDataset(Dataset):
+    """`list_num_frame` keeps the reference's meaning: frame counts per video in train mode (one random clip per video
+    and epoch, dataloader.py:251-253,270-272), (video, first frame) pairs otherwise -- every 4*T-th start for "val"
+    (dataloader.py:254-258), every T-th start plus the clip that ends with the video for "save" (dataloader.py:259-264)."""
+
     def __init__(self, path_data, len_snippet, mode="train", multi_frame=0, alternate=1):
-        ''' mode: train, val, save '''
-        self.path_data = path_data
-        self.len_snippet = len_snippet
-        self.mode = mode
-        self.multi_frame = multi_frame
-        self.alternate = alternate
-        n_img = lambda v: len(os.listdir(os.path.join(path_data, v, 'images')))
-        if self.mode == "train":                                          # dataloader.py:251-253
-            self.video_names = os.listdir(path_data)
-            self.list_num_frame = [n_img(d) for d in self.video_names]
-        elif self.mode == "val":                                          # dataloader.py:254-258
-            self.list_num_frame = []
-            for v in os.listdir(path_data):
-                for i in range(0, n_img(v) - self.alternate * self.len_snippet, 4 * self.len_snippet):
-                    self.list_num_frame.append((v, i))
-        else:                                                             # dataloader.py:259-264
-            self.list_num_frame = []
-            for v in os.listdir(path_data):
-                for i in range(0, n_img(v) - self.alternate * self.len_snippet, self.len_snippet):
-                    self.list_num_frame.append((v, i))
-                self.list_num_frame.append((v, n_img(v) - self.len_snippet))
+        assert mode in ("train", "val", "save")
+        self.path_data, self.len_snippet, self.mode = path_data, len_snippet, mode
+        self.multi_frame, self.alternate = multi_frame, alternate
+        videos = os.listdir(path_data)
+        counts = {v: len(os.listdir(os.path.join(path_data, v, 'images'))) for v in videos}
+        span = alternate * len_snippet                       # frames a clip covers
+        if mode == "train":
+            self.video_names = videos
+            self.list_num_frame = [counts[v] for v in videos]
+            return
+        hop = 4 * len_snippet if mode == "val" else len_snippet
+        self.list_num_frame = []
+        for v in videos:
+            self.list_num_frame += [(v, first) for first in range(0, counts[v] - span, hop)]
+            if mode == "save":
+                self.list_num_frame.append((v, counts[v] - len_snippet))
 
     def __len__(self):
         return len(self.list_num_frame)
 
     def __getitem__(self, idx):
         from PIL import Image
-        if self.mode == "train":                                          # dataloader.py:270-272
-            file_name = self.video_names[idx]
-            start_idx = np.random.randint(0, self.list_num_frame[idx] - self.alternate * self.len_snippet + 1)
+        T, step = self.len_snippet, self.alternate
+        if self.mode == "train":
+            video = self.video_names[idx]
+            first = np.random.randint(0, self.list_num_frame[idx] - step * T + 1)       # dataloader.py:272
         else:
-            (file_name, start_idx) = self.list_num_frame[idx]
-        path_clip = os.path.join(self.path_data, file_name, 'images')
-        path_annt = os.path.join(self.path_data, file_name, 'maps')
-        frames, gts, sz = [], [], None
-        for i in range(self.len_snippet):
-            name = '%04d.png' % (start_idx + self.alternate * i + 1)
-            img = Image.open(os.path.join(path_clip, name)).convert('RGB')
-            sz = img.size
-            frames.append(np.asarray(img))
-            if self.mode != "save" and (self.multi_frame != 0 or i == self.len_snippet - 1):
-                gts.append(np.asarray(Image.open(os.path.join(path_annt, name)).convert('L')))
-        clip = torch.from_numpy(np.stack(frames))                         # [T,h,w,3] uint8
+            video, first = self.list_num_frame[idx]
+        names = ['%04d.png' % (first + step * i + 1) for i in range(T)]                   # 1-based file names
+        img_dir, map_dir = os.path.join(self.path_data, video, 'images'), os.path.join(self.path_data, video, 'maps')
+        imgs = [Image.open(os.path.join(img_dir, n)).convert('RGB') for n in names]
+        clip = torch.from_numpy(np.stack([np.asarray(im) for im in imgs]))                # [T,h,w,3] uint8
         if self.mode == "save":
-            return clip, start_idx, file_name, sz
-        gt = torch.from_numpy(np.stack(gts))                              # [1 or T,h,w] uint8
-        return clip, (gt[-1] if self.multi_frame == 0 else gt)
+            return clip, first, video, imgs[-1].size
+        wanted = names if self.multi_frame != 0 else names[-1:]                           # dataloader.py:306-308: last frame's map
+        gt = torch.from_numpy(np.stack([np.asarray(Image.open(os.path.join(map_dir, n)).convert('L')) for n in wanted]))
+        return clip, (gt if self.multi_frame != 0 else gt[0])
 
 
 def collate_bytes(samples):
