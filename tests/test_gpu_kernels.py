@@ -1349,3 +1349,18 @@ def test_unfold1d(dt):
     bad = ymk("gpu").ct()
     bad.T += 1
     assert lib.vinet_unfold1d(C.byref(xmk("gpu").ct()), C.byref(bad), dt, stride, pad, _stream()) < 0
+
+
+@pytest.mark.parametrize("cin", [8, 32, 64])
+def test_conv3d_wgrad_skinny(cin):
+    """pointwise weight gradient with a channel-padded 8-wide dy (the 32 -> 1 head): the reduction kernel, on views with
+    a channel offset and a voxel count that is not a multiple of anything"""
+    lib = _lib()
+    assert lib.vinet_set_option(b"wgrad_skinny", 2) == 0
+    try:
+        case = ("skinny%d" % cin, (2, 3, 7, 11), cin, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, dict(x_ld=cin + 16, x_coff=8, dy_ld=24, dy_coff=16))
+        d0 = _run_wgrad_case(case, E.BF16)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_wgrad_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value == b"wgrad_skinny_kernel"
+    finally:
+        lib.vinet_set_option(b"wgrad_skinny", 1)

@@ -21,6 +21,8 @@ bool vinet_wgrad_use_ts(const VinetWgradDesc* d);
 bool vinet_wgrad_use_hs(const VinetWgradDesc* d);
 bool vinet_wgrad_use_rs(const VinetWgradDesc* d);
 int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s);
+bool vinet_wgrad_use_skinny(const VinetWgradDesc* d);
+int vinet_launch_wgrad_skinny(const VinetWgradDesc* d, hipStream_t s);
 bool vinet_wgrad_use_tf(const VinetWgradDesc* d);
 int vinet_launch_wgrad_tf(const VinetWgradDesc* d, hipStream_t s);
 int vinet_launch_wgrad_hs(const VinetWgradDesc* d, hipStream_t s);
@@ -260,6 +262,7 @@ static bool wgrad_use_dma(const VinetWgradDesc* d) {
 
 extern "C" int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* d, char* buf, int32_t n) {
   if (!d || !buf || n <= 0) return -1;
+  if (vinet_wgrad_use_skinny(d)) { snprintf(buf, n, "wgrad_skinny_kernel"); return 0; }
   if (vinet_wgrad_use_rs(d)) { snprintf(buf, n, "conv_wgrad_rs_kernel<W%d>", d->dy.W); return 0; }
   if (vinet_wgrad_use_hs(d)) { snprintf(buf, n, d->bnb_z ? "conv_wgrad_hs_kernel<bn_bwd>" : "conv_wgrad_hs_kernel"); return 0; }
   if (vinet_wgrad_use_ts(d)) { snprintf(buf, n, "conv_wgrad_ts_kernel<%s>", d->pre.scale ? "pre" : "plain"); return 0; }
@@ -287,6 +290,7 @@ extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   if (d->mode == VINET_CONV_STEM) VN_CHECK_ARG(d->x.C == 4 && d->Kp == 32, "wgrad stem: x.C must be 4, Kp 32");
   else VN_CHECK_ARG(d->Kp >= d->x.C, "wgrad: Kp < Cin");
 
+  if (vinet_wgrad_use_skinny(d)) return vinet_launch_wgrad_skinny(d, (hipStream_t)stream);
   if (vinet_wgrad_use_rs(d)) return vinet_launch_wgrad_rs(d, (hipStream_t)stream);
   if (vinet_wgrad_use_hs(d)) return vinet_launch_wgrad_hs(d, (hipStream_t)stream);
   if (vinet_wgrad_use_ts(d)) return vinet_launch_wgrad_ts(d, (hipStream_t)stream);

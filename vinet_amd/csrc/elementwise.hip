@@ -1883,6 +1883,76 @@ __global__ __launch_bounds__(256) void upsample2x_blk8_kernel(TView x, TView y, 
     }
 }
 
+// ---- "skinny" weight gradient: a pointwise conv with at most 8 output channels (ViNet's 32 -> 1 head, model.py:279: the
+// channel-padded dy has 8 columns, 7 of them exactly zero) over tens of millions of voxels is a per-channel reduction, not a
+// GEMM: dw[n][c] = sum_v dy[v][n] * x[v][c].  The 64 x 64 MFMA tile spent 0.9 ms (0.8 TF/s) on it; here a lane owns 8 input
+// channels of a strided share of the voxels with an 8 x 8 block of fp32 accumulators, lanes of equal channel group meet by
+// wave shuffles, waves in LDS, and a workgroup adds its 8 x Cin block to dw with one atomic per element.
+__global__ __launch_bounds__(256) void wgrad_skinny_kernel(TView x, TView dy, long nvox, int Kp, float* __restrict__ dw) {
+  __shared__ float red[4][8][64];                  // [wave][group][n * 8 + e]
+  const int G = x.C >> 3;                          // 1, 2, 4 or 8 groups of 8 input channels
+  const int tid = threadIdx.x, g = tid % G, r = tid / G, R = 256 / G;
+  float acc[8][8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[n][e] = 0.f;
+  for (long v = (long)blockIdx.x * R + r; v < nvox; v += (long)gridDim.x * R) {
+    float xv[8], gv[8];
+    ld8<bf16_t>((const bf16_t*)x.p + vox_lin(x, v) + g * 8, xv);
+    ld8<bf16_t>((const bf16_t*)dy.p + vox_lin(dy, v), gv);
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[n][e] = fmaf(gv[n], xv[e], acc[n][e]);
+  }
+  // lanes g, g + G, g + 2G, ... of a wave hold the same channel group
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = acc[n][e];
+      for (int o = 32; o >= G; o >>= 1) a += __shfl_xor(a, o);
+      acc[n][e] = a;
+    }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < G) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][lane][n * 8 + e] = acc[n][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < G * 64; i += 256) {
+    const int gg = i >> 6, ne = i & 63, n = ne >> 3, e = ne & 7;
+    const float a = red[0][gg][ne] + red[1][gg][ne] + red[2][gg][ne] + red[3][gg][ne];
+    atomicAdd(dw + (long)n * Kp + gg * 8 + e, a);
+  }
+}
+
+int g_vinet_opt_wgrad_skinny = 1;   // 0 = off, 2 = every eligible shape (tests)
+
+bool vinet_wgrad_use_skinny(const VinetWgradDesc* d) {
+  if (!g_vinet_opt_wgrad_skinny || d->dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC || d->ntaps != 1 || d->pre.scale || d->pre.relu ||
+      d->bnb_z)
+    return false;
+  const int Cin = d->x.C;
+  const bool shape = d->dy.C == 8 && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) && d->Kp >= Cin && d->sT == 1 && d->sH == 1 && d->sW == 1 &&
+                     d->x.T == d->dy.T && d->x.H == d->dy.H && d->x.W == d->dy.W && oct_ok(d->x) && oct_ok(d->dy);
+  if (!shape) return false;
+  return g_vinet_opt_wgrad_skinny >= 2 || (long)d->dy.B * d->dy.T * d->dy.H * d->dy.W >= (1L << 20);
+}
+
+int vinet_launch_wgrad_skinny(const VinetWgradDesc* d, hipStream_t s) {
+  // taps: a pointwise conv has one tap, (0, 0, 0, slice 0) -- nothing to read from the device-side table
+  const long nvox = view_voxels(d->dy);
+  const int R = 256 / (d->x.C / 8);
+  long blocks = (nvox + R - 1) / R;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(wgrad_skinny_kernel, dim3((unsigned)blocks), dim3(256), 0, s, make_view(d->x), make_view(d->dy), nvox, d->Kp, d->dw);
+  return vn_launch_status("wgrad_skinny");
+}
+
 // ---- 1-D unfold (im2col along T) of a single-channel signal: SoundNet's first conv (model.py:751: Conv2d(1, 16, (64, 1),
 // stride 2, padding 32)) has one input channel and 64 taps -- as a (k,1,1) conv its K axis would be 64 taps x 32 padded
 // channels with one real column in 32.  Unfolded, y[b, m, c] = x[b, s*m - p + c, channel 0] (zero outside), it is a pointwise
