@@ -158,6 +158,12 @@ int g_vinet_opt_pool_blk = 1;   // 1x3x3/s(1,2,2) max-pool backward per 2x2 inpu
 int g_vinet_opt_up_blk = 1;     // 8-channel upsample kernels (forward per 2x2 output block)
 int g_vinet_opt_n128_tile = 0;   // tuning: 128-wide layers on 128x128 (1) or 64x128 (2) tiles instead of 256x128
 int g_vinet_opt_n128_kmax = 20;  // 128-wide outputs: 128-row tiles up to this many K steps of 32 (0 = never)
+// Workgroups (one 512-thread workgroup per CU, 62-124 KB of LDS each) that the persistent row- / frame-streaming weight-gradient
+// kernels may occupy.  They run on a second stream beside the BN-backward / data-gradient chain, which is the critical path: on
+// every CU they sit on, a conv_dma / conv_pp workgroup of the main stream finds LDS for one resident workgroup instead of
+// two.  Whole step at 192 clips, alternating runs on one box: 256 -> 543.4 clips/s, 128 -> 546.0, 96 -> 547.7, 64 -> 550.9,
+// 48 -> 522 (the weight-gradient stream becomes the critical path), 32 -> 422.  96 keeps a 2x margin to that cliff.
+int g_vinet_opt_wgrad_cus = 96;
 int g_vinet_opt_n64_kmax = 64;   // 64-wide outputs: 128-row tiles up to this many K steps of 32
 int g_vinet_opt_n192_tile = 1;   // 128 x 192 tiles (waves 2 x 2) for N % 192 == 0 instead of 256 x 96 (0 = off, 2 = also on small grids: tests)
 int g_vinet_opt_reduce_il = 1;  // channel reductions: blocks interleave rounds over one window (0 = one contiguous range per block)
@@ -178,6 +184,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "up_blk")) { g_vinet_opt_up_blk = value; return 0; }
   if (name && !strcmp(name, "n128_tile")) { g_vinet_opt_n128_tile = value; return 0; }
   if (name && !strcmp(name, "n128_kmax")) { g_vinet_opt_n128_kmax = value; return 0; }
+  if (name && !strcmp(name, "wgrad_cus")) { g_vinet_opt_wgrad_cus = value < 8 ? 8 : (value > 256 ? 256 : value); return 0; }
   if (name && !strcmp(name, "n64_kmax")) { g_vinet_opt_n64_kmax = value; return 0; }
   if (name && !strcmp(name, "n192_tile")) { g_vinet_opt_n192_tile = value; return 0; }
   if (name && !strcmp(name, "reduce_il")) { g_vinet_opt_reduce_il = value; return 0; }

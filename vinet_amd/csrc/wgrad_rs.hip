@@ -20,6 +20,7 @@
 //   * the grid is (kT x Cin/64) groups x workers; a worker keeps its accumulators over all its items and flushes
 //     once with fp32 atomics (dw is zero on entry).
 #include "common.h"
+extern int g_vinet_opt_wgrad_cus;
 
 struct WgradRsArgs {
   const char* x;
@@ -381,7 +382,7 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   a.items = d->dy.B * a.To;
   a.dTo = make_fastdiv((uint32_t)a.To);
   const int groups = a.kT * a.cchunks * a.nchunks;
-  int workers = 256 / groups;       // one 512-thread workgroup per CU: never more than 256 in the grid (a second round would double the time)
+  int workers = g_vinet_opt_wgrad_cus / groups;       // one 512-thread workgroup per CU, never a second round; the cap leaves CUs to the main stream (conv_api.hip: wgrad_cus)
   if (workers < 1) workers = 1;
   if (workers > a.items) workers = a.items;
   a.workers = workers;

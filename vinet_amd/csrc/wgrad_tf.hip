@@ -16,6 +16,7 @@
 //   * loads of frame t+1 are issued before the MFMAs of frame t (named registers, masked selects: wgrad_rs.hip);
 //   * grid = (channel chunks x output chunks) x workers, never more than one workgroup per CU; one atomic flush.
 #include "common.h"
+extern int g_vinet_opt_wgrad_cus;
 
 struct WgradTfArgs {
   const char* x;
@@ -229,7 +230,7 @@ int vinet_launch_wgrad_tf(const VinetWgradDesc* d, hipStream_t s) {
   a.items = d->dy.B * a.strips;
   a.dStrips = make_fastdiv((uint32_t)a.strips);
   const int groups = a.cchunks * a.nchunks;
-  int workers = 256 / groups;
+  int workers = g_vinet_opt_wgrad_cus / groups;
   if (workers < 1) workers = 1;
   if (workers > a.items) workers = a.items;
   a.workers = workers;
