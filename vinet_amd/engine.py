@@ -40,6 +40,10 @@ _WEIGHTS_EPOCH = 0
 ROW_ALIGN = int(os.environ.get("VINET_ROW_ALIGN", "0"))      # bytes; 0 = dense rows.  128 measured neutral on the whole step
 STEM_FOLD = os.environ.get("VINET_STEM_FOLD", "1") != "0"   # padded/folded stem input (A/B switch)
 WGRAD_SIDE_STREAM = True
+# CUs the persistent weight-gradient kernels may occupy while they run beside the main stream (conv_api.hip: wgrad_cus);
+# without a second stream they are alone on the GPU and get all of it
+WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "96"))
+_WGRAD_CUS_SET = {}
 _SIDE_STREAMS = {}
 
 
@@ -289,6 +293,10 @@ class Ctx:
 
     def run_backward(self):
         self.side_used = False
+        cus = WGRAD_CUS if self.side_stream() is not None else 256
+        if _WGRAD_CUS_SET.get("v") != cus:
+            self.lib.vinet_set_option(b"wgrad_cus", cus)
+            _WGRAD_CUS_SET["v"] = cus
         for fn in reversed(self.tape):
             fn()
         if getattr(self, "side_used", False):
