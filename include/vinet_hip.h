@@ -204,8 +204,10 @@ int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_t ntaps, in
  * caller's to zero): the 1x1x1 convs of an Inception block that share an input are packed side by side along K
  * so that their data gradients are ONE conv (model_utils.py:176-187). */
 int vinet_pack_weights_multi(const int64_t* table, int32_t njobs, int64_t total, int32_t dtype, void* stream);
-/* packed fp32 dw -> torch layout; grad (+)= dw. */
-int vinet_unpack_wgrad(const float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem, int32_t accumulate,
+/* packed fp32 dw -> torch layout; grad (+)= dw.  flags: bit 0 = accumulate into grad (else store), bit 1 = hand
+ * `dw` back ZEROED (rows [0,N) of every slice, padding columns included), so a caller-owned persistent workspace
+ * meets vinet_conv3d_wgrad's "zero on entry" contract at the next step without a fill launch. */
+int vinet_unpack_wgrad(float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem, int32_t flags,
                        float* grad, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -337,7 +337,9 @@ class AbiEmulator:
             Kp = (Cin + 31) // 32 * 32
             D = _f32(dw, ntaps * N * Kp).reshape(ntaps, N, Kp)   # rows beyond N (padded heads) are never read
             v = D[:, :N, :Cin].transpose(1, 2, 0)
-        g[...] = g + v if accumulate else v
+        g[...] = g + v if (accumulate & 1) else v
+        if accumulate & 2:      # hand the workspace back zeroed (rows [0, N) of every slice)
+            D[:, :N, :] = 0
         return 0
 
     # -- layout ----------------------------------------------------------------

@@ -172,28 +172,41 @@ extern "C" int vinet_pack_weights_multi(const int64_t* table, int32_t njobs, int
   return vn_launch_status("pack_weights_multi");
 }
 
-__global__ void unpack_wgrad_kernel(const float* __restrict__ dw, int N, int Cin, int ntaps, int stem, int Kp,
-                                    int accumulate, float* __restrict__ grad) {
+__global__ void unpack_wgrad_kernel(float* __restrict__ dw, int N, int Cin, int ntaps, int stem, int Kp,
+                                    int flags, float* __restrict__ grad) {
+  const int accumulate = flags & 1, clear = flags & 2;
   const long total = (long)N * Cin * ntaps;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i % ntaps);
     const int c = (int)((i / ntaps) % Cin);
     const int n = (int)(i / ((long)ntaps * Cin));
-    float v;
-    if (stem) { const int kh = t / 7, kw = t % 7; v = dw[((long)kh * N + n) * 32 + kw * 4 + c]; }
-    else v = dw[((long)t * N + n) * Kp + c];
+    long src;
+    if (stem) { const int kh = t / 7, kw = t % 7; src = ((long)kh * N + n) * 32 + kw * 4 + c; }
+    else src = ((long)t * N + n) * Kp + c;
+    const float v = dw[src];
     grad[i] = accumulate ? grad[i] + v : v;
+    if (clear) dw[src] = 0.f;      // every packed element is read by exactly one thread: hand the buffer back zeroed
+  }
+  if (clear) {
+    // columns no torch element maps to (channel padding; split-K atomics may have touched them)
+    const int nsl = stem ? 7 : ntaps, kp = stem ? 32 : Kp;
+    const long ptotal = (long)nsl * N * kp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ptotal; i += (long)gridDim.x * blockDim.x) {
+      const int col = (int)(i % kp);
+      const bool valid = stem ? (col < 28 && (col & 3) < Cin) : (col < Cin);
+      if (!valid) dw[i] = 0.f;
+    }
   }
 }
 
-extern "C" int vinet_unpack_wgrad(const float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem,
-                                  int32_t accumulate, float* grad, void* stream) {
+extern "C" int vinet_unpack_wgrad(float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem,
+                                  int32_t flags, float* grad, void* stream) {
   VN_CHECK_ARG(dw && grad && N > 0 && Cin > 0 && ntaps > 0, "unpack_wgrad: bad arguments");
   const int Kp = stem ? 32 : (Cin + 31) / 32 * 32;
   const long total = (long)N * Cin * ntaps;
   int grid = ew_grid(total); if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dw, N, Cin, ntaps, stem, Kp,
-                     accumulate, grad);
+                     flags, grad);
   return vn_launch_status("unpack_wgrad");
 }
 

@@ -96,6 +96,10 @@ PROFILER = None
 JOINT_ENTRY = int(os.environ.get("VINET_JOINT_ENTRY", "1"))
 # the stem's BN-backward apply pass folded into its weight-gradient kernel (0 = separate pass)
 BN_BWD_FUSE = int(os.environ.get("VINET_BN_BWD_FUSE", "1"))
+# weight gradients of the BN-free (decoder) convs wait on the side stream until the tape reaches the encoder (0 = launch in tape order)
+DEFER_DECODER_WGRAD = int(os.environ.get("VINET_DEFER_DECODER_WGRAD", "0"))
+# packed weight-gradient workspaces owned by the conv plans and re-zeroed by vinet_unpack_wgrad (0 = a torch.zeros per conv and step)
+PERSISTENT_DW = int(os.environ.get("VINET_PERSISTENT_DW", "1"))
 
 
 def set_profiler(p):
@@ -257,6 +261,8 @@ class Ctx:
         self.training = training
         self.tape = [] if record else None
         self.stream = _stream_for(device)
+        self._side_keep = []
+        self._deferred = []
 
     @property
     def recording(self):
@@ -291,17 +297,32 @@ class Ctx:
             st = _SIDE_STREAMS[self.device.index] = torch.cuda.Stream(self.device)
         return st
 
+    def keep(self, *tensors):
+        """hold tensors that a side-stream kernel reads or writes until run_backward has joined the streams: the caching
+        allocator would otherwise hand a block released by the main stream's Python frame to the next main-stream
+        allocation while the side kernel is still using it"""
+        self._side_keep.extend(t for t in tensors if t is not None)
+
+    def flush_deferred(self):
+        jobs, self._deferred = self._deferred, []
+        for job in jobs:
+            job()
+
     def run_backward(self):
         self.side_used = False
+        self._side_keep = []
+        self._deferred = []
         cus = WGRAD_CUS if self.side_stream() is not None else 256
         if _WGRAD_CUS_SET.get("v") != cus:
             self.lib.vinet_set_option(b"wgrad_cus", cus)
             _WGRAD_CUS_SET["v"] = cus
         for fn in reversed(self.tape):
             fn()
+        self.flush_deferred()
         if getattr(self, "side_used", False):
             # the optimizer (and every buffer release that follows) is ordered after the side stream
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream())
+        self._side_keep = []
         self.tape = []
 
 
@@ -444,6 +465,7 @@ class ConvPlan:
             assert self.k == (1, 7, 7) and self.Cin == 3 and self.p[2] == 3
         self._packs = {}
         self._taps = {}
+        self._dw_ws = {}
 
     # ---- geometry ---------------------------------------------------------
     def site(self, xv):
@@ -532,11 +554,23 @@ class ConvPlan:
     def wants_wgrad(self):
         return self.weight.requires_grad
 
-    def unpack_wgrad(self, ctx, dw):
-        """packed fp32 dw -> += .grad in torch layout"""
+    def unpack_wgrad(self, ctx, dw, clear=False):
+        """packed fp32 dw -> += .grad in torch layout (`clear`: the kernel hands dw back zeroed)"""
         gw = _param_grad(self.weight)
-        ctx.call("vinet_unpack_wgrad", dw.data_ptr(), self.N, self.Cin, self.ntaps, 1 if self.stem else 0, 1,
+        ctx.call("vinet_unpack_wgrad", dw.data_ptr(), self.N, self.Cin, self.ntaps, 1 if self.stem else 0, 3 if clear else 1,
                  gw.data_ptr(), ctx.stream)
+
+    def grad_targets(self):
+        return [self.weight]
+
+    def dw_workspace(self, ctx, numel):
+        """persistent packed fp32 weight-gradient workspace of this conv: zero-filled ONCE; vinet_unpack_wgrad hands it
+        back zeroed after every use (flag bit 1), so a training step issues no fill launch per conv."""
+        key = (str(ctx.device), numel)
+        ws = self._dw_ws.get(key)
+        if ws is None:
+            ws = self._dw_ws[key] = torch.zeros(numel, dtype=torch.float32, device=ctx.device)
+        return ws
 
     def pack_numel(self, transpose):
         if self.stem and not transpose:
@@ -571,7 +605,10 @@ class JointConvPlan(ConvPlan):
         self.k, self.s, self.p = (1, 1, 1), (1, 1, 1), (0, 0, 0)
         self.N, self.Cin, self.ntaps, self.stem = sum(m.N for m in members), m0.Cin, 1, False
         self.temporal = False
-        self._packs, self._taps = {}, {}
+        self._packs, self._taps, self._dw_ws = {}, {}, {}
+
+    def grad_targets(self):
+        return [m.weight for m in self.members]
 
     def _pack_stamp(self):
         return tuple(m._pack_stamp() for m in self.members)
@@ -611,11 +648,11 @@ class JointConvPlan(ConvPlan):
         self._keep_table = table       # the launch reads it asynchronously
         return self._packs[key][1]
 
-    def unpack_wgrad(self, ctx, dw):
+    def unpack_wgrad(self, ctx, dw, clear=False):
         kp = self.kp(False)
         for m, off in zip(self.members, self.offs):
             gw = _param_grad(m.weight)
-            ctx.call("vinet_unpack_wgrad", dw.data_ptr() + off * kp * 4, m.N, m.Cin, 1, 0, 1, gw.data_ptr(), ctx.stream)
+            ctx.call("vinet_unpack_wgrad", dw.data_ptr() + off * kp * 4, m.N, m.Cin, 1, 0, 3 if clear else 1, gw.data_ptr(), ctx.stream)
 
 
 class _PackRegistry:
@@ -957,33 +994,52 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         ctx.call("vinet_channel_sum", C.byref(dy.ct()), dy.dt, ws.data_ptr(), plan.N, gb.data_ptr(), 1, ctx.stream)
     # ---- weight gradient (side stream) ---------------------------------------------
     if plan.wants_wgrad():
-        side = ctx.side_stream()
-        main_ptr = ctx.stream
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream(ctx.device))   # dy (and everything before it) is ready
-            ctx.side_used = True
-        with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+        for w_ in plan.grad_targets():
+            _param_grad(w_)          # (allocated on the main stream, not inside the side-stream context)
+
+        def wgrad_job():
+            side = ctx.side_stream()
+            main_ptr = ctx.stream
             if side is not None:
-                ctx.stream = side.cuda_stream
-            try:
-                kp = plan.kp(False)
-                nsl = 7 if plan.stem else plan.ntaps
-                dw = ctx.f32(nsl * Ny * kp, zero=True)
-                wd = _wgrad_desc(ctx, plan, x, dy, dw)
-                if fused_bnb is not None:
-                    zv, zf, zm, zi, z1, z2 = fused_bnb
-                    wd.bnb_z, wd.bnb_ld, wd.bnb_sB, wd.bnb_fwd = zv.ptr(), zv.ld, zv.sB, zf
-                    wd.bnb_mean, wd.bnb_invstd, wd.bnb_c1, wd.bnb_c2 = zm.data_ptr(), zi.data_ptr(), z1.data_ptr(), z2.data_ptr()
-                es = ESIZE[ctx.dt]
-                ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
-                         tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
-                         work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
-                                   bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
-                if Ny != plan.N:
-                    assert plan.ntaps == 1, "channel-padded outputs are only supported for 1x1x1 convs"
-                plan.unpack_wgrad(ctx, dw)
-            finally:
-                ctx.stream = main_ptr
+                side.wait_stream(torch.cuda.current_stream(ctx.device))   # dy (and everything before it) is ready
+                ctx.side_used = True
+            with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+                if side is not None:
+                    ctx.stream = side.cuda_stream
+                try:
+                    kp = plan.kp(False)
+                    nsl = 7 if plan.stem else plan.ntaps
+                    # persistent workspace, handed back zeroed by the unpack kernel; a channel-padded head (rows past
+                    # plan.N are never unpacked) takes a fresh zero-filled one
+                    persistent = PERSISTENT_DW and Ny == plan.N
+                    dw = plan.dw_workspace(ctx, nsl * Ny * kp) if persistent else ctx.f32(nsl * Ny * kp, zero=True)
+                    wd = _wgrad_desc(ctx, plan, x, dy, dw)
+                    if fused_bnb is not None:
+                        zv, zf, zm, zi, z1, z2 = fused_bnb
+                        wd.bnb_z, wd.bnb_ld, wd.bnb_sB, wd.bnb_fwd = zv.ptr(), zv.ld, zv.sB, zf
+                        wd.bnb_mean, wd.bnb_invstd, wd.bnb_c1, wd.bnb_c2 = zm.data_ptr(), zi.data_ptr(), z1.data_ptr(), z2.data_ptr()
+                    es = ESIZE[ctx.dt]
+                    ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
+                             tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
+                             work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
+                                       bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
+                    if Ny != plan.N:
+                        assert plan.ntaps == 1, "channel-padded outputs are only supported for 1x1x1 convs"
+                    plan.unpack_wgrad(ctx, dw, clear=persistent)
+                    if side is not None:
+                        ctx.keep(dw, dy.buf, x.v.buf, x.scale, x.shift, *(fused_bnb[2:] if fused_bnb is not None else ()))
+                finally:
+                    ctx.stream = main_ptr
+
+        # The decoder's weight gradients (convs without BatchNorm: MFMA-bound, persistent, LDS-heavy) would run beside the
+        # decoder's data gradients, which are MFMA-bound too: both lose.  Deferred, they start when the tape reaches the
+        # encoder, whose BN-backward passes and pools are HBM-bound and share a CU with them at little cost.  dy and x
+        # stay untouched meanwhile: gradient buffers are written once per backward and live until the tape is dropped.
+        if DEFER_DECODER_WGRAD and bn is None and ctx.side_stream() is not None:
+            ctx._deferred.append(wgrad_job)
+        else:
+            ctx.flush_deferred()
+            wgrad_job()
     # ---- data gradient -------------------------------------------------------------
     if x.needs_grad:
         xv = x.v

@@ -160,6 +160,7 @@ def build_parser():
     p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
     p.add_argument('--batch', default=1, type=int)
     p.add_argument('--graph', default=1, type=int, help="1 (default) = replay a captured hipGraph per model call (+ post-processing); 0 = eager launches")
+    p.add_argument('--allow_synthetic_weights', default=0, type=int, help="1 = fall back to procedural weights when --file_weight is missing (implied by --synthetic_frames)")
     p.add_argument('--image_size', default="360x640", type=str, help="synthetic mode: HxW of the source images the maps are resized to; 0 = keep the raw maps")
     return p
 
@@ -176,9 +177,13 @@ def main(argv=None):
                                  use_upsample=bool(args.decoder_upsample), num_hier=args.num_hier, num_clips=args.clip_size)
     if os.path.isfile(args.file_weight):
         m.load_state_dict(torch.load(args.file_weight, map_location="cpu"))
-    else:
+    elif args.synthetic_frames > 0 or args.allow_synthetic_weights:
         print("weight file? using procedural weights")
         m.load_state_dict(synth.synth_state_dict(m.state_dict(), 0))
+    else:
+        # the reference's torch.load fails on a missing checkpoint (generate_result.py:35): never write result
+        # directories from random weights by accident
+        raise FileNotFoundError("--file_weight %r does not exist (pass --allow_synthetic_weights 1 to run on procedural weights)" % args.file_weight)
     m = m.to(dev).eval()
     if args.synthetic_frames <= 0:
         t0 = time.time()

@@ -170,6 +170,7 @@ def validate(args, model=None, device=None):
 def build_parser():
     p = argparse.ArgumentParser()
     p.add_argument('--file_weight', default="./saved_models/no_trans_upsampling_reduced.pt", type=str)
+    p.add_argument('--allow_synthetic_weights', default=0, type=int, help="1 = fall back to procedural weights when --file_weight is missing")
     p.add_argument('--nhead', default=4, type=int)
     p.add_argument('--num_encoder_layers', default=3, type=int)
     p.add_argument('--transformer_in_channel', default=512, type=int)
@@ -202,9 +203,12 @@ def main(argv=None):
     m = model.VideoAudioSaliencyModel(**kw) if args.use_sound else model.VideoSaliencyModel(**kw)
     if os.path.isfile(args.file_weight):
         m.load_state_dict(torch.load(args.file_weight, map_location="cpu"))
-    else:
+    elif args.allow_synthetic_weights:
         print("weight file? using procedural weights")
         m.load_state_dict(synth.synth_state_dict(m.state_dict(), 0))
+    else:
+        # torch.load of the reference fails on a missing checkpoint (generate_result_audio_visual.py:138)
+        raise FileNotFoundError("--file_weight %r does not exist (pass --allow_synthetic_weights 1 to run on procedural weights)" % args.file_weight)
     m = m.to(dev).eval()
     t0 = time.time()
     n = validate(args, m, dev)

@@ -17,6 +17,8 @@ class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         params = [p for p in params if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        assert len(self.param_groups) == 1, "vinet_amd.optim.Adam updates one flat buffer with one set of hyper-parameters: pass a single parameter group"
+
         self._flatten()
         self._step = 0
         self.grad_scale = 1.0   # e.g. 1/world_size after a SUM all-reduce
@@ -51,6 +53,25 @@ class Adam(torch.optim.Optimizer):
         for p, o in zip(self._params, self._offs):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+    # the moments and the step count live in flat buffers outside Optimizer.state: carry them through
+    # state_dict() / load_state_dict() so a resumed run keeps its moments and bias correction
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["vinet_flat"] = dict(m=self.flat_m.detach().cpu().clone(), v=self.flat_v.detach().cpu().clone(), step=self._step,
+                                numel=[p.numel() for p in self._params])
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        flat = state_dict.pop("vinet_flat", None)
+        super().load_state_dict(state_dict)
+        assert len(self.param_groups) == 1
+        if flat is not None:
+            assert flat["numel"] == [p.numel() for p in self._params], "optimizer state belongs to a different parameter list"
+            self.flat_m.copy_(flat["m"])
+            self.flat_v.copy_(flat["v"])
+            self._step = int(flat["step"])
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -77,6 +77,8 @@ def build_parser():
     p.add_argument('--synthetic_steps', default=20, type=int, help="steps per epoch with --dataset synthetic")
     p.add_argument('--height', default=224, type=int)
     p.add_argument('--width', default=384, type=int)
+    p.add_argument('--s3d_weight', default="./S3D_kinetics400.pt", type=str,
+                   help="S3D Kinetics-400 checkpoint the backbone starts from when sound is off (train.py:138-177 hard-codes this path)")
     return p
 
 
@@ -194,6 +196,15 @@ def run(args, train_dataset=None, val_dataset=None):
     np.random.seed(0)
     torch.manual_seed(0)
     model = build_model(args)
+    # train.py:138-177: without sound the backbone starts from the S3D Kinetics-400 checkpoint when the file is there
+    if not (args.use_sound or args.use_vox):
+        import os
+        s3d = getattr(args, "s3d_weight", "./S3D_kinetics400.pt")
+        if os.path.isfile(s3d):
+            print('loading weight file')
+            remap_s3d_kinetics(torch.load(s3d, map_location="cpu"), model.backbone)
+        else:
+            print('weight file?')
     if args.load_weight != "None":
         sd = torch.load(args.load_weight, map_location="cpu")
         (model.visual_model if (args.use_sound or args.use_vox) else model).load_state_dict(sd)
@@ -212,7 +223,7 @@ def run(args, train_dataset=None, val_dataset=None):
         val_dataset = SyntheticClips(2 * world, args.clip_size, args.height, args.width, args.use_sound)
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True) if world > 1 else None
     train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=local_bs, shuffle=(sampler is None), sampler=sampler,
-                                               num_workers=args.no_workers, drop_last=True, collate_fn=collate)
+                                               num_workers=args.no_workers, drop_last=(world > 1), collate_fn=collate)
     val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=1, shuffle=False, num_workers=0, collate_fn=collate)
     if collate is not None:
         from . import dataloader

@@ -38,7 +38,9 @@ def loss_func(pred_map, gt, args):
     """utils.py:22-39."""
     assert pred_map.size() == gt.size()
     if pred_map.dim() == 4:
-        assert pred_map.size(0) == args.batch_size
+        # (the reference asserts size(0) == args.batch_size, utils.py:26; under one process per GPU the tensor holds
+        #  this rank's shard of the global batch and the last batch of an epoch may be partial, so only the shape
+        #  agreement above is required)
         pred_map = pred_map.permute((1, 0, 2, 3))
         gt = gt.permute((1, 0, 2, 3))
         total = None
