@@ -157,6 +157,10 @@ DECODER_TAILS = {
     16: dict(k5=2, tail=[(32, 1, 1, True)]),
     8: dict(k5=1, tail=[(32, 1, 1, True)]),
     48: dict(k5=2, tail=[(32, 32, 3, True), "relu", (32, 1, 1, True)]),
+    # BUILD-DEFINED, NO REFERENCE PARITY (BASELINE config 5): the reference wires no decoder for 64-frame
+    # clips (model.py:91-99); this is DecoderConvUp (model.py:251-311) with its last temporal conv (2,1,1)/s2 widened
+    # to (4,1,1)/s4 so that T ends at 1.  Checked only HIP-vs-this-restatement; no golden from the reference exists.
+    64: dict(k5=2, tail=[(32, 32, 4, False), "relu", (32, 1, 1, True)]),
 }
 
 
@@ -209,6 +213,13 @@ class DecoderConvUp48(_DecoderConvUp):
         super().__init__(48)
 
 
+class DecoderConvUp64(_DecoderConvUp):
+    """build-defined 64-frame variant, no reference counterpart (see DECODER_TAILS[64])"""
+
+    def __init__(self):
+        super().__init__(64)
+
+
 class VideoSaliencyModel(nn.Module):
     """model.py:72-112 (use_upsample=True, num_hier=3 path only; the ablation
     decoders are out of scope)."""
@@ -216,10 +227,10 @@ class VideoSaliencyModel(nn.Module):
     def __init__(self, transformer_in_channel=32, nhead=4, use_upsample=True, num_hier=3, num_clips=32):
         super().__init__()
         if not use_upsample or num_hier != 3 or num_clips not in DECODER_TAILS:
-            raise NotImplementedError("only use_upsample=True, num_hier=3, num_clips in {8,16,32,48}")
+            raise NotImplementedError("only use_upsample=True, num_hier=3, num_clips in {8,16,32,48} (+ build-defined 64)")
         self.backbone = BackBoneS3D()
         self.num_hier = num_hier
-        self.decoder = {8: DecoderConvUp8, 16: DecoderConvUp16, 32: DecoderConvUp, 48: DecoderConvUp48}[num_clips]()
+        self.decoder = {8: DecoderConvUp8, 16: DecoderConvUp16, 32: DecoderConvUp, 48: DecoderConvUp48, 64: DecoderConvUp64}[num_clips]()
 
     def forward(self, x):
         y0, y1, y2, y3 = self.backbone(x)

@@ -179,12 +179,17 @@ def e2e_case(RM, clips, H, W, seed, out, tag):
     print("e2e", tag, "ok: range [%.4f, %.4f] std %.4f argmax %d gap %.3g" % (y_r.min(), y_r.max(), y_r.std(), idx, gap))
 
 
-def decoder_case(RM, seed, out):
-    """DecoderConvUp8 alone (T-concat seams, 5 upsamples) incl. input grads."""
+def decoder_case(RM, seed, out, clips=8):
+    """DecoderConvUp{8,16,48} alone (T-concat seams, 5 upsamples, the clip-length specific tail) incl. input and
+    parameter grads.  Encoder feature maps of a `clips`-frame clip: T = clips/8, /4, /2, /2 (model.py:690-743)."""
     meta = {}
-    ref, ora = RM.DecoderConvUp8(), O.DecoderConvUp8()
+    cls = {8: "DecoderConvUp8", 16: "DecoderConvUp16", 48: "DecoderConvUp48", 32: "DecoderConvUp"}[clips]
+    ref, ora = getattr(RM, cls)(), getattr(O, cls)()
     sd = synth.synth_state_dict(ref.state_dict(), seed)
-    shapes = [(1, 1024, 1, 3, 6), (1, 832, 2, 6, 12), (1, 480, 4, 12, 24), (1, 192, 4, 24, 48)]
+    t0 = clips // 8
+    hw = (3, 6) if clips == 8 else (2, 3)
+    shapes = [(1, 1024, t0, hw[0], hw[1]), (1, 832, 2 * t0, 2 * hw[0], 2 * hw[1]), (1, 480, 4 * t0, 4 * hw[0], 4 * hw[1]),
+              (1, 192, 4 * t0, 8 * hw[0], 8 * hw[1])]
     ys = [synth.normal("dec_y%d" % i, s, seed).abs() for i, s in enumerate(shapes)]
     # un-calibrated logits are far from 0; calibrate as for e2e
     box, h = _logits_hook(ref, ref)
@@ -192,8 +197,10 @@ def decoder_case(RM, seed, out):
     with torch.no_grad():
         ref(*ys)
     h.remove()
-    w, b = synth.calibrate_head(sd["convtsp4.6.weight"], sd["convtsp4.6.bias"], float(box["l"].mean()), float(box["l"].std()))
-    sd["convtsp4.6.weight"], sd["convtsp4.6.bias"] = w, b
+    last = max(int(k.split(".")[1]) for k in sd if k.startswith("convtsp4.") and k.endswith(".bias"))
+    wk, bk = "convtsp4.%d.weight" % last, "convtsp4.%d.bias" % last
+    w, b = synth.calibrate_head(sd[wk], sd[bk], float(box["l"].mean()), float(box["l"].std()))
+    sd[wk], sd[bk] = w, b
     res = {}
     outs = []
     for m in (ref, ora):
@@ -222,9 +229,49 @@ def decoder_case(RM, seed, out):
         res["gp_stats:" + k] = np.array([float(gd.sum()), float((gd * gd).sum())])
         res["gp_head:" + k] = _np(g.reshape(-1)[:2048])
     res["head_w"], res["head_b"] = _np(w), _np(b)
-    res["meta"] = np.array(json.dumps(dict(meta, seed=seed, shapes=[list(s) for s in shapes])))
-    np.savez_compressed(os.path.join(out, "decoder8.npz"), **res)
-    print("decoder8 ok")
+    res["meta"] = np.array(json.dumps(dict(meta, seed=seed, shapes=[list(s) for s in shapes], clips=clips, head_w_key=wk, head_b_key=bk)))
+    np.savez_compressed(os.path.join(out, "decoder%d.npz" % clips), **res)
+    print("decoder%d ok" % clips)
+
+
+class _Args:
+    """the loss flags of train.py:21-66 that utils.get_loss reads"""
+
+    def __init__(self, **kw):
+        self.kldiv, self.cc, self.sim, self.l1 = True, False, False, False
+        self.kldiv_coeff, self.cc_coeff, self.sim_coeff, self.l1_coeff = 1.0, -1.0, -1.0, 1.0
+        self.batch_size = 2
+        self.__dict__.update(kw)
+
+
+def loss_func_case(seed, out):
+    """utils.loss_func / get_loss (utils.py:9-39) of the REAL reference: the default flag set, kldiv + cc + sim with the
+    reference's default coefficients (train.py:36-37), non-default coefficients, and the 4-D multi-frame path
+    (utils.py:27-37).  The reference allocates its accumulator with `.cuda()`: for this capture
+    `Tensor.cuda` is the identity, nothing else is patched."""
+    import utils as RUt      # the reference's utils.py (stubs for cv2 / torchvision are on sys.path)
+    meta, res = {}, {}
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        combos = {"default": _Args(), "kl_cc_sim": _Args(cc=True, sim=True),
+                  "coeffs": _Args(cc=True, sim=True, kldiv_coeff=0.5, cc_coeff=-2.0, sim_coeff=-0.25), "cc_only": _Args(kldiv=False, cc=True)}
+        s3 = synth.uniform("lf_s3", (2, 40, 56), seed, 0.01, 0.99)
+        g3 = synth.gt_map(2, 40, 56, seed)
+        s4 = synth.uniform("lf_s4", (2, 3, 24, 40), seed, 0.01, 0.99)
+        g4 = synth.gt_map(6, 24, 40, seed + 1).reshape(2, 3, 24, 40)
+        for name, a in combos.items():
+            for tag, (s_, g_) in {"3d": (s3, g3), "4d": (s4, g4)}.items():
+                si = s_.clone().requires_grad_(True)
+                v = RUt.loss_func(si, g_, a)
+                v.sum().backward()
+                res["%s_%s" % (name, tag)] = _np(v.detach())
+                res["%s_%s_grad" % (name, tag)] = _np(si.grad)
+        res["meta"] = np.array(json.dumps(dict(meta, seed=seed, combos={k: {f: getattr(v, f) for f in ("kldiv", "cc", "sim", "kldiv_coeff", "cc_coeff", "sim_coeff")} for k, v in combos.items()})))
+    finally:
+        torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(out, "loss_func.npz"), **res)
+    print("loss_func ok", {k: float(v.reshape(-1)[0]) for k, v in res.items() if v.ndim <= 1 and k != "meta" and not k.endswith("grad")})
 
 
 def loss_case(RL, seed, out):
@@ -364,6 +411,13 @@ def main():
     if sys.argv[1:] == ["loss"]:        # regenerate one fixture
         loss_case(RL, 3, out)
         return
+    if sys.argv[1:] == ["round2"]:      # the fixtures added in round 2 (the others are left untouched)
+        loss_func_case(5, out)
+        decoder_case(RM, 22, out, clips=16)
+        decoder_case(RM, 23, out, clips=48)
+        e2e_case(RM, 16, 64, 96, 34, out, "16x64x96")
+        e2e_case(RM, 48, 64, 96, 35, out, "48x64x96")
+        return
     block_case("basic_16_32", lambda: RU.BasicConv3d(16, 32, 1, 1), lambda: O.BasicConv3d(16, 32, 1, 1), (2, 16, 4, 6, 8), 11, out)
     block_case("sep_16_32_k3", lambda: RU.SepConv3d(16, 32, 3, 1, 1), lambda: O.SepConv3d(16, 32, 3, 1, 1), (2, 16, 4, 6, 8), 12, out)
     block_case("sep_3_64_k7s2", lambda: RU.SepConv3d(3, 64, 7, 2, 3), lambda: O.SepConv3d(3, 64, 7, 2, 3), (1, 3, 8, 16, 24), 13, out)
@@ -375,6 +429,11 @@ def main():
     train_step_case(RM, RL, 41, out)
     e2e_case(RM, 32, 224, 384, 33, out, "32x224x384")
     avinet_case(RM, 51, out)
+    loss_func_case(5, out)
+    decoder_case(RM, 22, out, clips=16)
+    decoder_case(RM, 23, out, clips=48)
+    e2e_case(RM, 16, 64, 96, 34, out, "16x64x96")
+    e2e_case(RM, 48, 64, 96, 35, out, "48x64x96")
 
 
 if __name__ == "__main__":

@@ -28,6 +28,43 @@ def test_sliding_window_schedule_matches_generate_result():
     assert GR.sliding_window_schedule(2 * T - 2, T) == []               # "more frames are needed"
 
 
+def test_schedule_equals_trace_captured_from_the_reference_loop():
+    """tests/golden/harness_trace.json holds the ordered (video, saved frame, clip frame
+    indices) list the REFERENCE's generate_result.validate produced with a recording stub model
+    (tests/golden/make_trace_golden.py); our schedule + video selection must reproduce it call for call."""
+    import json
+    import os
+    from tests.goldens import GOLDEN_DIR
+    cases = json.load(open(os.path.join(GOLDEN_DIR, "harness_trace.json")))["cases"]
+    assert len(cases) >= 6 and any(c["T"] == 32 for c in cases)
+    for c in cases:
+        T = c["T"]
+        assert c["ctor"]["num_clips"] == T and c["ctor"]["use_upsample"] is True and c["ctor"]["num_hier"] == 3
+        names = ["%03d" % (v + 1) for v in range(c["n_videos"])]
+        a, b = 0, len(names)
+        if c["start_idx"] != -1:                      # generate_result.py:44-46
+            ln = (1.0 / float(c["num_parts"])) * len(names)
+            a, b = int((c["start_idx"] - 1) * ln), int(c["start_idx"] * ln)
+        want = []
+        for v, name in enumerate(names):
+            if not (a <= v < b):
+                continue
+            for out_frame, clip, flipped in GR.sliding_window_schedule(c["n_frames"] + v, T):
+                want.append([name, "%04d.png" % out_frame, clip])
+        assert want == c["calls"], (c["n_videos"], c["n_frames"], T)
+
+
+def test_list_videos_splits_like_the_reference(tmp_path):
+    """generate_result.py:40-46: sorted directories, part `start_idx` of `num_parts` (1-based), -1 = all"""
+    for n in ("b", "a", "d", "c", "e"):
+        (tmp_path / n).mkdir()
+    (tmp_path / "file.txt").write_text("x")
+    assert GR.list_videos(str(tmp_path), -1, 4) == ["a", "b", "c", "d", "e"]
+    for k in (1, 2, 3):
+        ln = 5 / 3.0
+        assert GR.list_videos(str(tmp_path), k, 3) == ["a", "b", "c", "d", "e"][int((k - 1) * ln):int(k * ln)]
+
+
 def test_s3d_kinetics_key_remap():
     from vinet_amd import model
     bb = model.BackBoneS3D()

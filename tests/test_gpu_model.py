@@ -61,12 +61,19 @@ def test_losses():
     MC.losses_case(DEV)
 
 
-def test_decoder8_fp32():
+@pytest.mark.parametrize("clips", [8, 16, 48])
+def test_decoders_fp32(clips):
+    """DecoderConvUp8 / 16 / 48 against the reference's output, input gradients and parameter gradients"""
     E.set_default_dtype("fp32")
-    MC.decoder8_case(DEV)
+    MC.decoder_case(clips, DEV)
 
 
-@pytest.mark.parametrize("tag", ["8x96x192", "8x128x192", "32x224x384"])
+def test_loss_func_against_reference():
+    """utils.loss_func / get_loss: flag and coefficient combinations, 3-D and 4-D (multi-frame) inputs"""
+    MC.loss_func_case(DEV)
+
+
+@pytest.mark.parametrize("tag", ["8x96x192", "8x128x192", "16x64x96", "48x64x96", "32x224x384"])
 def test_e2e_fp32_parity_gate(tag):
     """north_star: <= 1e-3 abs on the float map, bit-exact argmax (we hold 1e-4)."""
     E.set_default_dtype("fp32")
@@ -74,12 +81,15 @@ def test_e2e_fp32_parity_gate(tag):
     _note("e2e_fp32_" + tag, dict(max_abs=d, top2_gap=meta["top2_gap"]))
 
 
-@pytest.mark.parametrize("tag", ["8x96x192", "32x224x384"])
-def test_e2e_bf16_reported(tag):
-    """bf16 activations/weights through ~25 stacked convs: bounded, reported, not the 1e-3 gate."""
+@pytest.mark.parametrize("tag", ["8x96x192", "8x128x192", "16x64x96", "48x64x96", "32x224x384"])
+def test_e2e_bf16_gate(tag):
+    """The benchmarked (bf16) path: bf16 activations / weights through ~25 stacked convs cannot meet the fp32 gate of
+    1e-3, but it is GATED: max abs error <= 2.5e-2 on a map whose range is [0.002, 0.65], linear
+    correlation with the reference's map >= 0.999, and the reference's fixation inside the bf16 map's top 5 pixels.
+    Whether the bf16 argmax matched is written to the parity report."""
     E.set_default_dtype("bf16")
-    d, meta = MC.e2e_case(tag, DEV, tol=5e-2, argmax=False)
-    _note("e2e_bf16_" + tag, dict(max_abs=d, top2_gap=meta["top2_gap"]))
+    info = MC.e2e_bf16_case(tag, DEV, tol=2.5e-2, cc_min=0.999, topk=5)
+    _note("e2e_bf16_" + tag, info)
 
 
 def test_train_step_fp32():
@@ -169,7 +179,7 @@ def test_avinet_train_step_fp32():
         e = float((p.grad.cpu() - ref[k].grad).norm() / (ref[k].grad.norm() + 1e-30))
         grp = k.split(".")[0]
         worst[grp] = max(worst.get(grp, 0.0), e)
-        assert e < 0.25, "%s: relative gradient error %.3e" % (k, e)
+        assert e < 0.08, "%s: relative gradient error %.3e" % (k, e)
     assert "audionet" in worst and "bilinear" in worst
     _note("avinet_train_fp32", dict(worst_rel_grad_err=worst))
 

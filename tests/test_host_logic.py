@@ -65,6 +65,31 @@ def test_decoder8_forward_backward():
     MC.decoder8_case(CPU)
 
 
+@pytest.mark.parametrize("clips", [16, 48])
+def test_decoder16_48_forward_backward(clips):
+    """the clip-length specific decoder tails (model.py:339-346, 463-469; the 48-frame one has a biased (3,1,1) conv)"""
+    MC.decoder_case(clips, CPU)
+
+
+def test_loss_func_matches_reference_goldens():
+    MC.loss_func_case(CPU)
+
+
+def test_64_frame_model_ends_at_one_frame():
+    """BASELINE config 5 (build-defined tail): host logic against the labelled oracle restatement"""
+    from oracle import vinet_cpu as O
+    from vinet_amd import model as VM
+    from vinet_amd import synth
+    m = VM.VideoSaliencyModel(num_clips=64).eval()
+    o = O.VideoSaliencyModel(num_clips=64).eval()
+    sd = synth.synth_state_dict(o.state_dict(), 3)
+    m.load_state_dict(sd)
+    o.load_state_dict(sd)
+    x = synth.clip(1, 64, 32, 32, 3).permute(0, 2, 1, 3, 4)
+    with torch.no_grad():
+        MC.close(m(x), o(x), 2e-5, "64-frame map")
+
+
 @pytest.mark.slow
 def test_e2e_8x96x192_inference():
     MC.e2e_case("8x96x192", CPU)

@@ -66,9 +66,11 @@ def test_losses():
         assert abs(float(O.kldiv(s, g.double())) - float(z["%s_kldiv_gt64" % tag])) < 1e-12
 
 
-def test_decoder8():
-    z, meta = G.load("decoder8")
-    m = O.DecoderConvUp8()
+@pytest.mark.parametrize("clips", [8, 16, 48])
+def test_decoders(clips):
+    """DecoderConvUp8 / 16 / 48 (model.py:375-435, 313-373, 437-498) against the reference's outputs and gradients"""
+    z, meta = G.load("decoder%d" % clips)
+    m = {8: O.DecoderConvUp8, 16: O.DecoderConvUp16, 48: O.DecoderConvUp48}[clips]()
     sd = G.state_dict_for(m, meta["seed"], z, meta)
     m.load_state_dict(sd)
     ys = [synth.normal("dec_y%d" % i, tuple(s), meta["seed"]).abs().requires_grad_(True) for i, s in enumerate(meta["shapes"])]
@@ -82,7 +84,33 @@ def test_decoder8():
         _close(ys[i].grad.reshape(-1)[:4096], z["gy%d_head" % i])
 
 
-@pytest.mark.parametrize("tag", ["8x96x192", "8x128x192"])
+def test_loss_func_matches_reference():
+    """utils.loss_func / get_loss (utils.py:9-39): flag / coefficient combinations and the 4-D multi-frame path"""
+    from tests.golden_args import LossArgs
+    z, meta = G.load("loss_func")
+    s3 = synth.uniform("lf_s3", (2, 40, 56), meta["seed"], 0.01, 0.99)
+    g3 = synth.gt_map(2, 40, 56, meta["seed"])
+    s4 = synth.uniform("lf_s4", (2, 3, 24, 40), meta["seed"], 0.01, 0.99)
+    g4 = synth.gt_map(6, 24, 40, meta["seed"] + 1).reshape(2, 3, 24, 40)
+    for name, flags in meta["combos"].items():
+        for tag, (s_, g_) in {"3d": (s3, g3), "4d": (s4, g4)}.items():
+            si = s_.clone().requires_grad_(True)
+            v = O.loss_func(si, g_, LossArgs(**flags))
+            v.sum().backward()
+            _close(v.detach(), z["%s_%s" % (name, tag)])
+            _close(si.grad, z["%s_%s_grad" % (name, tag)])
+
+
+def test_64_frame_variant_is_labelled_build_defined():
+    """BASELINE config 5: no reference decoder exists for 64 frames; the restatement says so and ends at T = 1"""
+    assert "NO REFERENCE PARITY" in open(O.__file__).read()
+    m = O.VideoSaliencyModel(num_clips=64).eval()
+    with torch.no_grad():
+        y = m(synth.clip(1, 64, 32, 32, 1).permute(0, 2, 1, 3, 4))
+    assert y.shape == (1, 32, 32)
+
+
+@pytest.mark.parametrize("tag", ["8x96x192", "8x128x192", "16x64x96", "48x64x96"])
 def test_e2e_small(tag):
     z, meta = G.load("e2e_" + tag)
     m = O.VideoSaliencyModel(num_clips=meta["clips"]).eval()

@@ -67,6 +67,9 @@ DECODER_TAILS = {
     16: dict(k5=2, tail=[(32, 1, 1, True)]),
     8: dict(k5=1, tail=[(32, 1, 1, True)]),
     48: dict(k5=2, tail=[(32, 32, 3, True), "relu", (32, 1, 1, True)]),
+    # BUILD-DEFINED (BASELINE config 5 "long-clip 64x256x448"): the reference wires no decoder for 64 frames
+    # (model.py:91-99); DecoderConvUp with the last temporal conv (2,1,1)/s2 -> (4,1,1)/s4.  No reference parity.
+    64: dict(k5=2, tail=[(32, 32, 4, False), "relu", (32, 1, 1, True)]),
 }
 
 
@@ -145,6 +148,11 @@ class DecoderConvUp48(_DecoderConvUp):
     _clips = 48
 
 
+class DecoderConvUp64(_DecoderConvUp):
+    """build-defined 64-frame decoder (DECODER_TAILS[64]); the reference has none"""
+    _clips = 64
+
+
 class _MapBody:
     """root wrapper for callables that end in the decoder head: NCDHW fp32 inputs
     (video clip and/or feature maps, audio) -> saliency map [B,H,W] fp32."""
@@ -205,10 +213,10 @@ class VideoSaliencyModel(nn.Module):
     def __init__(self, transformer_in_channel=32, nhead=4, use_upsample=True, num_hier=3, num_clips=32):
         super().__init__()
         if not use_upsample or num_hier != 3 or num_clips not in DECODER_TAILS:
-            raise NotImplementedError("vinet_amd implements use_upsample=True, num_hier=3, num_clips in {8,16,32,48}")
+            raise NotImplementedError("vinet_amd implements use_upsample=True, num_hier=3, num_clips in {8,16,32,48} (+ the build-defined 64)")
         self.backbone = BackBoneS3D()
         self.num_hier = num_hier
-        self.decoder = {8: DecoderConvUp8, 16: DecoderConvUp16, 32: DecoderConvUp, 48: DecoderConvUp48}[num_clips]()
+        self.decoder = {8: DecoderConvUp8, 16: DecoderConvUp16, 32: DecoderConvUp, 48: DecoderConvUp48, 64: DecoderConvUp64}[num_clips]()
 
     def _fwd(self, ctx, x):
         y0, y1, y2, y3 = self.backbone._fwd(ctx, x)
