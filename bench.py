@@ -28,10 +28,11 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
-# algorithmic work per clip at 32x224x384 (training)
-TRAIN_GFLOP_PER_CLIP = 675.0
-TRAIN_MB_PER_CLIP = 3014.7
+# algorithmic work per clip (training): (clip, height, width) -> (GFLOP, MB); config 5 is the
+# build-defined 64-frame variant (no reference parity)
+TRAIN_WORK = {(32, 224, 384): (675.0, 3014.7), (64, 256, 448): (1800.0, 7994.0), (8, 128, 192): (48.1, 219.0), (8, 224, 384): (168.5, 767.0)}
 STEP_MB_PER_GPU = 1119.6
+SWEEP_BATCHES = (1, 2, 4, 8, 16, 32)
 
 
 def parse():
@@ -39,7 +40,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=192, help="clips per GPU per step (weak scaling; the reference default global batch is 8)")
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (weak scaling; the reference default global batch is 8); "
+                    "0 = 192 at 32x224x384, 64 at 64x256x448 (what fits 288 GB with margin)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the local-batch sweep {1,2,4,8,16,32} that the N = 1 training line carries (SURVEY.md 8(d))")
+    ap.add_argument("--sweep-steps", type=int, default=2)
     ap.add_argument("--model", choices=["vinet", "avinet"], default="vinet",
                     help="avinet = BASELINE config 4: VideoAudioSaliencyModel with the SoundNet branch + bilinear fusion (32x224x384 only)")
     ap.add_argument("--clip", type=int, default=32)
@@ -130,6 +134,8 @@ def main():
     engine.set_default_dtype(args.dtype)
     engine.WGRAD_SIDE_STREAM = not args.no_side_stream
 
+    if args.batch <= 0:
+        args.batch = 64 if (args.clip, args.height, args.width) == (64, 256, 448) else 192
     B = args.batch
     av = args.model == "avinet"
     assert not av or (args.clip, args.height, args.width) == (32, 224, 384), "AViNet's bilinear fusion fixes the clip shape"
@@ -148,13 +154,16 @@ def main():
         opt = optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
         parallel.broadcast_parameters(opt)
 
-        def step():
+        def train_step(ins, g_):
             opt.zero_grad()
-            l = loss.kldiv(m(*inputs), gt)
+            l = loss.kldiv(m(*ins), g_)
             l.backward()
             parallel.allreduce_gradients(opt)
             opt.step()
             return l
+
+        def step():
+            return train_step(inputs, gt)
     else:
         m.eval()
         if args.graph:
@@ -239,6 +248,24 @@ def main():
                    flops=sum((v["work"] or {}).get("flops", 0.0) * v["count"] for v in domtab.values()),
                    bytes=sum((v["work"] or {}).get("bytes", 0.0) * v["count"] for v in domtab.values()))
 
+    # ---- local-batch sweep of the same step ({1,2,4,8,16,32}), N = 1 training only
+    sweep = None
+    if world == 1 and args.mode == "train" and not args.no_sweep:
+        sweep = {}
+        for b in SWEEP_BATCHES:
+            if b >= B:
+                continue
+            xs = x[:b]
+            ins = (xs, inputs[1][:b]) if av else (xs,)
+            gs = gt[:b]
+            train_step(ins, gs)
+            torch.cuda.synchronize()
+            t0s = time.perf_counter()
+            for _ in range(args.sweep_steps):
+                train_step(ins, gs)
+            torch.cuda.synchronize()
+            sweep[str(b)] = b * args.sweep_steps / (time.perf_counter() - t0s)
+
     if rank == 0:
         clips = world * B * args.steps
         value = clips / elapsed
@@ -271,8 +298,24 @@ def main():
             roof["traffic_source"] = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes); (2*FETCH+WRITE)*1024 B, L2-miss traffic incl. Infinity-Cache hits"
             roof["mfma_busy_frac_pmc"] = pmc.get("mfma_busy_frac")
         per_gpu = value / world
+        work = TRAIN_WORK.get((args.clip, args.height, args.width)) if args.mode == "train" else None
+        whole = None
+        if work is not None:
+            # the headline is the HBM fraction of the WHOLE path (the net's arithmetic intensity, 215 flop/B,
+            # is under the 312 flop/B ridge); the MFMA fraction is quoted beside it
+            gb_s = per_gpu * (work[1] + STEP_MB_PER_GPU / B) / 1e3
+            whole = dict(bound="hbm", achieved=gb_s, peak=HBM_PEAK_GBS, unit="GB/s", frac=gb_s / HBM_PEAK_GBS,
+                         mfma_achieved_tflops=per_gpu * work[0] / 1e3, mfma_frac=per_gpu * work[0] / 1e3 / MFMA_BF16_PEAK_TF,
+                         algorithmic_mb_per_clip=work[1], algorithmic_gflop_per_clip=work[0], per_step_mb=STEP_MB_PER_GPU,
+                         traffic=None)
+            try:   # L2-miss bytes of ONE step summed over every kernel, from the committed PMC passes of this command
+                if pj.get("step_traffic_bytes") and B == pj.get("batch", 32):
+                    whole["traffic"] = pj["step_traffic_bytes"]
+            except NameError:
+                pass
+        roof["whole_step"] = whole
         out = {
-            "metric": "clips/sec training (32x224x384 bf16)" if args.mode == "train" else "inference clips/sec (one output frame per clip)",
+            "metric": ("clips/sec training (%dx%dx%d %s)" % (args.clip, args.height, args.width, args.dtype)) if args.mode == "train" else "inference clips/sec (one output frame per clip)",
             "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -285,11 +328,11 @@ def main():
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                        "reserved_hbm_gb": round(torch.cuda.memory_reserved(dev) / 1e9, 1)},
             "roofline": roof,
-            "whole_step": {
-                "hbm_frac_of_8TBs": per_gpu * (TRAIN_MB_PER_CLIP + STEP_MB_PER_GPU / B) * 1e6 / (HBM_PEAK_GBS * 1e9),
-                "mfma_frac_of_2.5PF": per_gpu * TRAIN_GFLOP_PER_CLIP * 1e9 / (MFMA_BF16_PEAK_TF * 1e12),
-            } if (args.mode == "train" and (args.clip, args.height, args.width) == (32, 224, 384)) else None,
+            "whole_step": None if whole is None else {"hbm_frac_of_8TBs": whole["frac"], "mfma_frac_of_2.5PF": whole["mfma_frac"]},
         }
+        if sweep is not None:
+            sweep[str(B)] = value
+            out["sweep"] = dict(unit="clips/s", steps_each=args.sweep_steps, local_batch=sweep)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

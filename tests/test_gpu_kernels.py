@@ -32,7 +32,31 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- exact-arithmetic mode -----------------------------------------------------------------------------------------
+# Inside `exact_mode()` every tensor the case runners draw holds SMALL INTEGERS (activations, gradients and weights in
+# [-2, 2]; pending-affine / epilogue scales in {1, 2}, shifts in {-1, 0, 1}): exactly representable in bf16, every product
+# and every partial sum (|.| <= 4 K <= 2^17) exact in fp32 in ANY summation order, the bf16 rounding of the exact result
+# unique.  The kernels must then equal the ABI model BIT FOR BIT: a wrong tap, pad, stride phase, swizzle or a dropped
+# K tile cannot hide under a 2e-2 tolerance.  (Per-tile sums of squares are not exact: statistics keep their tolerance.)
+_EXACT = [False]
+
+
+class exact_mode:
+    def __enter__(self):
+        _EXACT[0] = True
+
+    def __exit__(self, *a):
+        _EXACT[0] = False
+        return False
+
+
+def _ints(name, shape, seed, lo, hi):
+    return torch.floor(synth.uniform(name, tuple(shape), seed, float(lo), float(hi) + 1.0)).clamp_(lo, hi)
+
+
 def _rand(name, shape, seed=0, scale=1.0):
+    if _EXACT[0]:
+        return _ints(name, shape, seed, -2, 2)
     return synth.normal(name, shape, seed) * scale
 
 
@@ -67,11 +91,20 @@ def view_pair(B, T, H, W, Cc, dt, name, seed=0, ld=None, c_off=0, t_total=None, 
 
 
 def fvec(name, n, seed=0, lo=None, hi=None):
+    if _EXACT[0]:
+        return Pair((_ints(name, (n,), seed, -1, 1) if lo is None else _ints(name, (n,), seed, 1, 2)).float())
     t = _rand(name, (n,), seed) if lo is None else synth.uniform(name, (n,), seed, lo, hi)
     return Pair(t.float())
 
 
 def _cmp(a, b, tol, what=""):
+    if _EXACT[0] and "stats" not in what:
+        assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+        if not torch.equal(a, b):
+            bad = (a.float() != b.float()).nonzero()
+            raise AssertionError("%s: NOT bit-identical on exact-arithmetic inputs: %d of %d elements differ, first at %s (got %s, expected %s)"
+                                 % (what, bad.shape[0], a.numel(), bad[0].tolist(), a.float()[tuple(bad[0])].item(), b.float()[tuple(bad[0])].item()))
+        return
     a, b = a.float(), b.float()
     scale = max(1.0, float(b.abs().max()))
     d = float((a - b).abs().max())
@@ -1364,3 +1397,54 @@ def test_conv3d_wgrad_skinny(cin):
         assert lib.vinet_conv3d_wgrad_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value == b"wgrad_skinny_kernel"
     finally:
         lib.vinet_set_option(b"wgrad_skinny", 1)
+
+
+# ---- exact arithmetic: every conv / weight-gradient kernel variant bit-identical with the ABI model ------------------
+def _exact_targets():
+    t = []
+    for c in CONV_CASES:
+        if c[7].get("act") != 2:                       # (a sigmoid is not exact)
+            t.append(("conv3d-" + c[0], test_conv3d, dict(case=c, dt=E.BF16)))
+    for shape in (3, 4):
+        for c in PP_CASES:
+            if c[7].get("act") != 2:
+                t.append(("pingpong%d-%s" % (shape, c[0]), test_conv3d_pingpong, dict(case=c, shape=shape)))
+    for c in N192_CASES:
+        t.append(("n192-" + c[0], test_conv3d_n192_tile, dict(case=c)))
+    for c in CONV_TS_CASES:
+        t.append(("tstream-" + c[0], test_conv3d_tstream, dict(case=c)))
+    for ksp in [(7, 2, 3), (3, 2, 1), (5, 3, 2)]:
+        for acc in (0, 1):
+            t.append(("tsd-k%ds%dp%d-acc%d" % (ksp + (acc,)), test_conv3d_tstream_dgrad_fused, dict(ksp=ksp, acc=acc)))
+    for r in (0, 1):
+        t.append(("ts-phase%d" % r, test_conv3d_tstream_dgrad_phase, dict(r=r)))
+    t.append(("stem-mode", test_conv3d_stem_mode, dict(dt=E.BF16)))
+    for hw in [(18, 22), (17, 23), (20, 128)]:
+        t.append(("stem-folded-%dx%d" % hw, test_stem_folded, dict(dt=E.BF16, hw=hw)))
+    for c in WGRAD_CASES:
+        t.append(("wgrad-" + c[0], test_conv3d_wgrad, dict(case=c, dt=E.BF16)))
+    for shape in (3, 4):
+        for c in WGRAD_PP_CASES:
+            t.append(("wgrad-pp%d-%s" % (shape, c[0]), test_conv3d_wgrad_pingpong, dict(case=c, shape=shape)))
+    for c in WGRAD_TS_CASES:
+        t.append(("wgrad-ts-" + c[0], test_conv3d_wgrad_tstream, dict(case=c)))
+    for c in WGRAD_RS_CASES:
+        t.append(("wgrad-rs-" + c[0], test_conv3d_wgrad_rowstream, dict(case=c)))
+    for c in WGRAD_TF_CASES:
+        t.append(("wgrad-tf-" + c[0], test_conv3d_wgrad_tframes, dict(case=c)))
+    t.append(("wgrad-stem", test_conv3d_wgrad_stem, dict(dt=E.BF16)))
+    for cin in (32, 64):
+        t.append(("wgrad-skinny-%d" % cin, test_conv3d_wgrad_skinny, dict(cin=cin)))
+    return t
+
+
+_EXACT_TARGETS = _exact_targets()
+
+
+@pytest.mark.parametrize("target", _EXACT_TARGETS, ids=[t[0] for t in _EXACT_TARGETS])
+def test_exact_arithmetic_bit_identity(target):
+    """small-integer bf16 inputs through every conv and weight-gradient kernel variant on the existing case tables:
+    the result must equal the ABI model bit for bit (see exact_mode above)"""
+    _, fn, kw = target
+    with exact_mode():
+        fn(**kw)

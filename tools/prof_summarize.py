@@ -68,6 +68,14 @@ for r in rows:
     if m:
         k = "conv_wgrad_dma_kernel<%s,%s,%s,%s>" % (m[1], m[2], m[3], m[5])
     short[k] = dict(traffic_bytes_per_launch=r["traffic_bytes_per_launch"], mfma_busy_frac=r["mfma_busy_frac"], avg_us=r["avg_us"])
-json.dump(dict(source="profiles/%s_pmc_summary.json" % tag, batch=batch, kernels=short), open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+# L2-miss bytes of ONE step over every kernel (the PMC passes profile 1 warm-up + 1 timed step: half of the total)
+def _tot(agg, name):
+    return sum(v[name][0] for v in agg.values() if name in v)
+
+
+step_traffic = int((2 * _tot(fe, "FETCH_SIZE") + _tot(wr, "WRITE_SIZE")) * 1024 / 2)
+json.dump(dict(source="profiles/%s_pmc_summary.json" % tag, batch=batch, step_traffic_bytes=step_traffic, kernels=short),
+          open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print("step traffic %.1f GB" % (step_traffic / 1e9))
 for r in rows[:14]:
     print("%-72s %5.1f%% %9.1f us  traffic %8.1f MB  mfma busy %s" % (r["kernel"][:72], r["pct_of_gpu_time"], r["avg_us"], r["traffic_bytes_per_launch"] / 1e6, r["mfma_busy_frac"]))
