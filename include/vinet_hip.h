@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 8
+#define VINET_ABI_VERSION 9
 
 enum { VINET_F32 = 0, VINET_BF16 = 1 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
@@ -82,7 +82,7 @@ typedef struct VinetAffine {
  *    materialised as a copy).
  *  - `stats` (optional): per-M-tile partial sums of the pre-activation values,
  *    layout [tilesM][2][N] fp32 (sum, sum of squares), tilesM =
- *    ceil(M / vinet_conv3d_tile_m(desc)); reduced by vinet_bn_finalize.
+ *    vinet_conv3d_stats_rows(desc); reduced by vinet_bn_finalize.
  *  - mode VINET_CONV_STEM: x has C == 4 (3 + zero pad), taps index kernel
  *    rows only and each K chunk of 32 is 8 consecutive W positions x 4
  *    channels (the 1x7x7 stride-2 stem, model.py:693 / model_utils.py:144).
@@ -122,7 +122,12 @@ typedef struct VinetConvDesc {
                            temporal conv in one launch (instead of one launch per stride phase): x = dy, y = dx,
                            w = the transposed pack, ntaps / sT / tpad = kernel length, stride and padding of the
                            FORWARD conv, oT = y.T; `taps` is ignored.  Only where
-                           vinet_conv3d_fuses_dgrad_phases(desc) returns 1.  0 = no promise. */
+                           vinet_conv3d_fuses_dgrad_phases(desc) returns 1.
+                           5 = 3 x 3 spatial footprint: every tap is (dt, dh, dw, slice) with |dh| <= 1 and |dw| <= 1, and
+                           taps of equal dt are contiguous in the table (ConvPlan.fwd_taps order and every stride phase of
+                           its data gradient): lets plain-input layers take the halo-tile kernel (conv_ht.h), which
+                           stages the activation patch once per (dt, 64 channels) instead of once per tap.
+                           0 = no promise. */
   int32_t tpad;
 } VinetConvDesc;
 
@@ -136,6 +141,9 @@ int64_t vinet_conv3d_splitk_bytes(const VinetConvDesc* desc);
 int vinet_conv3d_fuses_dgrad_phases(const VinetConvDesc* desc);
 /* BM of the tile configuration vinet_conv3d will pick for this problem. */
 int vinet_conv3d_tile_m(const VinetConvDesc* desc);
+/* Rows of the `stats` table ([rows][2][N]) the launch fills: ceil(M / tile_m) for the row-tiled kernels, the number
+ * of spatial tiles for the halo-tile kernel (partial tiles at the image border).  Size `stats` with this. */
+int vinet_conv3d_stats_rows(const VinetConvDesc* desc);
 /* Name of the kernel instantiation vinet_conv3d will launch for this problem
  * (profilers report kernels by that name). */
 int vinet_conv3d_kernel_name(const VinetConvDesc* desc, char* buf, int32_t n);

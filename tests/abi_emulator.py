@@ -149,7 +149,7 @@ class AbiEmulator:
         M, N = d.x.B * d.oT * d.oH * d.oW, d.y.C
         # conv_ts.hip::vinet_conv_use_ts -- the frame-streaming kernel of temporal 64 -> 64 convs: one stats row per 64 positions
         HW = d.oH * d.oW
-        if (d.tline and d.dtype == BF16 and d.out_dtype == BF16 and d.mode == 0 and d.x.C == 64 and N == 64 and d.Kp == 64 and
+        if (d.tline == 1 and d.dtype == BF16 and d.out_dtype == BF16 and d.mode == 0 and d.x.C == 64 and N == 64 and d.Kp == 64 and
                 2 <= d.ntaps <= 7 and d.sT in (1, 2) and d.ntaps >= d.sT and (d.sH, d.sW, d.omH, d.omW, d.ooH, d.ooW) == (1, 1, 1, 1, 0, 0) and
                 (d.x.H, d.x.W, d.y.H, d.y.W) == (d.oH, d.oW, d.oH, d.oW) and HW % 64 == 0 and 0 <= d.tpad < d.ntaps and
                 d.x.B * (HW // 64) >= 2048 and d.oT >= 4 and not (d.pre.relu and not d.pre.scale)):
@@ -211,6 +211,12 @@ class AbiEmulator:
                                    torch.from_numpy(w[kt].T.copy())).numpy().reshape(B, d.y.H, d.y.W, Cc)
         wr(d.y, d.out_dtype, out, bool(d.accumulate))
         return 0
+
+    def vinet_conv3d_stats_rows(self, d):
+        d = _deref(d)
+        M = d.x.B * d.oT * d.oH * d.oW
+        bm = self.vinet_conv3d_tile_m(d)
+        return (M + bm - 1) // bm
 
     def vinet_conv3d(self, d, stream):
         d = _deref(d)

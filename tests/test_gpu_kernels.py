@@ -233,6 +233,38 @@ def test_conv3d_pingpong(case, shape):
         lib.vinet_set_option(b"pp", 1)
 
 
+# the halo-tile kernel (conv_ht.h), forced: 32- and 16-wide tiles, partial row tiles (H not a multiple of 8 / 16), one /
+# several temporal taps with and without temporal stride, 1 / 2 / 3 channel chunks incl. partial ones (Cin = 24, 96, 160),
+# 32- / 64- / 96-wide column tiles with padded N, statistics, activations, accumulate into a strided stride-phase placement,
+# channel- and T-sliced views on both sides
+HT_CASES = [
+    ("ht_64_192", (2, 2, 8, 32), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(stats=True)),
+    ("ht_192_64_5t", (1, 5, 10, 32), 192, 64, (5, 3, 3), (5, 1, 1), (0, 1, 1), dict(act=1)),
+    ("ht_tw16_rows20", (2, 3, 20, 16), 96, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(stats=True, act=1)),
+    ("ht_tw16_w48", (1, 2, 28, 48), 128, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), {}),
+    ("ht_cin24_n32", (1, 4, 12, 64), 24, 32, (2, 3, 3), (2, 1, 1), (0, 1, 1), dict(act=1)),
+    ("ht_cin160_n80", (1, 2, 9, 32), 160, 80, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(epi=True, act=1)),
+    ("ht_3t_s1", (1, 4, 8, 32), 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), dict(stats=True)),
+    ("ht_slices", (2, 2, 8, 32), 64, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(in_ld=160, in_coff=32, out_ld=256, out_coff=64, stats=True)),
+    ("ht_tslice_in", (2, 6, 8, 16), 32, 48, (3, 3, 3), (3, 1, 1), (0, 1, 1), dict(in_ttotal=8, in_toff=1)),
+    ("ht_phase_acc", (2, 3, 8, 32), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(accumulate=True, om=(5, 2))),
+    ("ht_f32_out", (1, 1, 16, 32), 32, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(out_f32=True, epi_shift=True)),
+]
+
+
+@pytest.mark.parametrize("case", HT_CASES, ids=[c[0] for c in HT_CASES])
+def test_conv3d_halo_tile(case):
+    lib = _lib()
+    assert lib.vinet_set_option(b"ht", 2) == 0
+    try:
+        ex = dict(case[7], tline=5)
+        d0 = _run_conv_case(case[:7] + (ex,), E.BF16, forced=True)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_ht_kernel<"), buf.value
+    finally:
+        lib.vinet_set_option(b"ht", 1)
+
+
 # split-K (grids too small for the chip): long-K decoder shape, placement through a concat slice, padded fp32
 # head, a T-sliced input, a pending affine, a chunk count that does not divide over the splits
 SPLITK_CASES = [
@@ -370,7 +402,8 @@ def _run_conv_case(case, dt, forced=False, want_y=False):
     head = ex.get("head", False)
     Ny = (E.EG[dt] if head else N)
     odt = E.F32 if ex.get("out_f32") else dt
-    yp, ymk = view_pair(B, oT, oH, oW, Ny, odt, "y" + name, 2, ld=ex.get("out_ld"), c_off=ex.get("out_coff", 0))
+    omT, ooT = ex.get("om", (1, 0))
+    yp, ymk = view_pair(B, oT * omT, oH, oW, Ny, odt, "y" + name, 2, ld=ex.get("out_ld"), c_off=ex.get("out_coff", 0))
     Kp = E.rup(Cin, 32)
     ntaps = k[0] * k[1] * k[2]
     wmaster = _rand("w" + name, (N, Cin, ntaps), 3, 1.0 / math.sqrt(Cin * ntaps))
@@ -381,7 +414,7 @@ def _run_conv_case(case, dt, forced=False, want_y=False):
     pre_s, pre_h = fvec("ps" + name, Cin, 4, 0.5, 1.5), fvec("ph" + name, Cin, 5)
     os_, oh_ = fvec("os" + name, N, 6, 0.5, 1.5), fvec("oh" + name, N, 7)
     M = B * oT * oH * oW
-    rows = (M + 63) // 64
+    rows = (M + 63) // 64 + B * oT * 8
     stats = Pair(torch.zeros(rows * 2 * N))
 
     def mk(side):
@@ -400,7 +433,9 @@ def _run_conv_case(case, dt, forced=False, want_y=False):
         d.stats = stats.ptr(side) if ex.get("stats") else None
         d.n_valid = N if head else 0
         if ex.get("tline"):
-            d.tline, d.tpad = 1, p[0]
+            d.tline, d.tpad = (1 if ex["tline"] is True else ex["tline"]), p[0]
+        if ex.get("om"):            # output placement of a stride phase: positions (to*omT + ooT, ...) of a larger y
+            d.omT, d.ooT = ex["om"]
         if ex.get("splitk") and side == "gpu":
             nb = _lib().vinet_conv3d_splitk_bytes(C.byref(d))
             assert nb >= 2 * M * Ny * 4, "split-K plan expected for " + name
@@ -416,9 +451,11 @@ def _run_conv_case(case, dt, forced=False, want_y=False):
         d0 = mk("gpu")[0]._obj
         bm = _lib().vinet_conv3d_tile_m(C.byref(d0))
         assert forced or bm == AbiEmulator().vinet_conv3d_tile_m(d0)
-        r = (M + bm - 1) // bm
+        r = _lib().vinet_conv3d_stats_rows(C.byref(d0))
+        assert r >= (M + bm - 1) // bm and (forced or r == AbiEmulator().vinet_conv3d_stats_rows(d0))
+        rc = AbiEmulator().vinet_conv3d_stats_rows(d0)
         sg = stats.get("gpu")[:r * 2 * N].view(r, 2, N).double().sum(0)
-        sc = stats.get("cpu")[:r * 2 * N].view(r, 2, N).double().sum(0)
+        sc = stats.get("cpu")[:rc * 2 * N].view(rc, 2, N).double().sum(0)
         _cmp(sg, sc, 1e-4 if dt == E.F32 else 2e-2, "conv stats " + name)
     if want_y:
         return yp.get("gpu").clone()
@@ -1413,6 +1450,9 @@ def _exact_targets():
         t.append(("n192-" + c[0], test_conv3d_n192_tile, dict(case=c)))
     for c in CONV_TS_CASES:
         t.append(("tstream-" + c[0], test_conv3d_tstream, dict(case=c)))
+    for c in HT_CASES:
+        if not c[7].get("out_f32"):
+            t.append(("halo-" + c[0], test_conv3d_halo_tile, dict(case=c)))
     for ksp in [(7, 2, 3), (3, 2, 1), (5, 3, 2)]:
         for acc in (0, 1):
             t.append(("tsd-k%ds%dp%d-acc%d" % (ksp + (acc,)), test_conv3d_tstream_dgrad_fused, dict(ksp=ksp, acc=acc)))

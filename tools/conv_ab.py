@@ -47,6 +47,11 @@ SITES = [
     ("dg stem_t 64->64 4taps", 8, 16, 112, 192, 64, 64, (4, 1, 1), (1, 1, 1), (1, 0, 0)),
     ("dg b1.3s 192->64 1x3x3", 8, 16, 56, 96, 192, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("stem folded 32->64 7taps", 8, 32, 118, 100, 32, 64, (1, 7, 1), (1, 1, 1), (0, 0, 0)),
+    ("3b s 96->128 1x3x3", 8, 16, 28, 48, 96, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dg 3b s 128->96", 8, 16, 28, 48, 128, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("3c b2 32->96 1x3x3", 8, 16, 28, 48, 32, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dec5 64->32 2x3x3/2", 8, 4, 112, 192, 64, 32, (2, 3, 3), (2, 1, 1), (0, 1, 1)),
+    ("dg dec5 32->64 /ph", 8, 2, 112, 192, 32, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
 ]
 
 
@@ -68,6 +73,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--stats", action="store_true", help="forward convs also write BN statistics partials (training epilogue)")
     ap.add_argument("--only", default="", help="substring filter on site names")
+    ap.add_argument("--ht", action="store_true", help="A/B of the halo-tile kernel (conv_ht.h) against the default dispatch on the 3x3-spatial sites")
     args = ap.parse_args()
     libs = [(os.path.basename(p), bind(p)) for p in (args.lib or [L.LIB_PATH])]
     dev = torch.device("cuda:0")
@@ -81,6 +87,11 @@ def main():
             variants.append((ln + ":wdma", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), False))
             variants.append((ln + ":wdma-noperm", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=0), False))
             variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), True))
+        libs = []
+    if args.ht:
+        for ln, lib in libs:
+            variants.append((ln + ":default", lib, dict(ht=0), False))
+            variants.append((ln + ":ht", lib, dict(ht=2), False))
         libs = []
     for ln, lib in libs:
         variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=0, n64_tile=0, n192_tile=0, n128_tile=0), False))
@@ -98,6 +109,8 @@ def main():
     for (name, B, T, H, W, Cin, N, k, s, p) in SITES:
         if args.only and args.only not in name:
             continue
+        if args.ht and not (k[1:] == (3, 3) and W % 16 == 0):
+            continue
         B = args.batch
         oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
         x = torch.randn(B * T * H * W * Cin, device=dev).bfloat16()
@@ -110,7 +123,7 @@ def main():
         sc, sh = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev)
         dw = torch.zeros(ntaps * N * Kp, device=dev)
         flops = 2.0 * B * oT * oH * oW * N * Cin * ntaps
-        stats = torch.zeros(((B * oT * oH * oW + 63) // 64) * 2 * N, device=dev)
+        stats = torch.zeros(((B * oT * oH * oW + 63) // 64 + 8 * B * oT) * 2 * N, device=dev)
 
         def desc(pre):
             d = L.CConvDesc()
@@ -125,6 +138,8 @@ def main():
             d.pre = L.CAffine(sc.data_ptr(), sh.data_ptr(), 1) if pre else L.CAffine(None, None, 0)
             if args.stats:
                 d.stats = stats.data_ptr()
+            if k[1:] == (3, 3):
+                d.tline = 5
             return d
 
         def wdesc(pre):

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class CTensor(C.Structure):
@@ -58,6 +58,7 @@ _PT, _PC, _PW, _PP = C.POINTER(CTensor), C.POINTER(CConvDesc), C.POINTER(CWgradD
 SIGNATURES = {
     "vinet_conv3d": [_PC, _vp],
     "vinet_conv3d_tile_m": [_PC],
+    "vinet_conv3d_stats_rows": [_PC],
     "vinet_conv3d_splitk_bytes": [_PC],
     "vinet_conv3d_kernel_name": [_PC, C.c_char_p, _i32],
     "vinet_conv3d_wgrad": [_PW, _vp],

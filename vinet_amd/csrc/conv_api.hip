@@ -126,10 +126,16 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   a.tilesM = vn_div_up(M, t.BM());
   a.tilesN = vn_div_up(a.N, t.BN());
   a.splits = 1; a.chunks_per_split = 0; a.ws = nullptr;
+  a.ht_tilesH = a.ht_tilesW = 0;
+  a.ht_dN = a.ht_dW = a.ht_dH = a.ht_dTo = make_fastdiv(1);
   return 0;
 }
 
 static bool use_pp(const VinetConvDesc* d);
+static bool use_ht(const VinetConvDesc* d);
+struct HtShape { int nt, tw; };
+static HtShape ht_shape(const VinetConvDesc* d);
+extern int g_vinet_opt_ht, g_vinet_opt_ht_minhw;
 bool vinet_conv_use_ts(const VinetConvDesc* d);
 bool vinet_conv_use_hs(const VinetConvDesc* d);
 bool vinet_conv_use_tsd(const VinetConvDesc* d);
@@ -146,9 +152,22 @@ extern int g_vinet_opt_wgrad_skinny;
 extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   if (!d) return -1;
   if (vinet_conv_use_ts(d) || vinet_conv_use_hs(d)) return 64;
-  if (use_pp(d)) return 256;
+  if (use_ht(d) || use_pp(d)) return 256;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32)).BM();
+}
+
+/* rows of the [rows][2][N] statistics table this problem's launch fills (one per M tile; the halo-tile kernel's tiles
+ * are spatial, so partial tiles at the image border make it more than ceil(M / tile_m)) */
+extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
+  if (!d) return -1;
+  const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_ht(d)) {
+    const HtShape h = ht_shape(d);
+    return (int)((long)d->x.B * d->oT * vn_div_up(d->oH, 256 / h.tw) * vn_div_up(d->oW, h.tw));
+  }
+  const int bm = vinet_conv3d_tile_m(d);
+  return (int)((M + bm - 1) / bm);
 }
 
 int g_vinet_opt_dma = 1;
@@ -194,6 +213,8 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "n64_tile")) { g_vinet_opt_n64_tile = value; return 0; }
   if (name && !strcmp(name, "tperm")) { g_vinet_opt_tperm = value; return 0; }
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
+  if (name && !strcmp(name, "ht")) { g_vinet_opt_ht = value; return 0; }
+  if (name && !strcmp(name, "ht_minhw")) { g_vinet_opt_ht_minhw = value; return 0; }
   if (name && !strcmp(name, "splitk")) { g_vinet_opt_splitk = value; return 0; }
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
@@ -230,7 +251,9 @@ static int pp_bn(int N) {
 
 // conv_pp.h: plain bf16 inputs, enough K tiles to amortise the 6-half-tile prologue, enough
 // output channels to use a 256-wide tile, enough tiles to occupy the chip
+static bool use_ht(const VinetConvDesc* d);
 static bool use_pp(const VinetConvDesc* d) {
+  if (use_ht(d)) return false;
   if (!g_vinet_opt_pp || !use_dma(d) || d->pre.scale || d->ntaps > 64) return false;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const int N = d->y.C;
@@ -241,12 +264,44 @@ static bool use_pp(const VinetConvDesc* d) {
   return N >= 160 && nkt >= 16 && tiles >= 128;
 }
 
+// conv_ht.h: the caller promises (tline == 5) that every tap is (dt, dh, dw, slice) with |dh|, |dw| <= 1 and that taps
+// of equal dt are contiguous in the table; plain bf16 input, unit spatial stride, output extent = input extent, W a
+// multiple of 16.  Shape: tile width 32 when W allows it, else 16; column tile = the narrowest of 64 / 96 / 128 that
+// pads N least (192 = 2 x 96).
+int g_vinet_opt_ht = 1;         // 0 = off, 1 = heuristic, 2 = every eligible conv (tests)
+int g_vinet_opt_ht_minhw = 28 * 48;
+static HtShape ht_shape(const VinetConvDesc* d) {
+  HtShape h;
+  h.tw = (d->oW % 32 == 0) ? 32 : 16;
+  const int N = d->n_valid > 0 ? d->n_valid : d->y.C;
+  // 96-, 64- or 32-wide column tiles, whichever pads N least (ties: the widest); a 128-wide tile spills (12 B / lane)
+  int best = 4, bestpad = 1 << 30;
+  const int nts[3] = {6, 4, 2};
+  for (int i = 0; i < 3; ++i) {
+    const int bn = nts[i] * 16, pad = (N + bn - 1) / bn * bn;
+    if (pad < bestpad) { bestpad = pad; best = nts[i]; }
+  }
+  h.nt = best;
+  return h;
+}
+static bool use_ht(const VinetConvDesc* d) {
+  if (!g_vinet_opt_ht || !use_dma(d) || d->pre.scale || d->pre.relu || d->tline != 5) return false;
+  if (d->sH != 1 || d->sW != 1 || d->oH != d->x.H || d->oW != d->x.W || d->oW % 16 != 0 || d->ntaps > 64 || d->ntaps < 2) return false;
+  if (g_vinet_opt_ht >= 2) return true;
+  // measured (tools/conv_ab.py --ht, 64 clips): wins wherever the 64-channel K chunks are (nearly) full -- 504 -> 995 TF/s on
+  // the 192 -> 64 5x3x3 decoder conv, 528 -> 840 on the data gradient of 64 -> 192, 894 -> 1026 on 480 -> 192 (conv_pp before),
+  // 331 -> 510 on 64 -> 32 -- and loses where a chunk is half padding (Cin = 32: 410 -> 310; Cin = 96: 608 -> 535)
+  const int N = d->y.C;
+  const int k64 = (d->Kp + 63) / 64 * 64;
+  return (long)d->oH * d->oW >= g_vinet_opt_ht_minhw && N >= 32 && k64 * 20 <= d->Kp * 23;
+}
+
 // ---- split-K for grids that cannot fill the chip (batch-1 inference) ---------------------------
 int g_vinet_opt_splitk = 1;     // 0 = off; n >= 2 = tuning: minimum K chunks (of 32) per split
 struct SplitK { int splits, per; long bytes; };
 static SplitK splitk_plan(const VinetConvDesc* d) {
   SplitK p{1, 0, 0};
-  if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || vinet_conv_use_ts(d) || vinet_conv_use_hs(d) || d->stats || d->accumulate) return p;
+  if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || use_ht(d) || vinet_conv_use_ts(d) || vinet_conv_use_hs(d) || d->stats || d->accumulate) return p;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const int nchunks = d->ntaps * (d->Kp / 32);
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, nchunks);
@@ -303,6 +358,7 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   if (d->tline == 3) snprintf(buf, n, vinet_conv_use_tsd(d) ? "conv_tsd_kernel" : "(unsupported)");
   else if (vinet_conv_use_hs(d)) snprintf(buf, n, "conv_hs_kernel");
   else if (vinet_conv_use_ts(d)) snprintf(buf, n, "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
+  else if (use_ht(d)) { const HtShape h = ht_shape(d); snprintf(buf, n, "conv_ht_kernel<%d,%d>", h.nt * 16, h.tw); }
   else if (use_pp(d)) snprintf(buf, n, "conv_pp_kernel<%d>", pp_bn(d->y.C));
   else if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
   else snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", t.MT, t.NT, t.WM, t.WN, d->mode);
@@ -324,6 +380,16 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
   if (rc) return rc;
   if (vinet_conv_use_hs(d)) return vinet_launch_conv_hs(d, (hipStream_t)stream);
   if (vinet_conv_use_ts(d)) return vinet_launch_conv_ts(d, (hipStream_t)stream);
+  if (use_ht(d)) {
+    const HtShape h = ht_shape(d);
+    a.tilesN = vn_div_up(a.N, h.nt * 16);
+    a.ht_tilesH = vn_div_up(d->oH, 256 / h.tw);
+    a.ht_tilesW = vn_div_up(d->oW, h.tw);
+    a.tilesM = (int)((long)d->x.B * d->oT * a.ht_tilesH * a.ht_tilesW);
+    a.ht_dN = make_fastdiv((uint32_t)a.tilesN); a.ht_dW = make_fastdiv((uint32_t)a.ht_tilesW);
+    a.ht_dH = make_fastdiv((uint32_t)a.ht_tilesH); a.ht_dTo = make_fastdiv((uint32_t)d->oT);
+    return vinet_launch_conv_ht_bf16(h.nt, h.tw, a, (hipStream_t)stream);
+  }
   if (use_pp(d)) {
     const int bn = pp_bn(a.N);
     a.tilesM = vn_div_up(a.M, 256);

@@ -1,6 +1,7 @@
 // bf16 instantiations of the implicit-GEMM convolution.
 #include "conv_dma.h"
 #include "conv_pp.h"
+#include "conv_ht.h"
 
 #define CASE(MT_, NT_, WM_, WN_)                                                            \
   if (t.MT == MT_ && t.NT == NT_ && t.WM == WM_ && t.WN == WN_)                             \
@@ -30,4 +31,19 @@ int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t
 // 256x256x64 ping-pong kernel (conv_pp.h): plain inputs only
 int vinet_launch_conv_pp_bf16(int bn, const ConvArgs& a, hipStream_t s) {
   return bn == 192 ? launch_conv_pp_cfg<4, 2, 192>(a, s) : launch_conv_pp_cfg<2, 4, 256>(a, s);
+}
+
+// halo-tile kernel (conv_ht.h): 3x3 spatial taps on plain inputs; nt = 16-column tiles per workgroup, tw = tile width
+int vinet_launch_conv_ht_bf16(int nt, int tw, const ConvArgs& a, hipStream_t s) {
+  if (tw == 32) {
+    if (nt == 2) return launch_conv_ht_cfg<2, 32, 3>(a, s);
+    if (nt == 4) return launch_conv_ht_cfg<4, 32, 3>(a, s);
+    if (nt == 6) return launch_conv_ht_cfg<6, 32, 3>(a, s);
+  } else if (tw == 16) {
+    if (nt == 2) return launch_conv_ht_cfg<2, 16, 3>(a, s);
+    if (nt == 4) return launch_conv_ht_cfg<4, 16, 3>(a, s);
+    if (nt == 6) return launch_conv_ht_cfg<6, 16, 3>(a, s);
+  }
+  vinet_set_error("conv ht bf16: no kernel for nt=%d tw=%d", nt, tw);
+  return -1;
 }

@@ -1,0 +1,248 @@
+// Halo-tile implicit-GEMM convolution for kernels with 3x3 SPATIAL taps (bf16, gfx950): the 1x3x3 convs of the
+// SepConv3d blocks (model_utils.py:144), the kT x 3 x 3 / stride-kT decoder convs (model.py:256-276) and every
+// data gradient of those (one launch per temporal stride phase, each a 1x3x3 conv over dy).
+//
+// Why a third conv generation next to conv_dma.h / conv_pp.h: those stage an im2col A tile per K step, i.e. the
+// activation patch is fetched from L2 once PER TAP (9x for a 3x3 kernel) -- 11.7 (conv_dma) / 7.8 (conv_pp) bytes
+// staged per kFLOP, and the CU's L2 -> LDS path, not MFMA or HBM, bounds them.  Here a
+// workgroup owns a SPATIAL tile of one output frame (TR rows x TW columns = 256 positions) and stages the input
+// patch with its one-pixel halo ((TR+2) x (TW+2) positions x 64 channels = 43.5 KB) ONCE per (temporal tap,
+// channel chunk); the nine spatial taps are nine fragment ADDRESSES into that halo image, not nine copies.  Per
+// K step (tap, 64 channels) only the weight tile (BN x 128 B, L2 resident, contiguous) is staged: 4.8 KB of halo
+// + 8...16 KB of weights per 2.1...4.2 MFLOP = 4...6 B/kFLOP.
+//
+//   * 256 threads = 4 waves stacked along M (wave = 64 positions x all BN columns), two workgroups per CU.
+//   * LDS: [halo image: 352 positions x 128 B][B ring: BSLOTS x BN rows x 128 B].  Both are written by
+//     `global_load_lds_dwordx4` in 8-row x 128-B pieces (whole cache lines), lane-linear on the LDS side, with the
+//     16-byte chunk index XOR (row & 7) applied on the SOURCE address and again on the ds_read_b128: a fragment
+//     read touches 16 consecutive rows (positions p0..p0+15, any alignment), whose (p & 7) take all 8 values twice
+//     -> conflict-free (MI355X_MICROARCH.md, LDS table: ds_read_b128 lane groups).
+//   * out-of-image halo positions, frames outside the clip and channels past Cin read a zero page (branch-free
+//     source selection: every wave issues exactly HL / BL DMAs, so the counted `s_waitcnt vmcnt` is exact).
+//   * K order: temporal tap (group) outer, channel chunk middle, the group's spatial taps inner.  One raw
+//     s_barrier per K step; the weight tiles of the next BSLOTS-1 steps are in flight across it.  A new (group,
+//     chunk) re-stages the halo image: one extra barrier + a full drain, hidden by the CU's second workgroup.
+//   * epilogue: the shared conv_epilogue (BN partial sums, activation, accumulate, arbitrary placement) with the
+//     row -> voxel map of the spatial tile.
+#pragma once
+#include "conv_dma.h"
+
+template <int NT, int TW, int BSLOTS>
+struct ConvHtCfg {
+  static constexpr int THREADS = 256, BM = 256, TR = BM / TW, HW = TW + 2, HR = TR + 2;
+  static constexpr int NPOS = HR * HW;                  // halo positions
+  static constexpr int HPIECES = (NPOS + 7) / 8;        // DMA pieces of 8 positions x 128 B
+  static constexpr int HL = (HPIECES + 3) / 4;          // halo DMAs per wave
+  static constexpr int HALO_BYTES = HL * 4 * 1024;
+  static constexpr int BN = NT * 16;
+  static constexpr int BL = NT / 2;                     // weight DMAs per wave and K step (BN / 8 pieces over 4 waves)
+  static constexpr int BSLOT_BYTES = BN * 128;
+  static constexpr int KLOOP_BYTES = HALO_BYTES + BSLOTS * BSLOT_BYTES;
+  static constexpr int EROW = BN + 4;
+  static constexpr int EPI_BYTES = 4 * 16 * EROW * 4 + 4 * BN * 2 * 4;
+  static constexpr int SMEM = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
+  static_assert(NT % 2 == 0 && (TW == 32 || TW == 16), "shapes");
+  static_assert(BSLOTS >= 2 && BL * (BSLOTS - 2) <= 63, "vmcnt immediate range");
+};
+
+// K-step cursor: tap t of the group [t0, t1) (equal temporal offset), channel chunk c0
+struct HtCursor {
+  int t, c0, t0, t1;
+};
+
+template <int NT, int TW, int BSLOTS>
+__global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
+  using Cfg = ConvHtCfg<NT, TW, BSLOTS>;
+  constexpr int HW = Cfg::HW, TR = Cfg::TR, HL = Cfg::HL, BL = Cfg::BL, MT = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const halo = smem;
+  char* const bring = smem + Cfg::HALO_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* zero = (const char*)g_vinet_zero_page;
+
+  // ---- workgroup -> (column tile, spatial tile, frame) ---------------------------------------------------------------
+  const uint32_t wg = (uint32_t)xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t sp = fdiv(wg, a.ht_dN);                      // spatial tile index = statistics row
+  const int tile_n = (int)(wg - sp * (uint32_t)a.tilesN);
+  const uint32_t q1 = fdiv(sp, a.ht_dW);
+  const int tw_i = (int)(sp - q1 * (uint32_t)a.ht_tilesW);
+  const uint32_t frame = fdiv(q1, a.ht_dH);
+  const int th_i = (int)(q1 - frame * (uint32_t)a.ht_tilesH);
+  const uint32_t bb = fdiv(frame, a.ht_dTo);
+  const int to = (int)(frame - bb * (uint32_t)a.To), b = (int)bb;
+  const int h0 = th_i * TR, w0 = tw_i * TW;
+
+  // ---- this lane's DMA role: row (lane >> 3) of an 8-row piece, LDS slot (lane & 7), source chunk slot ^ row -----------
+  const int prow = lane >> 3;
+  const int src_chunk = (lane & 7) ^ prow;
+  int hal_off[HL];            // element offset of this lane's halo position inside a frame (+ its chunk); 0 when out of range
+  unsigned hal_ok = 0;
+#pragma unroll
+  for (int j = 0; j < HL; ++j) {
+    const int p = (j * 4 + wave) * 8 + prow;
+    const int hr = p / HW, hc = p - hr * HW;
+    const int h = h0 - 1 + hr, w = w0 - 1 + hc;
+    const bool ok = (p < Cfg::NPOS) & ((unsigned)h < (unsigned)a.Hi) & ((unsigned)w < (unsigned)a.Wi);
+    hal_off[j] = ok ? (h * a.Wi + w) * a.ldx + src_chunk * 8 : 0;
+    hal_ok |= (unsigned)ok << j;
+  }
+  const char* const xb = a.x + (long)b * a.sBx * 2;
+  const long frame_elems = (long)a.Hi * a.Wi * a.ldx;
+  long b_off[BL];
+  unsigned b_ok[BL];
+#pragma unroll
+  for (int j = 0; j < BL; ++j) {
+    const int n = (j * 4 + wave) * 8 + prow;
+    const int nn = tile_n * Cfg::BN + n;
+    b_ok[j] = (unsigned)(nn < a.Nw);
+    b_off[j] = ((long)(b_ok[j] ? nn : 0) * a.Kp + src_chunk * 8) * 2;
+  }
+  const long slice_bytes = (long)a.Nw * a.Kp * 2;
+
+  auto dma = [&](const char* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto group_end = [&](int t0) {
+    const int dt = load_tap(a.taps, t0).x;
+    int t1 = t0 + 1;
+    while (t1 < a.ntaps && load_tap(a.taps, t1).x == dt) ++t1;
+    return t1;
+  };
+  auto advance = [&](HtCursor& c) {
+    ++c.t;
+    if (c.t == c.t1) {
+      c.c0 += 64;
+      if (c.c0 < a.Kp) {
+        c.t = c.t0;
+      } else {
+        c.c0 = 0;
+        c.t0 = c.t1;
+        c.t = c.t0;
+        if (c.t0 < a.ntaps) c.t1 = group_end(c.t0);
+      }
+    }
+  };
+  auto issue_halo = [&](const HtCursor& c) {
+    const int dt = load_tap(a.taps, c.t0).x;
+    const int t = to * a.sT + dt;
+    const unsigned tok = (unsigned)((unsigned)t < (unsigned)a.Ti) & (unsigned)(c.c0 + src_chunk * 8 < a.Cin);
+    const char* base = xb + ((long)t * frame_elems + c.c0) * 2;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const unsigned ok = tok & ((hal_ok >> j) & 1u);
+      const char* src = zero + (((base + (long)hal_off[j] * 2) - zero) & -(long)ok);
+      dma(src, halo + (j * 4 + wave) * 1024);
+    }
+  };
+  auto issue_b = [&](int slot, const HtCursor& c) {
+    char* dst = bring + slot * Cfg::BSLOT_BYTES + wave * 1024;
+    if (c.t0 < a.ntaps) {
+      const int4 tp = load_tap(a.taps, c.t);
+      const long delta = (long)tp.w * slice_bytes + (long)c.c0 * 2;
+      const unsigned cok = (unsigned)(c.c0 + src_chunk * 8 < a.Kp);
+#pragma unroll
+      for (int j = 0; j < BL; ++j) {
+        const unsigned ok = cok & b_ok[j];
+        const char* src = zero + (((a.w + b_off[j] + delta) - zero) & -(long)ok);
+        dma(src, dst + j * 4096);
+      }
+    } else {   // past the last K step: keep the DMA count per step exact
+#pragma unroll
+      for (int j = 0; j < BL; ++j) dma(zero, dst + j * 4096);
+    }
+  };
+
+  // ---- fragments ---------------------------------------------------------------------------------------------------------
+  f32x4_v acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+  // halo position of this lane's row of A fragment i for the centre tap; rows of a fragment are 16 consecutive columns
+  int pl[MT], mb[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int r = TW == 32 ? 2 * wave + (i >> 1) : 4 * wave + i;
+    const int c = TW == 32 ? (i & 1) * 16 : 0;
+    pl[i] = (r + 1) * HW + (c + 1) + (lane & 15);
+    const int ho = h0 + r, wo = w0 + c;
+    mb[i] = (ho < a.Ho && wo < a.Wo) ? (int)((frame * (uint32_t)a.Ho + (uint32_t)ho) * (uint32_t)a.Wo + (uint32_t)wo) : -1;
+  }
+  const int kq = lane >> 4;                                           // this lane's 16-byte k group inside a 32-wide K half
+  const int bfo0 = (lane & 15) * 128 + (((kq) ^ (lane & 7)) << 4);    // weight fragment rows: n & 7 == lane & 7
+  const int bfo1 = (lane & 15) * 128 + (((4 + kq) ^ (lane & 7)) << 4);
+
+  auto compute = [&](int slot, const HtCursor& c) {
+    const int4 tp = load_tap(a.taps, c.t);
+    const int tapoff = tp.y * HW + tp.z;
+    const char* Bs = bring + slot * Cfg::BSLOT_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_v af[MT], bfr[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int p = pl[i] + tapoff;
+        af[i] = *(const bf16x8_v*)(halo + (p << 7) + ((((kk << 2) + kq) ^ (p & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8_v*)(Bs + j * 2048 + (kk ? bfo1 : bfo0));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mfma_bf16_acc(acc[i][j], af[i], bfr[j]);
+    }
+  };
+
+  // ---- pipeline ----------------------------------------------------------------------------------------------------------
+  const int cpt = (a.Kp + 63) >> 6;
+  const int nsteps = a.ntaps * cpt;
+  HtCursor cc{0, 0, 0, 0}, ci{0, 0, 0, 0};
+  cc.t1 = ci.t1 = group_end(0);
+#pragma unroll
+  for (int s = 0; s < BSLOTS - 1; ++s) {
+    issue_b(s, ci);
+    advance(ci);
+  }
+  int slot = 0, fill = BSLOTS - 1;
+  for (int s = 0; s < nsteps; ++s) {
+    if (cc.t == cc.t0) {                           // new (temporal tap, channel chunk): re-stage the halo image
+      __builtin_amdgcn_s_barrier();                // everyone has finished reading the old one
+      asm volatile("" ::: "memory");
+      issue_halo(cc);
+      wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<BL*(BSLOTS - 2)>();               // my weight DMAs of this step have landed
+    }
+    __builtin_amdgcn_s_barrier();                  // everyone's have; everyone finished reading slot `fill`
+    asm volatile("" ::: "memory");
+    issue_b(fill, ci);
+    advance(ci);
+    compute(slot, cc);
+    advance(cc);
+    asm volatile("" ::: "memory");
+    slot = slot + 1 == BSLOTS ? 0 : slot + 1;
+    fill = fill + 1 == BSLOTS ? 0 : fill + 1;
+  }
+  wait_vmcnt<0>();
+  mfma_drain();
+  __syncthreads();
+  conv_epilogue<MT, NT, 4, 1>(a, acc, smem, (int)sp, tile_n, mb);
+}
+
+template <int NT, int TW, int BSLOTS>
+static int launch_conv_ht_cfg(const ConvArgs& a, hipStream_t s) {
+  using Cfg = ConvHtCfg<NT, TW, BSLOTS>;
+  auto kern = conv_ht_kernel<NT, TW, BSLOTS>;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_ht): %s", hipGetErrorString(e)); return (int)e; }
+    attr_done[dev & 63] = true;
+  }
+  const long grid = (long)a.tilesN * a.ht_tilesW * a.ht_tilesH * a.To * (a.M / ((long)a.To * a.Ho * a.Wo));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), Cfg::SMEM, s, a);
+  return vn_launch_status("conv_ht");
+}

@@ -49,6 +49,9 @@ struct ConvArgs {
   // (run-to-run deterministic) and applies the epilogue
   int splits, chunks_per_split;
   float* ws;
+  // spatial halo tiles (conv_ht.h): tiles per image in H and W, workgroup index -> (column tile, spatial tile) decode
+  int ht_tilesH, ht_tilesW;
+  FastDiv ht_dN, ht_dW, ht_dH, ht_dTo;
 };
 
 // logical M-tile index -> tile position in memory order
@@ -90,8 +93,11 @@ VN_DEV void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// `mb` (optional): the tile's rows are not consecutive voxels (spatial halo tiles, conv_ht.h): mb[i] is the linear
+// voxel index of the first row of this wave's 16-row group i, or < 0 when the whole group lies outside the iteration
+// space; nullptr = rows tile_m*BM + ... as usual.  `tile_m` stays the statistics row of the workgroup.
 template <int MT, int NT, int WARPS_M, int WARPS_N>
-VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem, int tile_m, int tile_n) {
+VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem, int tile_m, int tile_n, const int* mb = nullptr) {
   constexpr int BM = 16 * MT * WARPS_M, BN = 16 * NT * WARPS_N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
@@ -129,9 +135,10 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m_wave + i * 16 + (lane >> 4) * 4 + r;
+        const int m = (mb ? mb[i] : m_wave + i * 16) + (lane >> 4) * 4 + r;
+        const bool mok = mb ? mb[i] >= 0 : m < a.M;
         const float v = fmaf(acc[i][j][r], sc[j], sh[j]);
-        const float vs = (nok[j] && m < a.M) ? v : 0.f;
+        const float vs = (nok[j] && mok) ? v : 0.f;
         s_sum[j] += vs; s_sq[j] += vs * vs;
         float o = fmaxf(v, relu_floor);
         if (sigm) o = 1.f / (1.f + __expf(-o));
@@ -143,18 +150,20 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
       for (int k = 0; k < ITERS; ++k) {
         const int e = lane + 64 * k;
         const int rr = e / VPR, cc = (e % VPR) * 4;
-        const int m = m_wave + i * 16 + rr;
+        const int m = (mb ? mb[i] : m_wave + i * 16) + rr;
+        const bool mok = mb ? mb[i] >= 0 : m < a.M;
         const int n = n_wave + cc;
         const float4 v = *(const float4*)&Ew[rr * EROW + cc];
-        if (m < a.M && n < a.N)
+        if (mok && n < a.N)
           *(uint2*)((bf16_t*)a.y + (long)m * a.ldy + n) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
       }
     } else {
       for (int e = lane; e < 16 * VPR; e += 64) {
         const int rr = e / VPR, cc = (e % VPR) * 4;
-        const int m = m_wave + i * 16 + rr;
+        const int m = (mb ? mb[i] : m_wave + i * 16) + rr;
+        const bool mok = mb ? mb[i] >= 0 : m < a.M;
         const int n = n_wave + cc;
-        if (m < a.M && n < a.N) {
+        if (mok && n < a.N) {
           const float4 v = *(const float4*)&Ew[rr * EROW + cc];
           long off;
           if (a.y_linear) {
@@ -421,6 +430,7 @@ int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipSt
 int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_pp_bf16(int bn, const ConvArgs& a, hipStream_t s);
+int vinet_launch_conv_ht_bf16(int nt, int tw, const ConvArgs& a, hipStream_t s);
 
 template <typename T, int MT, int NT, int WM, int WN, int MODE>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {

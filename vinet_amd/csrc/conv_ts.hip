@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
 int g_vinet_opt_conv_ts = 1;   // 0 = off, 2 = force on every eligible shape (tests)
 
 bool vinet_conv_use_ts(const VinetConvDesc* d) {
-  if (!g_vinet_opt_conv_ts || !d->tline || d->dtype != VINET_BF16 || d->out_dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
+  if (!g_vinet_opt_conv_ts || d->tline != 1 || d->dtype != VINET_BF16 || d->out_dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
   if (d->pre.scale && !(d->pre.relu && d->pre.shift)) return false;
   if (d->pre.relu && !d->pre.scale) return false;
   const long HW = (long)d->oH * d->oW;

@@ -96,8 +96,8 @@ PROFILER = None
 JOINT_ENTRY = int(os.environ.get("VINET_JOINT_ENTRY", "1"))
 # the stem's BN-backward apply pass folded into its weight-gradient kernel (0 = separate pass)
 BN_BWD_FUSE = int(os.environ.get("VINET_BN_BWD_FUSE", "1"))
-# weight gradients of the BN-free (decoder) convs wait on the side stream until the tape reaches the encoder (0 = launch in tape order)
-DEFER_DECODER_WGRAD = int(os.environ.get("VINET_DEFER_DECODER_WGRAD", "0"))
+# weight gradients of the BN-free (decoder) convs wait on the side stream until the tape reaches the encoder (0 = launch in tape order); +0.5 % on the whole step at 192 clips (550.7 / 551.7 vs 548.2 / 548.2 clips/s, alternating runs on one box)
+DEFER_DECODER_WGRAD = int(os.environ.get("VINET_DEFER_DECODER_WGRAD", "1"))
 # packed weight-gradient workspaces owned by the conv plans and re-zeroed by vinet_unpack_wgrad (0 = a torch.zeros per conv and step)
 PERSISTENT_DW = int(os.environ.get("VINET_PERSISTENT_DW", "1"))
 
@@ -461,6 +461,9 @@ class ConvPlan:
         self.stem = stem
         # (k,1,1) kernel: tap kt is (kt - pT, 0, 0, kt)
         self.temporal = self.k[1] == 1 and self.k[2] == 1 and self.p[1] == 0 and self.p[2] == 0 and self.s[1] == 1 and self.s[2] == 1
+        # 3 x 3 spatial footprint, unit spatial stride, "same" padding: fwd_taps (kt-major) and every stride phase of the data
+        # gradient keep |dh|, |dw| <= 1 with equal-dt taps contiguous -- the promise behind VinetConvDesc::tline == 5
+        self.spatial3 = (not stem) and self.k[1:] == (3, 3) and self.p[1:] == (1, 1) and self.s[1:] == (1, 1)
         if stem:
             assert self.k == (1, 7, 7) and self.Cin == 3 and self.p[2] == 3
         self._packs = {}
@@ -518,8 +521,14 @@ class ConvPlan:
             key = ("dg", in_dims, rT, rH, rW)
             offs = sorted(r_[0] for r_ in rows)
             tline = self.temporal and offs == list(range(offs[0], offs[0] + len(offs)))
+            tl = 1 if tline else 0
+            if self.spatial3:
+                dts = [r_[0] for r_ in rows]
+                assert all(abs(r_[1]) <= 1 and abs(r_[2]) <= 1 for r_ in rows) and dts == sorted(dts, key=dts.index)
+                assert all(dts[i] == dts[i - 1] or dts[i] not in dts[:i] for i in range(1, len(dts))), "equal-dt taps must be contiguous"
+                tl = 5
             phases.append(dict(taps=self._dev_taps(key, rows, device), ntaps=len(rows), Q=(QT, QH, QW), r=(rT, rH, rW),
-                               tline=1 if tline else 0, tpad=-offs[0] if tline else 0))
+                               tline=tl, tpad=-offs[0] if tline else 0))
         covered = all(len(p_) == min(s, I) for p_, s, I in zip(per, self.s, in_dims))
         return phases, (full and covered)
 
@@ -604,7 +613,7 @@ class JointConvPlan(ConvPlan):
         self.weight, self.bias = None, None
         self.k, self.s, self.p = (1, 1, 1), (1, 1, 1), (0, 0, 0)
         self.N, self.Cin, self.ntaps, self.stem = sum(m.N for m in members), m0.Cin, 1, False
-        self.temporal = False
+        self.temporal = self.spatial3 = False
         self._packs, self._taps, self._dw_ws = {}, {}, {}
 
     def grad_targets(self):
@@ -839,6 +848,8 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         d.tline, d.tpad = 1, plan.p[0]      # promise to the library (it cannot read the device-side tap table)
     elif folded:
         d.tline = 2                         # taps (0, kh, 0, kh): ConvPlan.folded_taps
+    elif plan.spatial3:
+        d.tline = 5                         # 3 x 3 spatial footprint, kt-major tap order: ConvPlan.fwd_taps
     M = xv.B * oT * oH * oW
     site = plan.site(xv)
     es = ESIZE[lib_dt]
@@ -887,8 +898,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
             res.scale = res.shift = None
             res.relu = False
     else:
-        bm = ctx.lib.vinet_conv3d_tile_m(C.byref(d))
-        rows = (M + bm - 1) // bm
+        rows = ctx.lib.vinet_conv3d_stats_rows(C.byref(d))
         stats = ctx.f32(rows * 2 * plan.N)
         d.out_scale, d.out_shift, d.act, d.stats = None, _ptr(plan.bias), L.ACT_NONE, stats.data_ptr()
         ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
