@@ -46,7 +46,7 @@ struct ConvDmaCfg {
   static constexpr int STAGE_BYTES = (BM + BNP) * 64;
   static constexpr int WNC = NT * 16, EROW = WNC + 4;
   static constexpr int KLOOP_BYTES = STAGES * STAGE_BYTES;   // PRE adds scale[Kp], shift[Kp] behind the ring
-  static constexpr int EPI_BYTES = 4 * 16 * EROW * 4 + WARPS_M * BN * 2 * 4;
+  static constexpr int EPI_BYTES = conv_epi_bytes<MT, NT, WARPS_M, WARPS_N>();
   static int smem_bytes(int Kp) {
     const int k = KLOOP_BYTES + (PRE ? 2 * Kp * 4 : 0);
     return k > EPI_BYTES ? k : EPI_BYTES;

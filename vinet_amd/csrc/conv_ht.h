@@ -39,15 +39,10 @@ struct ConvHtCfg {
   static constexpr int BSLOT_BYTES = BN * 128;
   static constexpr int KLOOP_BYTES = HALO_BYTES + BSLOTS * BSLOT_BYTES;
   static constexpr int EROW = BN + 4;
-  static constexpr int EPI_BYTES = 4 * 16 * EROW * 4 + 4 * BN * 2 * 4;
+  static constexpr int EPI_BYTES = conv_epi_bytes<4, NT, 4, 1>();
   static constexpr int SMEM = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
   static_assert(NT % 2 == 0 && (TW == 32 || TW == 16), "shapes");
   static_assert(BSLOTS >= 2 && BL * (BSLOTS - 2) <= 63, "vmcnt immediate range");
-};
-
-// K-step cursor: tap t of the group [t0, t1) (equal temporal offset), channel chunk c0
-struct HtCursor {
-  int t, c0, t0, t1;
 };
 
 template <int NT, int TW, int BSLOTS>
@@ -60,6 +55,10 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const char* zero = (const char*)g_vinet_zero_page;
 
+#ifdef VINET_CONV_TIMING
+  const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+  unsigned long long tm_halo = 0, tm_h0 = 0;
+#endif
   // ---- workgroup -> (column tile, spatial tile, frame) ---------------------------------------------------------------
   const uint32_t wg = (uint32_t)xcd_remap(blockIdx.x, gridDim.x);
   const uint32_t sp = fdiv(wg, a.ht_dN);                      // spatial tile index = statistics row
@@ -103,31 +102,11 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
-  auto group_end = [&](int t0) {
-    const int dt = load_tap(a.taps, t0).x;
-    int t1 = t0 + 1;
-    while (t1 < a.ntaps && load_tap(a.taps, t1).x == dt) ++t1;
-    return t1;
-  };
-  auto advance = [&](HtCursor& c) {
-    ++c.t;
-    if (c.t == c.t1) {
-      c.c0 += 64;
-      if (c.c0 < a.Kp) {
-        c.t = c.t0;
-      } else {
-        c.c0 = 0;
-        c.t0 = c.t1;
-        c.t = c.t0;
-        if (c.t0 < a.ntaps) c.t1 = group_end(c.t0);
-      }
-    }
-  };
-  auto issue_halo = [&](const HtCursor& c) {
-    const int dt = load_tap(a.taps, c.t0).x;
+  // halo image of (temporal offset dt, channel chunk c0)
+  auto issue_halo = [&](int dt, int c0) {
     const int t = to * a.sT + dt;
-    const unsigned tok = (unsigned)((unsigned)t < (unsigned)a.Ti) & (unsigned)(c.c0 + src_chunk * 8 < a.Cin);
-    const char* base = xb + ((long)t * frame_elems + c.c0) * 2;
+    const unsigned tok = (unsigned)((unsigned)t < (unsigned)a.Ti) & (unsigned)(c0 + src_chunk * 8 < a.Cin);
+    const char* base = xb + ((long)t * frame_elems + c0) * 2;
 #pragma unroll
     for (int j = 0; j < HL; ++j) {
       const unsigned ok = tok & ((hal_ok >> j) & 1u);
@@ -135,21 +114,16 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
       dma(src, halo + (j * 4 + wave) * 1024);
     }
   };
-  auto issue_b = [&](int slot, const HtCursor& c) {
+  // weight tile of (slice, c0) into ring slot `slot`; live == false: the same number of DMAs from the zero page
+  auto issue_b = [&](int slot, bool live, int slice, int c0) {
     char* dst = bring + slot * Cfg::BSLOT_BYTES + wave * 1024;
-    if (c.t0 < a.ntaps) {
-      const int4 tp = load_tap(a.taps, c.t);
-      const long delta = (long)tp.w * slice_bytes + (long)c.c0 * 2;
-      const unsigned cok = (unsigned)(c.c0 + src_chunk * 8 < a.Kp);
+    const long delta = (long)slice * slice_bytes + (long)c0 * 2;
+    const unsigned cok = (unsigned)live & (unsigned)(c0 + src_chunk * 8 < a.Kp);
 #pragma unroll
-      for (int j = 0; j < BL; ++j) {
-        const unsigned ok = cok & b_ok[j];
-        const char* src = zero + (((a.w + b_off[j] + delta) - zero) & -(long)ok);
-        dma(src, dst + j * 4096);
-      }
-    } else {   // past the last K step: keep the DMA count per step exact
-#pragma unroll
-      for (int j = 0; j < BL; ++j) dma(zero, dst + j * 4096);
+    for (int j = 0; j < BL; ++j) {
+      const unsigned ok = cok & b_ok[j];
+      const char* src = zero + (((a.w + b_off[j] + delta) - zero) & -(long)ok);
+      dma(src, dst + j * 4096);
     }
   };
 
@@ -160,74 +134,125 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
   // halo position of this lane's row of A fragment i for the centre tap; rows of a fragment are 16 consecutive columns
-  int pl[MT], mb[MT];
+  int pl[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int r = TW == 32 ? 2 * wave + (i >> 1) : 4 * wave + i;
     const int c = TW == 32 ? (i & 1) * 16 : 0;
     pl[i] = (r + 1) * HW + (c + 1) + (lane & 15);
-    const int ho = h0 + r, wo = w0 + c;
-    mb[i] = (ho < a.Ho && wo < a.Wo) ? (int)((frame * (uint32_t)a.Ho + (uint32_t)ho) * (uint32_t)a.Wo + (uint32_t)wo) : -1;
   }
+  // row -> voxel map of this wave for the epilogue: TR / 4 image rows of the tile, TW / 16 row groups each
+  constexpr int WROWS = TR / 4;
+  const int hw0 = h0 + wave * WROWS;
+  EpiRows er;
+  er.m0 = (int)((frame * (uint32_t)a.Ho + (uint32_t)hw0) * (uint32_t)a.Wo + (uint32_t)w0);
+  er.ipr = TW / 16;
+  er.rstride = a.Wo;
+  er.nrows = a.Ho - hw0 < 0 ? 0 : (a.Ho - hw0 > WROWS ? WROWS : a.Ho - hw0);
   const int kq = lane >> 4;                                           // this lane's 16-byte k group inside a 32-wide K half
   const int bfo0 = (lane & 15) * 128 + (((kq) ^ (lane & 7)) << 4);    // weight fragment rows: n & 7 == lane & 7
   const int bfo1 = (lane & 15) * 128 + (((4 + kq) ^ (lane & 7)) << 4);
 
-  auto compute = [&](int slot, const HtCursor& c) {
-    const int4 tp = load_tap(a.taps, c.t);
-    const int tapoff = tp.y * HW + tp.z;
+  auto compute = [&](int slot, int tapoff) {
     const char* Bs = bring + slot * Cfg::BSLOT_BYTES;
+    // all fragment reads of the K step are issued before its first MFMA (the second half's LDS latency hides behind
+    // the first half's MFMAs; hipcc otherwise reads, waits, multiplies, reads, waits, multiplies)
+    bf16x8_v af[2][MT], bfr[2][NT];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_v af[MT], bfr[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int p = pl[i] + tapoff;
-        af[i] = *(const bf16x8_v*)(halo + (p << 7) + ((((kk << 2) + kq) ^ (p & 7)) << 4));
+        af[kk][i] = *(const bf16x8_v*)(halo + (p << 7) + ((((kk << 2) + kq) ^ (p & 7)) << 4));
       }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8_v*)(Bs + j * 2048 + (kk ? bfo1 : bfo0));
+      for (int j = 0; j < NT; ++j) bfr[kk][j] = *(const bf16x8_v*)(Bs + j * 2048 + (kk ? bfo1 : bfo0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mfma_bf16_acc(acc[i][j], af[i], bfr[j]);
-    }
+        for (int j = 0; j < NT; ++j) mfma_bf16_acc(acc[i][j], af[kk][i], bfr[kk][j]);
   };
 
   // ---- pipeline ----------------------------------------------------------------------------------------------------------
-  const int cpt = (a.Kp + 63) >> 6;
-  const int nsteps = a.ntaps * cpt;
-  HtCursor cc{0, 0, 0, 0}, ci{0, 0, 0, 0};
-  cc.t1 = ci.t1 = group_end(0);
+  // for each group of taps with equal temporal offset (<= 9: the 3x3 footprint), for each 64-channel chunk: stage the
+  // halo image and run the group's taps, fully unrolled -- the tap rows live in scalar registers (loaded once per group),
+  // ring slots and vmcnt counts are compile-time.  The weight tiles of the next BSLOTS-1 taps are in flight across
+  // each step's barrier; the last steps of a block issue zero-page DMAs so that the counts stay exact.
+  constexpr int GT = 9;
+#ifdef VINET_CONV_TIMING
+  const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
+  int t0 = 0;
+  while (t0 < a.ntaps) {
+    // tap rows of the group, packed into scalar registers: (slice << 8 | halo offset + 128) in 16 bits each
+    unsigned long long tq0 = 0, tq1 = 0;
+    uint32_t tq2 = 0;
+    const int dt = load_tap(a.taps, t0).x;
+    int nt = 0;
 #pragma unroll
-  for (int s = 0; s < BSLOTS - 1; ++s) {
-    issue_b(s, ci);
-    advance(ci);
-  }
-  int slot = 0, fill = BSLOTS - 1;
-  for (int s = 0; s < nsteps; ++s) {
-    if (cc.t == cc.t0) {                           // new (temporal tap, channel chunk): re-stage the halo image
-      __builtin_amdgcn_s_barrier();                // everyone has finished reading the old one
-      asm volatile("" ::: "memory");
-      issue_halo(cc);
-      wait_vmcnt<0>();
-    } else {
-      wait_vmcnt<BL*(BSLOTS - 2)>();               // my weight DMAs of this step have landed
+    for (int j = 0; j < GT; ++j) {
+      const bool in = (t0 + j < a.ntaps) && (nt == j);
+      const int4 tp = load_tap(a.taps, t0 + j < a.ntaps ? t0 + j : t0);
+      const bool same = in && tp.x == dt;
+      const unsigned long long e = (unsigned long long)(((tp.w & 0xff) << 8) | ((tp.y * HW + tp.z + 128) & 0xff));
+      if (j < 4) tq0 |= e << (j * 16);
+      else if (j < 8) tq1 |= e << ((j - 4) * 16);
+      else tq2 = (uint32_t)e;
+      nt += same ? 1 : 0;
     }
-    __builtin_amdgcn_s_barrier();                  // everyone's have; everyone finished reading slot `fill`
-    asm volatile("" ::: "memory");
-    issue_b(fill, ci);
-    advance(ci);
-    compute(slot, cc);
-    advance(cc);
-    asm volatile("" ::: "memory");
-    slot = slot + 1 == BSLOTS ? 0 : slot + 1;
-    fill = fill + 1 == BSLOTS ? 0 : fill + 1;
+    auto tap_word = [&](int j) {      // j may be >= nt (prefetch past the group): the caller masks with `live`
+      const unsigned long long q = j < 4 ? tq0 : tq1;
+      const uint32_t w16 = j < 8 ? (uint32_t)(q >> ((j & 3) * 16)) : tq2;
+      return w16 & 0xffffu;
+    };
+    for (int c0 = 0; c0 < a.Kp; c0 += 64) {
+#ifdef VINET_CONV_TIMING
+      tm_h0 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();                // everyone has finished reading the old halo image and ring
+      asm volatile("" ::: "memory");
+      issue_halo(dt, c0);
+#pragma unroll
+      for (int j = 0; j < BSLOTS - 1; ++j) issue_b(j, j < nt, (int)(tap_word(j) >> 8), c0);
+      int slot = 0, fill = BSLOTS - 1;
+      for (int j = 0; j < nt; ++j) {
+        wait_vmcnt<BL*(BSLOTS - 2)>();             // halo image (first step) and my weight DMAs of this step have landed
+#ifdef VINET_CONV_TIMING
+        if (j == 0) tm_halo += __builtin_amdgcn_s_memtime() - tm_h0;
+#endif
+        __builtin_amdgcn_s_barrier();              // everyone's have; everyone finished reading slot `fill`
+        asm volatile("" ::: "memory");
+        const int jn = j + BSLOTS - 1;
+        issue_b(fill, jn < nt, (int)(tap_word(jn < GT ? jn : 0) >> 8), c0);
+        compute(slot, (int)(tap_word(j) & 0xffu) - 128);
+        asm volatile("" ::: "memory");
+        slot = slot + 1 == BSLOTS ? 0 : slot + 1;
+        fill = fill + 1 == BSLOTS ? 0 : fill + 1;
+      }
+    }
+    t0 += nt;
   }
   wait_vmcnt<0>();
   mfma_drain();
   __syncthreads();
-  conv_epilogue<MT, NT, 4, 1>(a, acc, smem, (int)sp, tile_n, mb);
+#ifdef VINET_CONV_TIMING
+  const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+  const float* dbg_ptr = a.out_shift;
+  ConvArgs a2 = a;
+  a2.out_shift = nullptr; a2.out_scale = nullptr;
+  conv_epilogue<MT, NT, 4, 1>(a2, acc, smem, (int)sp, tile_n, &er);
+  if (tid == 0 && dbg_ptr) {   // tuning build only: out_shift doubles as a [grid][4] float dump
+    const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+    float* dbg = (float*)dbg_ptr + (long)blockIdx.x * 4;
+    dbg[0] = (float)(tm1 - tm0); dbg[1] = (float)(tm2 - tm1); dbg[2] = (float)(tm3 - tm2); dbg[3] = (float)tm_halo;
+  }
+#else
+  conv_epilogue<MT, NT, 4, 1>(a, acc, smem, (int)sp, tile_n, &er);
+#endif
 }
 
 template <int NT, int TW, int BSLOTS>

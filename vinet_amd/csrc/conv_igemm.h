@@ -64,6 +64,14 @@ VN_DEV int conv_tile_perm(const ConvArgs& a, int i) {
   return (int)((b * (uint32_t)a.perm_T + t) * (uint32_t)a.perm_P + c);
 }
 
+// LDS the epilogue needs behind a K loop (every kernel sizes its dynamic LDS with max(K loop, this))
+template <int MT, int NT, int WARPS_M, int WARPS_N>
+constexpr int conv_epi_bytes() {
+  constexpr int W = WARPS_M * WARPS_N, WNC = NT * 16, BN = WNC * WARPS_N, GP = MT < 4 ? MT : 4;
+  constexpr int general = W * 16 * (WNC + 4) * 4, fast8 = W * GP * 16 * (WNC + 8) * 2;
+  return (general > fast8 ? general : fast8) + WARPS_M * BN * 2 * 4;
+}
+
 template <typename T, int MT, int NT, int WARPS_M, int WARPS_N>
 struct ConvCfg {
   static constexpr int BM = 16 * MT * WARPS_M;
@@ -77,7 +85,7 @@ struct ConvCfg {
   static constexpr int WNC = NT * 16;                   // columns per wave
   static constexpr int EROW = WNC + 4;                  // epilogue LDS row stride (floats)
   static constexpr int KLOOP_BYTES = 2 * (A_BYTES + B_BYTES);
-  static constexpr int EPI_BYTES = 4 * 16 * EROW * 4 + WARPS_M * BN * 2 * 4;
+  static constexpr int EPI_BYTES = conv_epi_bytes<MT, NT, WARPS_M, WARPS_N>();
   static constexpr int SMEM = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
 };
 
@@ -93,26 +101,98 @@ VN_DEV void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// `mb` (optional): the tile's rows are not consecutive voxels (spatial halo tiles, conv_ht.h): mb[i] is the linear
-// voxel index of the first row of this wave's 16-row group i, or < 0 when the whole group lies outside the iteration
-// space; nullptr = rows tile_m*BM + ... as usual.  `tile_m` stays the statistics row of the workgroup.
+// Row -> voxel map of a wave's 16-row groups.  Row-tiled kernels: group i starts at voxel m0 + 16 i (ipr == 0).  Spatial
+// halo tiles (conv_ht.h): a wave owns `ipr` groups per image row, group i starts at m0 + (i / ipr) * rstride + (i % ipr) * 16
+// and is inside the iteration space iff i / ipr < nrows.
+struct EpiRows {
+  int m0, ipr, rstride, nrows;
+};
+
+// `rows` (optional): see EpiRows; nullptr = rows tile_m*BM + ... as usual.  `tile_m` stays the statistics row of the workgroup.
 template <int MT, int NT, int WARPS_M, int WARPS_N>
-VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem, int tile_m, int tile_n, const int* mb = nullptr) {
+VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem, int tile_m, int tile_n, const EpiRows* rows = nullptr) {
   constexpr int BM = 16 * MT * WARPS_M, BN = 16 * NT * WARPS_N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   constexpr int WNC = NT * 16, EROW = WNC + 4;
   float* Ew = (float*)smem + wave * (16 * EROW);
-  float* red = (float*)smem + (WARPS_M * WARPS_N) * 16 * EROW;
+  float* red = (float*)(smem + conv_epi_bytes<MT, NT, WARPS_M, WARPS_N>() - WARPS_M * BN * 2 * 4);
   const int m_wave = tile_m * BM + wm * MT * 16;
   const int n_wave = tile_n * BN + wn * WNC;
   const bool do_stats = a.stats != nullptr;
   const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;   // branch-free ReLU: max(v, floor)
+  const EpiRows er = rows ? *rows : EpiRows{m_wave, 0, 0, 0};
+  // first voxel of row group i, and how many of its 16 rows lie inside the iteration space
+  auto group_m0 = [&](int i) { return er.ipr ? er.m0 + (i / er.ipr) * er.rstride + (i % er.ipr) * 16 : er.m0 + i * 16; };
+  auto group_rows = [&](int i) { return er.ipr ? ((i / er.ipr) < er.nrows ? 16 : 0) : a.M - (er.m0 + i * 16); };
 
   // per-column epilogue constants and running BN partial sums (accumulated row group by row
   // group below, so only ONE 16-row group of the accumulator is live in VGPRs at a time:
   // a 128-register accumulator tile leaves no room for a whole-tile first pass)
-  float sc[NT], sh[NT], s_sum[NT], s_sq[NT];
+  float s_sum[NT], s_sq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { s_sum[j] = 0.f; s_sq[j] = 0.f; }
+  const bool sigm = a.act == VINET_ACT_SIGMOID;
+  const bool fast = a.vec_ok && !a.out_f32 && !a.accumulate && a.y_linear;
+
+  // ---- the fast path proper: bf16 rows of whole 8-channel groups, 16-byte aligned --------------------------------------
+  // The epilogue is VALU-issue bound (s_memtime: 20k cycles per 256 x 96 tile, as long as the nine K steps of a 64-channel
+  // 3x3 conv), so this path spends as few instructions per element as the job allows: values are rounded to bf16 by
+  // v_cvt_pk_bf16_f32 BEFORE the LDS transposition (statistics are taken from the fp32 values first); the staging tile
+  // is bf16 and holds up to four row groups (64 rows x all columns of the wave), so one pair of wave-level fences serves
+  // 64 rows and the column constants are scalars of the outer loop, not arrays that live beside a 128-register
+  // accumulator; one conflict-free ds_read_b128 = 8 channels of one voxel; stores are 16 bytes per lane (half as many
+  // store instructions: the store queue, not bandwidth, paces a write burst).
+  if (fast && !sigm && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (((uintptr_t)a.y) & 15) == 0) {
+    constexpr int GP = MT < 4 ? MT : 4;               // row groups per staging pass
+    constexpr int EROWH = WNC + 8;                    // staging row stride in bf16 (16-byte multiple; rows 4 apart sit 16 banks apart)
+    constexpr int VPR8 = WNC / 8, IT8 = (GP * 16 * VPR8 + 63) / 64;
+    static_assert(MT % GP == 0, "row groups per pass");
+    bf16_t* Eh = (bf16_t*)smem + wave * (GP * 16 * EROWH);
+#pragma unroll
+    for (int pass = 0; pass < MT / GP; ++pass) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n_wave + j * 16 + (lane & 15);
+        const bool nokj = n < a.Nw;
+        const float scj = (a.out_scale && nokj) ? a.out_scale[n] : 1.f;
+        const float shj = (a.out_shift && nokj) ? a.out_shift[n] : 0.f;
+        float ss = s_sum[j], qq = s_sq[j];
+#pragma unroll
+        for (int ii = 0; ii < GP; ++ii) {
+          const int i = pass * GP + ii;
+          const int mlim = group_rows(i);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) * 4 + r;
+            float av;      // explicit read: the accumulator stays in the AGPR file until this very use
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av) : "a"(acc[i][j][r]));
+            const float v = fmaf(av, scj, shj);
+            const float vs = (nokj && row < mlim) ? v : 0.f;
+            ss += vs; qq += vs * vs;
+            const float o = fmaxf(v, relu_floor);
+            uint32_t pk;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(pk) : "v"(o));
+            Eh[(ii * 16 + row) * EROWH + j * 16 + (lane & 15)] = (bf16_t)pk;
+          }
+        }
+        s_sum[j] = ss; s_sq[j] = qq;
+        __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: hoisted accumulator reads of later tiles spill
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int k = 0; k < IT8; ++k) {
+        const int e = lane + 64 * k;
+        const int rrow = e / VPR8, cc = (e - rrow * VPR8) * 8;     // staging row (0 .. GP*16), first of 8 channels
+        const int i = pass * GP + (rrow >> 4), rr = rrow & 15;
+        const uint4 v = *(const uint4*)&Eh[rrow * EROWH + cc];
+        if (e < GP * 16 * VPR8 && n_wave + cc < a.N && rr < group_rows(i))
+          *(uint4*)((bf16_t*)a.y + ((long)(group_m0(i) + rr) * a.ldy + n_wave + cc)) = v;
+      }
+      wave_lds_fence();
+    }
+  } else {
+  float sc[NT], sh[NT];
   bool nok[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -120,12 +200,7 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     nok[j] = n < a.Nw;
     sc[j] = (a.out_scale && nok[j]) ? a.out_scale[n] : 1.f;
     sh[j] = (a.out_shift && nok[j]) ? a.out_shift[n] : 0.f;
-    s_sum[j] = 0.f; s_sq[j] = 0.f;
   }
-  const bool sigm = a.act == VINET_ACT_SIGMOID;
-
-  // common case: bf16 output, 4-channel vectors, plain store, output offset linear in m
-  const bool fast = a.vec_ok && !a.out_f32 && !a.accumulate && a.y_linear;
   constexpr int VPR = WNC / 4;             // 4-channel vectors per tile row
   constexpr int ITERS = (16 * VPR) / 64;   // store instructions per lane per row group
   static_assert((16 * VPR) % 64 == 0, "row group must divide over the wave");
@@ -135,9 +210,11 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = (mb ? mb[i] : m_wave + i * 16) + (lane >> 4) * 4 + r;
-        const bool mok = mb ? mb[i] >= 0 : m < a.M;
-        const float v = fmaf(acc[i][j][r], sc[j], sh[j]);
+        const int m = group_m0(i) + (lane >> 4) * 4 + r;
+        const bool mok = (lane >> 4) * 4 + r < group_rows(i);
+        float av;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av) : "a"(acc[i][j][r]));
+        const float v = fmaf(av, sc[j], sh[j]);
         const float vs = (nok[j] && mok) ? v : 0.f;
         s_sum[j] += vs; s_sq[j] += vs * vs;
         float o = fmaxf(v, relu_floor);
@@ -150,8 +227,8 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
       for (int k = 0; k < ITERS; ++k) {
         const int e = lane + 64 * k;
         const int rr = e / VPR, cc = (e % VPR) * 4;
-        const int m = (mb ? mb[i] : m_wave + i * 16) + rr;
-        const bool mok = mb ? mb[i] >= 0 : m < a.M;
+        const int m = group_m0(i) + rr;
+        const bool mok = rr < group_rows(i);
         const int n = n_wave + cc;
         const float4 v = *(const float4*)&Ew[rr * EROW + cc];
         if (mok && n < a.N)
@@ -160,8 +237,8 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     } else {
       for (int e = lane; e < 16 * VPR; e += 64) {
         const int rr = e / VPR, cc = (e % VPR) * 4;
-        const int m = (mb ? mb[i] : m_wave + i * 16) + rr;
-        const bool mok = mb ? mb[i] >= 0 : m < a.M;
+        const int m = group_m0(i) + rr;
+        const bool mok = rr < group_rows(i);
         const int n = n_wave + cc;
         if (mok && n < a.N) {
           const float4 v = *(const float4*)&Ew[rr * EROW + cc];
@@ -209,6 +286,7 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     wave_lds_fence();   // all lanes have read this row group before the next one overwrites it
   }
 
+  }   // (general path)
   if (do_stats) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
