@@ -169,6 +169,8 @@ CONV_CASES = [
     ("xslice_pw", (2, 2, 6, 8), 256, 176, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(pre=True, stats=True, in_ld=368, in_coff=112,
                                                                               out_ld=480, out_coff=0)),
     ("xslice_plain", (1, 3, 6, 6), 64, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(in_ld=104, in_coff=40, act=1)),
+    # a stride phase of a data gradient: rows stored to every 3rd frame of a longer tensor (plain store: the 16-byte epilogue path)
+    ("phase_store", (2, 4, 7, 9), 96, 160, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(om=(3, 1))),
 ]
 
 
@@ -248,6 +250,7 @@ HT_CASES = [
     ("ht_slices", (2, 2, 8, 32), 64, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(in_ld=160, in_coff=32, out_ld=256, out_coff=64, stats=True)),
     ("ht_tslice_in", (2, 6, 8, 16), 32, 48, (3, 3, 3), (3, 1, 1), (0, 1, 1), dict(in_ttotal=8, in_toff=1)),
     ("ht_phase_acc", (2, 3, 8, 32), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(accumulate=True, om=(5, 2))),
+    ("ht_phase_store", (2, 3, 12, 32), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(om=(5, 3))),
     ("ht_f32_out", (1, 1, 16, 32), 32, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(out_f32=True, epi_shift=True)),
 ]
 

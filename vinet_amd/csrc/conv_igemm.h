@@ -143,7 +143,9 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   // 64 rows and the column constants are scalars of the outer loop, not arrays that live beside a 128-register
   // accumulator; one conflict-free ds_read_b128 = 8 channels of one voxel; stores are 16 bytes per lane (half as many
   // store instructions: the store queue, not bandwidth, paces a write burst).
-  if (fast && !sigm && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (((uintptr_t)a.y) & 15) == 0) {
+  // (any output placement: a stride phase of a data gradient scatters its rows over a longer tensor)
+  if (a.vec_ok && !a.out_f32 && !sigm && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (a.sBy & 7) == 0 &&
+      (((uintptr_t)a.y) & 15) == 0) {
     constexpr int GP = MT < 4 ? MT : 4;               // row groups per staging pass
     constexpr int EROWH = WNC + 8;                    // staging row stride in bf16 (16-byte multiple; rows 4 apart sit 16 banks apart)
     constexpr int VPR8 = WNC / 8, IT8 = (GP * 16 * VPR8 + 63) / 64;
@@ -180,14 +182,54 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
         __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: hoisted accumulator reads of later tiles spill
       }
       wave_lds_fence();
-#pragma unroll
-      for (int k = 0; k < IT8; ++k) {
+      // (accumulate: y += result, both operands bf16 -- the old values are fetched four stores ahead)
+      auto item = [&](int k, bool& ok, long& off, uint4& v) {
         const int e = lane + 64 * k;
         const int rrow = e / VPR8, cc = (e - rrow * VPR8) * 8;     // staging row (0 .. GP*16), first of 8 channels
         const int i = pass * GP + (rrow >> 4), rr = rrow & 15;
-        const uint4 v = *(const uint4*)&Eh[rrow * EROWH + cc];
-        if (e < GP * 16 * VPR8 && n_wave + cc < a.N && rr < group_rows(i))
-          *(uint4*)((bf16_t*)a.y + ((long)(group_m0(i) + rr) * a.ldy + n_wave + cc)) = v;
+        v = *(const uint4*)&Eh[rrow * EROWH + cc];
+        ok = e < GP * 16 * VPR8 && n_wave + cc < a.N && rr < group_rows(i);
+        const int m = group_m0(i) + rr;
+        if (a.y_linear) {
+          off = (long)m * a.ldy;
+        } else {
+          int b, to, ho, wo;
+          decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
+          off = (long)b * a.sBy + ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) * (long)a.ldy;
+        }
+        off += n_wave + cc;
+      };
+      if (!a.accumulate) {
+#pragma unroll
+        for (int k = 0; k < IT8; ++k) {
+          bool ok; long off; uint4 v;
+          item(k, ok, off, v);
+          if (ok) *(uint4*)((bf16_t*)a.y + off) = v;
+        }
+      } else {
+        constexpr int CH = IT8 < 4 ? IT8 : 4;
+#pragma unroll
+        for (int k0 = 0; k0 < IT8; k0 += CH) {
+          bool ok[CH]; long off[CH]; uint4 v[CH], q[CH];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            ok[c] = false; off[c] = 0; v[c] = make_uint4(0, 0, 0, 0);
+            if (k0 + c < IT8) item(k0 + c, ok[c], off[c], v[c]);
+            q[c] = ok[c] ? *(const uint4*)((const bf16_t*)a.y + off[c]) : make_uint4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const uint32_t vw[4] = {v[c].x, v[c].y, v[c].z, v[c].w}, qw[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+              const float lo = __uint_as_float(vw[h] << 16) + __uint_as_float(qw[h] << 16);
+              const float hi = __uint_as_float(vw[h] & 0xffff0000u) + __uint_as_float(qw[h] & 0xffff0000u);
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ow[h]) : "v"(lo), "v"(hi));
+            }
+            if (ok[c]) *(uint4*)((bf16_t*)a.y + off[c]) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+          }
+        }
       }
       wave_lds_fence();
     }
