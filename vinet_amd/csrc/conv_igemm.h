@@ -125,6 +125,13 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   // first voxel of row group i, and how many of its 16 rows lie inside the iteration space
   auto group_m0 = [&](int i) { return er.ipr ? er.m0 + (i / er.ipr) * er.rstride + (i % er.ipr) * 16 : er.m0 + i * 16; };
   auto group_rows = [&](int i) { return er.ipr ? ((i / er.ipr) < er.nrows ? 16 : 0) : a.M - (er.m0 + i * 16); };
+  // element offset of voxel m (channel 0) in y: any placement (a stride phase of a data gradient scatters its rows)
+  auto voxel_off = [&](int m) {
+    if (a.y_linear) return (long)m * a.ldy;
+    int b, to, ho, wo;
+    decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
+    return (long)b * a.sBy + ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) * (long)a.ldy;
+  };
 
   // per-column epilogue constants and running BN partial sums (accumulated row group by row
   // group below, so only ONE 16-row group of the accumulator is live in VGPRs at a time:
@@ -144,7 +151,8 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   // accumulator; one conflict-free ds_read_b128 = 8 channels of one voxel; stores are 16 bytes per lane (half as many
   // store instructions: the store queue, not bandwidth, paces a write burst).
   // (any output placement: a stride phase of a data gradient scatters its rows over a longer tensor)
-  if (a.vec_ok && !a.out_f32 && !sigm && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (a.sBy & 7) == 0 &&
+  const bool fast8 = a.vec_ok && !a.out_f32 && !sigm && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (a.sBy & 7) == 0 && (((uintptr_t)a.y) & 15) == 0;
+  if (fast8 && !a.accumulate && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (a.sBy & 7) == 0 &&
       (((uintptr_t)a.y) & 15) == 0) {
     constexpr int GP = MT < 4 ? MT : 4;               // row groups per staging pass
     constexpr int EROWH = WNC + 8;                    // staging row stride in bf16 (16-byte multiple; rows 4 apart sit 16 banks apart)
@@ -182,53 +190,83 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
         __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: hoisted accumulator reads of later tiles spill
       }
       wave_lds_fence();
-      // (accumulate: y += result, both operands bf16 -- the old values are fetched four stores ahead)
       auto item = [&](int k, bool& ok, long& off, uint4& v) {
         const int e = lane + 64 * k;
         const int rrow = e / VPR8, cc = (e - rrow * VPR8) * 8;     // staging row (0 .. GP*16), first of 8 channels
         const int i = pass * GP + (rrow >> 4), rr = rrow & 15;
         v = *(const uint4*)&Eh[rrow * EROWH + cc];
         ok = e < GP * 16 * VPR8 && n_wave + cc < a.N && rr < group_rows(i);
-        const int m = group_m0(i) + rr;
-        if (a.y_linear) {
-          off = (long)m * a.ldy;
-        } else {
-          int b, to, ho, wo;
-          decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
-          off = (long)b * a.sBy + ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) * (long)a.ldy;
-        }
-        off += n_wave + cc;
+        off = voxel_off(group_m0(i) + rr) + n_wave + cc;
       };
-      if (!a.accumulate) {
 #pragma unroll
-        for (int k = 0; k < IT8; ++k) {
-          bool ok; long off; uint4 v;
-          item(k, ok, off, v);
-          if (ok) *(uint4*)((bf16_t*)a.y + off) = v;
+      for (int k = 0; k < IT8; ++k) {
+        bool ok; long off; uint4 v;
+        item(k, ok, off, v);
+        if (ok) *(uint4*)((bf16_t*)a.y + off) = v;
+      }
+      wave_lds_fence();
+    }
+  } else if (fast8 && a.accumulate) {
+    // y += result (the data gradients that join an existing gradient): ONE rounding, of old + new in fp32 -- so the staging
+    // tile stays fp32, half as many row groups per pass; the old values are fetched two stores ahead (more spill the 128-register tiles)
+    constexpr int GP = MT < 4 ? (MT < 2 ? 1 : MT / 2) : 2;
+    constexpr int EROWF = WNC + 4;
+    constexpr int VPR8 = WNC / 8, IT8 = (GP * 16 * VPR8 + 63) / 64, CH = IT8 < 2 ? IT8 : 2;
+    static_assert(MT % GP == 0, "row groups per pass");
+    float* Ef = (float*)smem + wave * (GP * 16 * EROWF);
+#pragma unroll
+    for (int pass = 0; pass < MT / GP; ++pass) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n_wave + j * 16 + (lane & 15);
+        const bool nokj = n < a.Nw;
+        const float scj = (a.out_scale && nokj) ? a.out_scale[n] : 1.f;
+        const float shj = (a.out_shift && nokj) ? a.out_shift[n] : 0.f;
+        float ss = s_sum[j], qq = s_sq[j];
+#pragma unroll
+        for (int ii = 0; ii < GP; ++ii) {
+          const int i = pass * GP + ii;
+          const int mlim = group_rows(i);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) * 4 + r;
+            float av;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av) : "a"(acc[i][j][r]));
+            const float v = fmaf(av, scj, shj);
+            const float vs = (nokj && row < mlim) ? v : 0.f;
+            ss += vs; qq += vs * vs;
+            Ef[(ii * 16 + row) * EROWF + j * 16 + (lane & 15)] = fmaxf(v, relu_floor);
+          }
         }
-      } else {
-        constexpr int CH = IT8 < 4 ? IT8 : 4;
+        s_sum[j] = ss; s_sq[j] = qq;
+      }
+      wave_lds_fence();
 #pragma unroll
-        for (int k0 = 0; k0 < IT8; k0 += CH) {
-          bool ok[CH]; long off[CH]; uint4 v[CH], q[CH];
+      for (int k0 = 0; k0 < IT8; k0 += CH) {
+        bool ok[CH]; long off[CH]; uint4 q[CH]; int rd[CH];
 #pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            ok[c] = false; off[c] = 0; v[c] = make_uint4(0, 0, 0, 0);
-            if (k0 + c < IT8) item(k0 + c, ok[c], off[c], v[c]);
-            q[c] = ok[c] ? *(const uint4*)((const bf16_t*)a.y + off[c]) : make_uint4(0, 0, 0, 0);
+        for (int c = 0; c < CH; ++c) {
+          const int e = lane + 64 * (k0 + c);
+          const int rrow = e / VPR8, cc = (e - rrow * VPR8) * 8;
+          const int i = pass * GP + (rrow >> 4), rr = rrow & 15;
+          ok[c] = (k0 + c < IT8) && e < GP * 16 * VPR8 && n_wave + cc < a.N && rr < group_rows(i);
+          off[c] = voxel_off(group_m0(i) + rr) + n_wave + cc;
+          rd[c] = rrow * EROWF + cc;
+          q[c] = ok[c] ? *(const uint4*)((const bf16_t*)a.y + off[c]) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float4 v0 = *(const float4*)&Ef[ok[c] ? rd[c] : 0], v1 = *(const float4*)&Ef[ok[c] ? rd[c] + 4 : 0];
+          const float vf[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          const uint32_t qw[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+          uint32_t ow[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const float lo = vf[2 * h] + __uint_as_float(qw[h] << 16);
+            const float hi = vf[2 * h + 1] + __uint_as_float(qw[h] & 0xffff0000u);
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ow[h]) : "v"(lo), "v"(hi));
           }
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            const uint32_t vw[4] = {v[c].x, v[c].y, v[c].z, v[c].w}, qw[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
-            uint32_t ow[4];
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-              const float lo = __uint_as_float(vw[h] << 16) + __uint_as_float(qw[h] << 16);
-              const float hi = __uint_as_float(vw[h] & 0xffff0000u) + __uint_as_float(qw[h] & 0xffff0000u);
-              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ow[h]) : "v"(lo), "v"(hi));
-            }
-            if (ok[c]) *(uint4*)((bf16_t*)a.y + off[c]) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-          }
+          if (ok[c]) *(uint4*)((bf16_t*)a.y + off[c]) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
       }
       wave_lds_fence();
