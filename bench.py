@@ -151,14 +151,16 @@ def main():
 
     if args.mode == "train":
         m.train()
-        opt = optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+        opt = optim.Adam(parallel.trainable_parameters(m), lr=1e-4)
         parallel.broadcast_parameters(opt)
+        buckets = parallel.GradientBuckets(opt)      # N > 1: bucketed RCCL all-reduce issued from the tape, overlapped with backward
 
         def train_step(ins, g_):
             opt.zero_grad()
+            buckets.begin_step()
             l = loss.kldiv(m(*ins), g_)
             l.backward()
-            parallel.allreduce_gradients(opt)
+            buckets.finish()
             opt.step()
             return l
 

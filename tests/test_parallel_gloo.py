@@ -106,3 +106,112 @@ def test_shard_batch():
     assert parallel.shard_batch(8, 0, 2) == (0, 4) and parallel.shard_batch(8, 1, 2) == (4, 8)
     with pytest.raises(AssertionError):
         parallel.shard_batch(7, 0, 2)
+
+
+# ---- ViNet-8 with BatchNorm: bucketed overlapped all-reduce == one flat all-reduce == torch DDP -------------------------------
+def _vinet8(seed):
+    from vinet_amd import model as VM
+    from vinet_amd import synth
+    m = VM.VideoSaliencyModel(num_clips=8)
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), seed))
+    return m.train()
+
+
+def _vinet_batch(B):
+    from vinet_amd import synth
+    return synth.clip(B, 8, 32, 32, 3).permute(0, 2, 1, 3, 4), synth.gt_map(B, 32, 32, 3)
+
+
+def _worker_vinet(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from tests.abi_emulator import AbiEmulator
+    from vinet_amd import _lib as L
+    from vinet_amd import engine as E
+    from vinet_amd import loss as VL
+    from vinet_amd import optim as VO
+    from vinet_amd import parallel
+    L._install_test_double(AbiEmulator())
+    E.set_default_dtype("fp32")
+    parallel.init_from_env(backend="gloo")
+    x, gt = _vinet_batch(world)
+    xs, gs = x[rank:rank + 1], gt[rank:rank + 1]
+    res = {}
+    # (a) one flat all-reduce after backward
+    m = _vinet8(7)
+    opt = VO.Adam(parallel.trainable_parameters(m), lr=1e-3)
+    opt.zero_grad()
+    VL.kldiv(m(xs), gs).backward()
+    parallel.allreduce_gradients(opt)
+    res["flat"] = opt.flat_g.clone() * opt.grad_scale
+    res["bn_rm"] = m.backbone.base1[0].bn_s.running_mean.clone()
+    # (b) bucketed, issued from the tape (tiny buckets: many of them, every split point exercised)
+    m = _vinet8(7)
+    opt = VO.Adam(parallel.trainable_parameters(m), lr=1e-3)
+    bk = parallel.GradientBuckets(opt, bucket_bytes=1 << 20)
+    assert len(bk.buckets) > 8 and bk.buckets[0][1] == opt.flat_g.numel() and bk.buckets[-1][0] == 0
+    opt.zero_grad()
+    bk.begin_step()
+    VL.kldiv(m(xs), gs).backward()
+    launched_in_backward = sum(bk._launched)
+    bk.finish()
+    res["bucketed"] = opt.flat_g.clone() * opt.grad_scale
+    res["launched_in_backward"] = launched_in_backward
+    res["nbuckets"] = len(bk.buckets)
+    # (c) torch DistributedDataParallel around the same module, torch.optim-style access to .grad
+    m = _vinet8(7)
+    ddp = parallel.ddp_wrap(m)
+    assert E.param_grad_mode() == "autograd"
+    VL.kldiv(ddp(xs), gs).backward()
+    res["ddp"] = torch.cat([p.grad.reshape(-1) for p in parallel.trainable_parameters(m)])
+    res["order"] = [p.numel() for p in parallel.trainable_parameters(m)]
+    # (d) torch.autograd.grad returns real parameter gradients in that mode
+    m2 = _vinet8(7)
+    ps = parallel.trainable_parameters(m2)[:4]
+    gl = torch.autograd.grad(VL.kldiv(m2(xs), gs), ps)
+    res["autograd_grad_ok"] = all(g is not None and g.shape == p.shape and float(g.abs().sum()) > 0 for g, p in zip(gl, ps)) and all(p.grad is None for p in ps)
+    E.set_param_grad_mode("fused")
+    torch.save(res, os.path.join(out, "vinet_rank%d.pt" % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("world", [2, 4])
+def test_vinet8_bucketed_allreduce_and_ddp(tmp_path, world):
+    """ViNet-8 (BatchNorm in training mode, per-replica statistics) on `world` gloo ranks: the bucketed all-reduce the tape
+    issues during backward, the one-shot flat all-reduce and torch's DistributedDataParallel around the same module
+    all produce the same averaged gradient; replicas agree; BatchNorm statistics stay per replica."""
+    port = _free_port()
+    mp.spawn(_worker_vinet, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, "vinet_rank%d.pt" % r)) for r in range(world)]
+    r0 = rs[0]
+    assert r0["nbuckets"] > 8 and r0["launched_in_backward"] >= r0["nbuckets"] - 1, "buckets must go out from inside backward"
+    assert r0["autograd_grad_ok"]
+    for r in rs[1:]:
+        assert torch.equal(r["flat"], r0["flat"]) and torch.equal(r["bucketed"], r0["bucketed"])
+        assert not torch.equal(r["bn_rm"], r0["bn_rm"]), "BatchNorm statistics are per replica (train.py:181-185 semantics)"
+    # (with more than two ranks the ring's summation order depends on the chunking of the tensor: equal to fp32 round-off)
+    if world == 2:
+        assert torch.equal(r0["bucketed"], r0["flat"]), "bucketing must not change the reduction"
+    db = (r0["bucketed"] - r0["flat"]).abs().max() / (r0["flat"].abs().max() + 1e-30)
+    assert float(db) < 1e-6, "bucketed and flat all-reduce disagree: %g" % float(db)
+    # flat buffer slots are 16-byte aligned: gather the parameter ranges before comparing with DDP's .grad
+    off, chunks = 0, []
+    for n in r0["order"]:
+        chunks.append(r0["flat"][off:off + n])
+        off += (n + 3) // 4 * 4
+    flat = torch.cat(chunks)
+    d = (flat - r0["ddp"]).abs().max() / (flat.abs().max() + 1e-30)
+    assert float(d) < 1e-5, "DDP and the flat all-reduce disagree: %g" % float(d)
+
+
+def test_trainable_parameters_skip_soundnet_heads():
+    """conv8_objs / conv8_scns (11.48 M parameters, model.py:788-791) never get a gradient: not in the buffer"""
+    from vinet_amd import model as VM
+    from vinet_amd import parallel
+    m = VM.VideoAudioSaliencyModel(num_clips=32)
+    allp = sum(p.numel() for p in m.parameters())
+    used = sum(p.numel() for p in parallel.trainable_parameters(m))
+    assert allp - used == 1024 * 1000 * 8 + 1000 + 1024 * 401 * 8 + 401

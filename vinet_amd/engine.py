@@ -42,7 +42,7 @@ STEM_FOLD = os.environ.get("VINET_STEM_FOLD", "1") != "0"   # padded/folded stem
 WGRAD_SIDE_STREAM = True
 # CUs the persistent weight-gradient kernels may occupy while they run beside the main stream (conv_api.hip: wgrad_cus);
 # without a second stream they are alone on the GPU and get all of it
-WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "96"))
+WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "144"))
 _WGRAD_CUS_SET = {}
 _SIDE_STREAMS = {}
 
@@ -735,6 +735,7 @@ class BNState:
         db = _param_grad(self.beta) if self.beta is not None and self.beta.requires_grad else None
         ctx.call("vinet_bn_bwd_finalize", ws.data_ptr() + o, rows, N, ld, float(M), scale.data_ptr() + o, 1 if train_bn else 0,
                  _ptr(dg), _ptr(db), invstd.data_ptr() + o, c1.data_ptr() + o, c2.data_ptr() + o, ctx.stream)
+        _note_param_grad(ctx, self.gamma, self.beta)
 
 
 class JointBN:
@@ -762,6 +763,19 @@ class JointBN:
     def bwd_finalize(self, ctx, ws, rows, N, M, scale, train_bn, invstd, c1, c2):
         for m, w, o in zip(self.members, self.widths, self.offs):
             m.bwd_finalize(ctx, ws, rows, w, M, scale, train_bn, invstd, c1, c2, off=o, ld=N)
+
+
+# Called as hook(ctx, param) when the tape has LAUNCHED the last kernel that writes `param`'s gradient in this backward
+# (weight gradients: on the side stream; BatchNorm / bias gradients: on the main stream).  vinet_amd.parallel's
+# GradientBuckets hangs its bucketed, overlapped all-reduce on it.  The current stream is the main stream when it fires.
+PARAM_GRAD_HOOK = None
+
+
+def _note_param_grad(ctx, *params):
+    if PARAM_GRAD_HOOK is not None:
+        for p in params:
+            if p is not None and p.requires_grad:
+                PARAM_GRAD_HOOK(ctx, p)
 
 
 def _param_grad(p):
@@ -1002,6 +1016,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         # channels modulo N leaves the real sums untouched
         assert Ny % plan.N == 0 and (Ny == plan.N or plan.N == 1)
         ctx.call("vinet_channel_sum", C.byref(dy.ct()), dy.dt, ws.data_ptr(), plan.N, gb.data_ptr(), 1, ctx.stream)
+        _note_param_grad(ctx, plan.bias)
     # ---- weight gradient (side stream) ---------------------------------------------
     if plan.wants_wgrad():
         for w_ in plan.grad_targets():
@@ -1040,6 +1055,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                         ctx.keep(dw, dy.buf, x.v.buf, x.scale, x.shift, *(fused_bnb[2:] if fused_bnb is not None else ()))
                 finally:
                     ctx.stream = main_ptr
+            _note_param_grad(ctx, *plan.grad_targets())
 
         # The decoder's weight gradients (convs without BatchNorm: MFMA-bound, persistent, LDS-heavy) would run beside the
         # decoder's data gradients, which are MFMA-bound too: both lose.  Deferred, they start when the tape reaches the
@@ -1171,10 +1187,31 @@ def unfold1d_forward(ctx, x, k, stride, pad):
 # autograd entry point: one node per root module call
 # ----------------------------------------------------------------------------
 
+# How parameter gradients leave a root module's backward:
+#   "fused"    (default) the tape's kernels accumulate straight into `param.grad` (views of the optimizer's flat buffer
+#              when vinet_amd.optim.Adam is used) and the autograd node returns None for parameters: no extra pass;
+#   "autograd" the node RETURNS the parameter gradients and autograd's own AccumulateGrad nodes add them to `.grad`,
+#              so `torch.autograd.grad(loss, params)`, gradient hooks and torch's DistributedDataParallel (whose
+#              reducer hangs its bucket hooks on those nodes, train.py:181-185 wraps the reference module the same
+#              way with nn.DataParallel) see this module like any nn.Module.  Costs one fill + one add per parameter.
+_PARAM_GRAD_MODE = os.environ.get("VINET_PARAM_GRAD_MODE", "fused")
+
+
+def set_param_grad_mode(mode):
+    global _PARAM_GRAD_MODE
+    assert mode in ("fused", "autograd")
+    _PARAM_GRAD_MODE = mode
+
+
+def param_grad_mode():
+    return _PARAM_GRAD_MODE
+
+
 class _TapeFn(torch.autograd.Function):
     """Runs `body.run` on the engine.  Forward records the tape; backward seeds
     the output gradients, replays the tape (which accumulates parameter
-    gradients straight into `.grad`) and returns the input gradients."""
+    gradients straight into `.grad`) and returns the input gradients -- and, in
+    "autograd" mode, the parameter gradients (see _PARAM_GRAD_MODE)."""
 
     @staticmethod
     def forward(fctx, body, n_in, *tensors):
@@ -1182,14 +1219,30 @@ class _TapeFn(torch.autograd.Function):
         ectx = body.make_ctx(inputs[0].device, record=True)
         outs, state = body.run(ectx, inputs, [t.requires_grad for t in inputs])
         fctx.body, fctx.ectx, fctx.state, fctx.n_par = body, ectx, state, len(tensors) - n_in
+        fctx.params = tensors[n_in:]
         return tuple(outs)
 
     @staticmethod
     def backward(fctx, *gouts):
         ectx = fctx.ectx
         ectx.stream = _stream_for(ectx.device)
-        gin = fctx.body.seed(ectx, fctx.state, gouts)
-        return (None, None) + tuple(gin) + (None,) * fctx.n_par
+        if _PARAM_GRAD_MODE == "fused":
+            gin = fctx.body.seed(ectx, fctx.state, gouts)
+            return (None, None) + tuple(gin) + (None,) * fctx.n_par
+        # "autograd": let the tape write into fresh buffers, hand them back, leave `.grad` to AccumulateGrad
+        params = fctx.params
+        saved = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        try:
+            gin = fctx.body.seed(ectx, fctx.state, gouts)
+            grads = [p.grad for p in params]
+        finally:
+            for p, g in zip(params, saved):
+                p.grad = g
+        base = 2 + len(gin)
+        grads = [g if fctx.needs_input_grad[base + i] else None for i, g in enumerate(grads)]
+        return (None, None) + tuple(gin) + tuple(grads)
 
 
 def run_root(body, inputs, params):

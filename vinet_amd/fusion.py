@@ -30,6 +30,7 @@ def bilinear_forward(ctx, bil, y0, audio, out_thw):
             gb = E._param_grad(bias) if (bias is not None and bias.requires_grad) else None
             ctx.call("vinet_bilinear_bwd", v1.ptr(), v2.ptr(), dg.ptr(), ctx.dt, w.data_ptr(), B, Cc, I, J, O,
                      d1.ptr() if d1 else None, d2.ptr() if d2 else None, E._ptr(gw), E._ptr(gb), ctx.stream)
+            E._note_param_grad(ctx, w, bias)
             if d1 is not None:
                 x1.mark_grad_ready()
             if d2 is not None:

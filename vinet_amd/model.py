@@ -270,6 +270,9 @@ class SoundNet(nn.Module):
     on a raw waveform [B,1,L,1] -> [B,1024,3,1].  conv8_objs / conv8_scns exist in
     the checkpoint but are never used in forward (model.py:788-791)."""
     compute_dtype = None
+    # never touched by forward (model.py:788-791, 793-825): kept for checkpoint compatibility, kept OUT of the optimizer's
+    # flat buffer and the gradient all-reduce (vinet_amd.parallel.trainable_parameters)
+    unused_parameter_names = ("conv8_objs.weight", "conv8_objs.bias", "conv8_scns.weight", "conv8_scns.bias")
 
     def __init__(self):
         super().__init__()
@@ -302,10 +305,12 @@ class SoundNet(nn.Module):
 
 
 class VideoAudioSaliencyModel(nn.Module):
-    """model.py:191-249, use_transformer=False.  Unlike the reference the SoundNet
-    weights are not read from ./soundnet8_final.pth inside the constructor
-    (model.py:224); call `load_soundnet(path)` or load a full state_dict."""
+    """model.py:191-249, use_transformer=False.  Like the reference the constructor
+    reads the SoundNet weights from ./soundnet8_final.pth (model.py:224) when that
+    file is there; the reference fails without it, here the branch then keeps its
+    default init and says so (load a full state_dict or call `load_soundnet(path)`)."""
     compute_dtype = None
+    soundnet_checkpoint = "./soundnet8_final.pth"
 
     def __init__(self, use_transformer=False, transformer_in_channel=32, num_encoder_layers=3, nhead=4,
                  use_upsample=True, num_hier=3, num_clips=32):
@@ -315,6 +320,12 @@ class VideoAudioSaliencyModel(nn.Module):
         self.use_transformer = False
         self.visual_model = VideoSaliencyModel(transformer_in_channel, nhead, use_upsample, num_hier, num_clips)
         self.audionet = SoundNet()
+        import os
+        if os.path.isfile(self.soundnet_checkpoint):
+            self.load_soundnet(self.soundnet_checkpoint)
+            print("Loaded SoundNet Weights")
+        else:
+            print("SoundNet weights? (%s not found: default init)" % self.soundnet_checkpoint)
         self.maxpool = _Marker("maxpool3d", kernel_size=(4, 1, 1), stride=(2, 1, 2), padding=(0, 0, 0))
         self.bilinear = _BilinearParams(42, 3, 4 * 7 * 12)
 

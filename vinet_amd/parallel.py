@@ -1,11 +1,26 @@
 """Clip-level data parallelism: one process per GPU, RCCL over xGMI.
 
 Replaces the reference's single-process `nn.DataParallel` (train.py:181-185).
-Clips are independent, so the only exchange per step is the gradient reduction:
-ONE all-reduce(SUM) over the optimizer's flat fp32 gradient buffer (124.4 MB for
+Clips are independent, so the only exchange per step is the gradient reduction: an
+all-reduce(SUM) over the optimizer's flat fp32 gradient buffer (124.4 MB for
 ViNet-32, no packing: the wgrad kernels accumulate straight into that buffer),
-averaged by folding 1/world into the fused Adam kernel.  BatchNorm statistics stay
-per replica, exactly as under DataParallel (replica-0 stats are the ones saved).
+averaged by folding 1/world into the fused Adam kernel.
+
+  * `GradientBuckets`: the flat buffer is cut into contiguous buckets in REVERSE
+    parameter order (the decoder -- 23.2 M of the 31.1 M parameters -- finishes its
+    backward first); a bucket's all-reduce is issued, asynchronously and on RCCL's
+    own stream, the moment the tape has launched the last kernel that writes one of
+    its gradients (engine.PARAM_GRAD_HOOK), ordered behind BOTH the main stream and
+    the weight-gradient side stream by events -- so the exchange overlaps the rest
+    of the backward pass.  `allreduce_gradients` is the one-shot form.
+  * parameters that never receive a gradient -- SoundNet's conv8_objs / conv8_scns,
+    11.48 M parameters the reference's forward never touches (model.py:788-791) --
+    stay out of the buffer: `trainable_parameters(model)`.
+  * BatchNorm statistics stay per replica, exactly as under DataParallel (whose
+    replica-0 statistics are the ones that survive a step); `broadcast_buffers`
+    makes every replica adopt rank 0's before a checkpoint or validation.
+  * the modules are also plain nn.Modules to torch's DistributedDataParallel:
+    `ddp_wrap(model)` switches the engine to engine.set_param_grad_mode("autograd").
 """
 import os
 
@@ -62,3 +77,115 @@ def allreduce_scalar_mean(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t /= dist.get_world_size()
     return t
+
+
+def trainable_parameters(model):
+    """parameters that take part in training: requires_grad and reachable from the forward pass.  Modules list the
+    ones their forward never uses in `unused_parameter_names` (AViNet: SoundNet's two classification heads)."""
+    skip = set()
+    for prefix, mod in model.named_modules():
+        for name in getattr(mod, "unused_parameter_names", ()):
+            skip.add((prefix + "." if prefix else "") + name)
+    return [p for n, p in model.named_parameters() if p.requires_grad and n not in skip]
+
+
+def broadcast_buffers(model, src=0):
+    """every replica adopts rank `src`'s buffers (BatchNorm running statistics: 85.5 KB for ViNet-32)"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for b in model.buffers():
+            dist.broadcast(b, src=src)
+
+
+def ddp_wrap(model, **kw):
+    """torch.nn.parallel.DistributedDataParallel around a vinet_amd module: the root autograd node then returns its
+    parameter gradients to autograd (engine 'autograd' mode) so DDP's bucket hooks fire."""
+    from . import engine
+    engine.set_param_grad_mode("autograd")
+    dev = next(model.parameters()).device
+    if dev.type == "cuda":
+        kw.setdefault("device_ids", [dev.index])
+    return torch.nn.parallel.DistributedDataParallel(model, **kw)
+
+
+class GradientBuckets:
+    """Bucketed all-reduce of vinet_amd.optim.Adam's flat gradient buffer, overlapped with the backward pass.
+
+        buckets = GradientBuckets(optimizer)           # once
+        optimizer.zero_grad(); buckets.begin_step()
+        loss.backward()                                # buckets go out as their gradients complete
+        buckets.finish(); optimizer.step()
+    """
+
+    def __init__(self, optimizer, bucket_bytes=25 << 20):
+        self.opt = optimizer
+        ps, offs = optimizer._params, optimizer._offs
+        total = optimizer.flat_g.numel()
+        self.buckets = []          # [lo, hi) element ranges of flat_g, last parameters first
+        self.index = {}
+        hi, members = total, []
+        for p, o in zip(reversed(ps), reversed(offs)):
+            members.append(p)
+            if (hi - o) * 4 >= bucket_bytes:
+                self._add(o, hi, members)
+                hi, members = o, []
+        if members:
+            self._add(0, hi, members)
+        self._works, self._pending, self._launched = [], [], []
+        self._comm_streams = {}
+
+    def _add(self, lo, hi, members):
+        for p in members:
+            self.index[id(p)] = len(self.buckets)
+        self.buckets.append((lo, hi, len(members)))
+
+    def active(self):
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def begin_step(self):
+        from . import engine
+        self._works = []
+        self._pending = [n for _, _, n in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        if self.active():
+            engine.PARAM_GRAD_HOOK = self._on_param
+        self.opt.grad_scale = 1.0 / dist.get_world_size() if self.active() else 1.0
+
+    def _on_param(self, ctx, p):
+        b = self.index.get(id(p))
+        if b is None or self._launched[b]:
+            return
+        self._pending[b] -= 1
+        if self._pending[b] <= 0:
+            self._launch(b, ctx)
+
+    def _launch(self, b, ctx=None):
+        lo, hi, _ = self.buckets[b]
+        t = self.opt.flat_g[lo:hi]
+        self._launched[b] = True
+        if t.is_cuda:
+            dev = t.device
+            comm = self._comm_streams.get(dev.index)
+            if comm is None:
+                comm = self._comm_streams[dev.index] = torch.cuda.Stream(dev)
+            comm.wait_stream(torch.cuda.current_stream(dev))              # BatchNorm / bias gradients and everything before them
+            side = ctx.side_stream() if ctx is not None else None
+            if side is not None:
+                comm.wait_stream(side)                                    # the weight-gradient kernels launched so far
+            with torch.cuda.stream(comm):
+                self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """buckets whose parameters got no (or not every) gradient this step go out now; then the optimizer's stream waits
+        for every bucket"""
+        from . import engine
+        engine.PARAM_GRAD_HOOK = None
+        if not self.active():
+            return
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works = []

@@ -142,6 +142,9 @@ def train_epoch(model, optimizer, loader, epoch, device, args, world=1):
         img_clips = sample[0].to(device).permute((0, 2, 1, 3, 4))
         gt_sal = sample[1].to(device)
         optimizer.zero_grad()
+        buckets = getattr(optimizer, "buckets", None)
+        if buckets is not None:
+            buckets.begin_step()
         if args.use_sound or args.use_vox:
             pred_sal = model(img_clips, sample[2].to(device))
         else:
@@ -149,7 +152,10 @@ def train_epoch(model, optimizer, loader, epoch, device, args, world=1):
         assert pred_sal.size() == gt_sal.size()
         loss = loss_func(pred_sal, gt_sal, args)
         loss.backward()
-        parallel.allreduce_gradients(optimizer)
+        if buckets is not None:
+            buckets.finish()                       # bucketed all-reduce, issued from the tape during backward
+        else:
+            parallel.allreduce_gradients(optimizer)
         optimizer.step()
         lv = float(parallel.allreduce_scalar_mean(loss.detach()))
         total_loss.update(lv)
@@ -229,9 +235,10 @@ def run(args, train_dataset=None, val_dataset=None):
         from . import dataloader
         train_loader.device_batch = dataloader.DeviceBatch(device, "train")
         val_loader.device_batch = dataloader.DeviceBatch(device, "val")
-    params = [p for p in model.parameters() if p.requires_grad]
+    params = parallel.trainable_parameters(model)
     optimizer = optim.Adam(params, lr=args.lr)
     parallel.broadcast_parameters(optimizer)
+    optimizer.buckets = parallel.GradientBuckets(optimizer)
     best_loss = None
     for epoch in range(args.no_epochs):
         if sampler is not None:
@@ -241,6 +248,8 @@ def run(args, train_dataset=None, val_dataset=None):
         if epoch == 0:
             val_loss = np.inf
             best_loss = val_loss
+        if world > 1:
+            parallel.broadcast_buffers(model)      # replicas keep their own BatchNorm statistics during an epoch; rank 0's are saved
         if val_loss <= best_loss and rank == 0:
             best_loss = val_loss
             print('[{:2d},  save, {}]'.format(epoch, args.model_val_path))
