@@ -561,11 +561,11 @@ class AbiEmulator:
     def vinet_upsample2x_bwd(self, dy, dx, dtype, accumulate, stream):
         dy, dx = _deref(dy), _deref(dx)
         g = torch.from_numpy(np.ascontiguousarray(rd(dy, dtype))).permute(0, 4, 1, 2, 3)
-        with torch.enable_grad():
-            xin = torch.zeros((dx.B, dx.C, dx.T, dx.H, dx.W), requires_grad=True)
-            out = torch.nn.functional.interpolate(xin, scale_factor=(1, 2, 2), mode="trilinear", align_corners=False)
-            out.backward(g)
-        wr(dx, dtype, xin.grad.permute(0, 2, 3, 4, 1).numpy(), bool(accumulate))
+        # transpose of the separable stencil, written out (no autograd: the custom-op tests call this below the autograd key)
+        def U(n):       # [n in, 2n out]: out[o] = sum_i U[i, o] x[i]
+            return torch.nn.functional.interpolate(torch.eye(n).unsqueeze(0), scale_factor=2, mode="linear", align_corners=False)[0]
+        gx = torch.einsum("io,bctop,jp->bctij", U(dx.H), g.float(), U(dx.W))
+        wr(dx, dtype, gx.permute(0, 2, 3, 4, 1).contiguous().numpy(), bool(accumulate))
         return 0
 
     # -- losses / optimizer -----------------------------------------------------------
@@ -602,9 +602,17 @@ class AbiEmulator:
 
     def vinet_loss_bwd(self, which, s, gt, gt_is_f64, B, n, saved, gscale, coeff, accumulate, ds, stream):
         sv, gv = self._loss_inputs(s, gt, gt_is_f64, B, n)
-        with torch.enable_grad():
-            sv.requires_grad_(True)
-            self._loss_value(which, sv, gv).mean().backward()
+
+        def run():
+            with torch.enable_grad():
+                sv.requires_grad_(True)
+                self._loss_value(which, sv, gv).mean().backward()
+        # (a fresh thread has default dispatch keys: when a torch.library custom op calls this below the autograd key,
+        #  autograd is off for the calling thread whatever enable_grad says)
+        import threading
+        th = threading.Thread(target=run)
+        th.start()
+        th.join()
         gs = float(_f32(gscale, 1)[0]) if gscale else 1.0
         g = (sv.grad * gs * coeff).numpy().astype(np.float32)
         d = _f32(ds, B * n).reshape(B, n)

@@ -433,3 +433,115 @@ def test_audio_visual_harness_with_avinet(tmp_path):
         got = np.asarray(Image.open(tmp_path / "out" / "v1" / ("%04d.png" % (o + 1)))).astype(int)
         # batch-2 calls in the harness vs batch 1 here: BN is in eval mode, so only bf16 accumulation order can differ
         assert np.abs(got - want.astype(int)).max() <= 2, (o, np.abs(got - want.astype(int)).max())
+
+
+def test_custom_ops_on_device():
+    """vinet_amd.ops (torch.library custom ops over the C ABI): conv3d forward / data gradient / weight gradient, pool and
+    upsample on the real library against torch's operators (fp32 exact path; bf16 within bf16 round-off)"""
+    import torch.nn.functional as F
+    from vinet_amd import ops
+    x = synth.normal("gopx", (2, 16, 4, 12, 16), 1)
+    w = synth.normal("gopw", (32, 16, 1, 3, 3), 2) * 0.1
+    b = synth.normal("gopb", (32,), 3)
+    proj = synth.normal("gopp", (2, 32, 4, 12, 16), 4)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.relu(F.conv3d(xr, wr, br, padding=(0, 1, 1)))
+    (ref * proj).sum().backward()
+    for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 4e-2)):
+        xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dt).requires_grad_(True)
+        wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        y = ops.conv3d(xc, wd, bd, (1, 1, 1), (0, 1, 1), act=L.ACT_RELU)
+        yn = y.permute(0, 4, 1, 2, 3).float()
+        assert float((yn.cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+        (yn * proj.to(DEV)).sum().backward()
+        assert MC.relerr(xc.grad.permute(0, 4, 1, 2, 3).float(), xr.grad) <= (1e-5 if dt == torch.float32 else 2e-2)
+        assert MC.relerr(wd.grad, wr.grad) <= (1e-5 if dt == torch.float32 else 2e-2)
+        assert MC.relerr(bd.grad, br.grad) <= (1e-5 if dt == torch.float32 else 2e-2)
+    xp = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV).requires_grad_(True)
+    z = ops.upsample2x(ops.maxpool3d(xp, (1, 3, 3), (1, 2, 2), (0, 1, 1)))
+    xq = x.clone().requires_grad_(True)
+    zr = F.interpolate(F.max_pool3d(xq, (1, 3, 3), (1, 2, 2), (0, 1, 1)), scale_factor=(1, 2, 2), mode="trilinear")
+    MC.close(z.permute(0, 4, 1, 2, 3), zr, 1e-6, "pool + upsample op")
+    z.sum().backward()
+    zr.sum().backward()
+    MC.close(xp.grad.permute(0, 4, 1, 2, 3), xq.grad, 1e-5, "pool + upsample op gradient")
+
+
+def _two_rank_worker(rank, world, port, out, backend):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    from vinet_amd import optim as VO
+    from vinet_amd import parallel
+    L.load()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        assert float(t[0]) == world
+    except Exception as e:     # e.g. RCCL refusing two ranks on one device
+        torch.save(dict(error=repr(e)), os.path.join(out, "rank%d.pt" % rank))
+        return
+    E.set_default_dtype("bf16")
+    x = synth.clip(world, 8, 64, 96, 3).permute(0, 2, 1, 3, 4)[rank:rank + 1].to(dev)
+    gt = synth.gt_map(world, 64, 96, 3)[rank:rank + 1].to(dev)
+    res = {}
+    for mode in ("flat", "bucketed"):
+        m = VM.VideoSaliencyModel(num_clips=8)
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), 7))
+        m = m.to(dev).train()
+        opt = VO.Adam(parallel.trainable_parameters(m), lr=1e-3)
+        bk = parallel.GradientBuckets(opt, bucket_bytes=4 << 20)
+        for _ in range(2):
+            opt.zero_grad()
+            if mode == "bucketed":
+                bk.begin_step()
+            VL.kldiv(m(x), gt).backward()
+            if mode == "bucketed":
+                bk.finish()
+            else:
+                parallel.allreduce_gradients(opt)
+            if _ == 0:
+                res[mode + "_g"] = (opt.flat_g * opt.grad_scale).cpu()
+            opt.step()
+        torch.cuda.synchronize()
+        res[mode + "_p"] = opt.flat_p.cpu()
+    torch.save(res, os.path.join(out, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_bucketed_allreduce(tmp_path):
+    """The N > 1 path ON A GPU: two ranks share cuda:0 (backend nccl = RCCL when it accepts two ranks on one device, else
+    gloo on device tensors).  The bucketed all-reduce -- issued from the tape while the weight-gradient side stream and the
+    main stream are both busy, joined by events -- must give the gradients and parameters of the flat one-shot all-reduce
+    after the whole backward, and both replicas must agree."""
+    import socket
+    import torch.multiprocessing as mp
+    used = None
+    for backend in ("nccl", "gloo"):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        d = tmp_path / backend
+        d.mkdir()
+        mp.spawn(_two_rank_worker, args=(2, port, str(d), backend), nprocs=2, join=True)
+        rs = [torch.load(str(d / ("rank%d.pt" % r))) for r in range(2)]
+        if not any("error" in r for r in rs):
+            used = backend
+            break
+        _note("two_rank_gpu_backend_refused", dict(backend=backend, error=[r.get("error") for r in rs]))
+    assert used is not None, "neither nccl nor gloo could run two ranks on one GPU"
+    r0, r1 = rs
+    assert torch.equal(r0["flat_p"], r1["flat_p"]) and torch.equal(r0["bucketed_p"], r1["bucketed_p"]), "replicas diverged"
+    dg = float((r0["bucketed_g"] - r0["flat_g"]).abs().max() / (r0["flat_g"].abs().max() + 1e-30))
+    assert dg < 1e-6, "bucketed (overlapped) all-reduce differs from the flat one: %g" % dg
+    _note("two_rank_gpu", dict(backend=used, bucketed_vs_flat_grad=dg))
