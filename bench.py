@@ -251,22 +251,39 @@ def main():
                    bytes=sum((v["work"] or {}).get("bytes", 0.0) * v["count"] for v in domtab.values()))
 
     # ---- local-batch sweep of the same step ({1,2,4,8,16,32}), N = 1 training only
-    sweep = None
+    # (each point eager -- one Python-issued launch per kernel -- and as a replayed hipGraph of the step, vinet_amd.graph)
+    sweep, sweep_eager = None, None
     if world == 1 and args.mode == "train" and not args.no_sweep:
-        sweep = {}
+        from vinet_amd.graph import GraphedTrainStep
+        sweep, sweep_eager = {}, {}
+        import gc
         for b in SWEEP_BATCHES:
             if b >= B:
                 continue
-            xs = x[:b]
-            ins = (xs, inputs[1][:b]) if av else (xs,)
-            gs = gt[:b]
+            xs = x[:b].contiguous()
+            ins = (xs, inputs[1][:b].contiguous()) if av else (xs,)
+            gs = gt[:b].contiguous()
             train_step(ins, gs)
             torch.cuda.synchronize()
             t0s = time.perf_counter()
             for _ in range(args.sweep_steps):
                 train_step(ins, gs)
             torch.cuda.synchronize()
-            sweep[str(b)] = b * args.sweep_steps / (time.perf_counter() - t0s)
+            sweep_eager[str(b)] = b * args.sweep_steps / (time.perf_counter() - t0s)
+            gc.collect()
+            torch.cuda.empty_cache()
+            gstep = GraphedTrainStep(m, opt, loss.kldiv, ins, gs)
+            gstep(ins, gs)
+            torch.cuda.synchronize()
+            n = max(args.sweep_steps, 4)
+            t0s = time.perf_counter()
+            for _ in range(n):
+                gstep(ins, gs)
+            torch.cuda.synchronize()
+            sweep[str(b)] = b * n / (time.perf_counter() - t0s)
+            del gstep
+            gc.collect()
+            torch.cuda.empty_cache()
 
     if rank == 0:
         clips = world * B * args.steps
@@ -334,7 +351,10 @@ def main():
         }
         if sweep is not None:
             sweep[str(B)] = value
-            out["sweep"] = dict(unit="clips/s", steps_each=args.sweep_steps, local_batch=sweep)
+            sweep_eager[str(B)] = value
+            out["sweep"] = dict(unit="clips/s", steps_each=args.sweep_steps, local_batch=sweep, local_batch_eager=sweep_eager,
+                                note="local_batch: the step replayed as one hipGraph (vinet_amd.graph.GraphedTrainStep) for batches below the "
+                                     "headline's, which is eager; local_batch_eager: one Python-issued launch per kernel")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

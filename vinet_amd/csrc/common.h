@@ -15,13 +15,25 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_v;
 #define VN_DEV __device__ __forceinline__
 
 VN_DEV float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-VN_DEV bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved (same as aten)
+// fp32 -> bf16, round-to-nearest-even, NaN stays NaN (same as aten): ONE instruction on gfx950 (v_cvt_pk_bf16_f32; the
+// integer formulation -- NaN test, rounding add, shift -- is 6-8 VALU per element, and the pools, the upsample, the conv
+// epilogues and the stem's streaming kernels are VALU-issue bound where they write bf16).  -DVINET_SOFT_BF16: the integer form.
+#if defined(VINET_SOFT_BF16) || !defined(__HIP_DEVICE_COMPILE__)
+VN_DEV bf16_t f2bf(float f) {
   uint32_t u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
 VN_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+#else
+VN_DEV uint32_t pack2bf(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+VN_DEV bf16_t f2bf(float f) { return (bf16_t)pack2bf(f, f); }
+#endif
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {

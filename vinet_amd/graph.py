@@ -37,3 +37,53 @@ class GraphedInference:
             dst.copy_(src)
         self.graph.replay()
         return self.static_out
+
+
+class GraphedTrainStep:
+    """One training step -- zero_grad, forward, loss, backward -- captured into a hipGraph; the fused Adam launch follows each
+    replay (its bias corrections are host scalars).  At the reference's batch sizes (train.py:43: a GLOBAL batch of 8, i.e.
+    1-8 clips per GPU) a step is ~1500 kernel launches issued from Python for a few milliseconds of GPU work: host bound.
+    Everything the tape does is capturable as it is: all launches go to torch's current stream or to the weight-gradient
+    side stream (forked from and joined back to it by events), all memory is the caching allocator's, the weight packs of
+    the whole model are rebuilt by ONE multi-pack launch at the top of the step (captured: it re-runs at every replay),
+    gradients land in the optimizer's flat buffer at fixed addresses.
+
+        step = GraphedTrainStep(model, optimizer, vinet_amd.loss.kldiv, (clips,), gt)
+        loss = step((clips,), gt)          # same shapes as at capture
+    """
+
+    def __init__(self, model, optimizer, loss_fn, inputs, gt, warmup=2):
+        assert all(t.is_cuda for t in inputs) and gt.is_cuda, "graph capture needs GPU tensors"
+        self.model, self.opt, self.loss_fn = model.train(), optimizer, loss_fn
+        self.static_in = [t.clone() for t in inputs]
+        self.static_gt = gt.clone()
+        self._bns = [m for m in model.modules() if hasattr(m, "note_training_step")]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # weight packs, tap tables, persistent workspaces, LDS attributes, autograd's own set-up
+                self._body()
+                self.opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._body()
+
+    def _body(self):
+        self.opt.zero_grad()
+        loss = self.loss_fn(self.model(*self.static_in), self.static_gt)
+        loss.backward()
+        return loss.detach()
+
+    def __call__(self, inputs, gt):
+        for dst, src in zip(self.static_in, inputs):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        if self.static_gt.data_ptr() != gt.data_ptr():
+            self.static_gt.copy_(gt)
+        self.graph.replay()
+        for bn in self._bns:                 # (host-side bookkeeping the captured body did once: num_batches_tracked)
+            bn.note_training_step()
+        self.opt.step()
+        return self.static_loss
