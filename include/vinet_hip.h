@@ -139,6 +139,10 @@ int vinet_conv3d(const VinetConvDesc* desc, void* stream);
 int64_t vinet_conv3d_splitk_bytes(const VinetConvDesc* desc);
 /* 1 if vinet_conv3d accepts this tline == 3 descriptor (fused stride phases of a temporal data gradient). */
 int vinet_conv3d_fuses_dgrad_phases(const VinetConvDesc* desc);
+/* 1 if the kernel vinet_conv3d picks for this problem applies the pending affine `pre` ONCE per staged activation (the
+ * halo-tile kernel transforms its LDS image in place) rather than at every fragment read: callers that would otherwise
+ * materialise relu(bn(x)) with vinet_copy_affine first can skip that pass. */
+int vinet_conv3d_applies_pre_once(const VinetConvDesc* desc);
 /* BM of the tile configuration vinet_conv3d will pick for this problem. */
 int vinet_conv3d_tile_m(const VinetConvDesc* desc);
 /* Rows of the `stats` table ([rows][2][N]) the launch fills: ceil(M / tile_m) for the row-tiled kernels, the number

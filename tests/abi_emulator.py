@@ -212,6 +212,9 @@ class AbiEmulator:
         wr(d.y, d.out_dtype, out, bool(d.accumulate))
         return 0
 
+    def vinet_conv3d_applies_pre_once(self, d):
+        return 0
+
     def vinet_conv3d_stats_rows(self, d):
         d = _deref(d)
         M = d.x.B * d.oT * d.oH * d.oW

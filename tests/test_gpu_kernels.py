@@ -252,6 +252,16 @@ HT_CASES = [
     ("ht_phase_acc", (2, 3, 8, 32), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(accumulate=True, om=(5, 2))),
     ("ht_phase_store", (2, 3, 12, 32), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(om=(5, 3))),
     ("ht_f32_out", (1, 1, 16, 32), 32, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(out_f32=True, epi_shift=True)),
+    # pending BatchNorm + ReLU applied once per staged element, in LDS (padding must stay zero behind the affine)
+    ("ht_pre_64_96", (2, 2, 8, 32), 64, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(pre=True, stats=True)),
+    ("ht_pre_tw16_cin96", (1, 3, 20, 16), 96, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), dict(pre=True, act=1)),
+    ("ht_pre_slices", (2, 2, 9, 32), 128, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(pre=True, in_ld=160, in_coff=32, stats=True)),
+    # temporal mode: (3,1,1) taps, 64 positions x 4 output frames per workgroup; frames / positions not multiples of 4 / 64,
+    # plain and pending-affine inputs, accumulate (the data gradient joining an existing one), sliced views
+    ("htt_192", (2, 6, 8, 16), 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, stats=True)),
+    ("htt_pre_128", (1, 5, 14, 24), 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, pre=True, stats=True, act=1)),
+    ("htt_acc_slices", (2, 7, 6, 8), 64, 96, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, accumulate=True, in_ld=160, in_coff=32, out_ld=256, out_coff=64)),
+    ("htt_pre_cin160", (1, 4, 8, 8), 160, 80, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, pre=True, epi=True)),
 ]
 
 
@@ -260,7 +270,8 @@ def test_conv3d_halo_tile(case):
     lib = _lib()
     assert lib.vinet_set_option(b"ht", 2) == 0
     try:
-        ex = dict(case[7], tline=5)
+        ex = dict(case[7])
+        ex.setdefault("tline", 5)
         d0 = _run_conv_case(case[:7] + (ex,), E.BF16, forced=True)
         buf = C.create_string_buffer(128)
         assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_ht_kernel<"), buf.value

@@ -47,6 +47,10 @@ SITES = [
     ("dg stem_t 64->64 4taps", 8, 16, 112, 192, 64, 64, (4, 1, 1), (1, 1, 1), (1, 0, 0)),
     ("dg b1.3s 192->64 1x3x3", 8, 16, 56, 96, 192, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("stem folded 32->64 7taps", 8, 32, 118, 100, 32, 64, (1, 7, 1), (1, 1, 1), (0, 0, 0)),
+    ("3c t 192->192 3x1x1", 8, 16, 28, 48, 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("3b t 128->128 3x1x1", 8, 16, 28, 48, 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("4f t 320->320 3x1x1", 8, 8, 14, 24, 320, 320, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("4d t 256->256 3x1x1", 8, 8, 14, 24, 256, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     ("3b s 96->128 1x3x3", 8, 16, 28, 48, 96, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("dg 3b s 128->96", 8, 16, 28, 48, 128, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("3c b2 32->96 1x3x3", 8, 16, 28, 48, 32, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
@@ -92,6 +96,8 @@ def main():
         for ln, lib in libs:
             variants.append((ln + ":default", lib, dict(ht=0), False))
             variants.append((ln + ":ht", lib, dict(ht=2), False))
+            variants.append((ln + ":default+pre", lib, dict(ht=0), True))
+            variants.append((ln + ":ht+pre", lib, dict(ht=2), True))
         libs = []
     for ln, lib in libs:
         variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=0, n64_tile=0, n192_tile=0, n128_tile=0), False))
@@ -109,7 +115,7 @@ def main():
     for (name, B, T, H, W, Cin, N, k, s, p) in SITES:
         if args.only and args.only not in name:
             continue
-        if args.ht and not (k[1:] == (3, 3) and W % 16 == 0):
+        if args.ht and not ((k[1:] == (3, 3) and W % 16 == 0) or (k == (3, 1, 1) and (H * W) % 16 == 0)):
             continue
         B = args.batch
         oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
@@ -140,6 +146,8 @@ def main():
                 d.stats = stats.data_ptr()
             if k[1:] == (3, 3):
                 d.tline = 5
+            elif k[1:] == (1, 1) and k[0] > 1:
+                d.tline, d.tpad = 1, p[0]
             return d
 
         def wdesc(pre):

@@ -59,6 +59,7 @@ SIGNATURES = {
     "vinet_conv3d": [_PC, _vp],
     "vinet_conv3d_tile_m": [_PC],
     "vinet_conv3d_stats_rows": [_PC],
+    "vinet_conv3d_applies_pre_once": [_PC],
     "vinet_conv3d_splitk_bytes": [_PC],
     "vinet_conv3d_kernel_name": [_PC, C.c_char_p, _i32],
     "vinet_conv3d_wgrad": [_PW, _vp],

@@ -133,9 +133,9 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
 
 static bool use_pp(const VinetConvDesc* d);
 static bool use_ht(const VinetConvDesc* d);
-struct HtShape { int nt, tw; };
+struct HtShape { int nt, tw, tm, pre; };
 static HtShape ht_shape(const VinetConvDesc* d);
-extern int g_vinet_opt_ht, g_vinet_opt_ht_minhw;
+extern int g_vinet_opt_ht, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
 bool vinet_conv_use_ts(const VinetConvDesc* d);
 bool vinet_conv_use_hs(const VinetConvDesc* d);
 bool vinet_conv_use_tsd(const VinetConvDesc* d);
@@ -164,6 +164,7 @@ extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_ht(d)) {
     const HtShape h = ht_shape(d);
+    if (h.tm) return (int)((long)d->x.B * vn_div_up(d->oT, 4) * vn_div_up((long)d->oH * d->oW, 64));
     return (int)((long)d->x.B * d->oT * vn_div_up(d->oH, 256 / h.tw) * vn_div_up(d->oW, h.tw));
   }
   const int bm = vinet_conv3d_tile_m(d);
@@ -215,6 +216,9 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
   if (name && !strcmp(name, "ht")) { g_vinet_opt_ht = value; return 0; }
   if (name && !strcmp(name, "ht_minhw")) { g_vinet_opt_ht_minhw = value; return 0; }
+  if (name && !strcmp(name, "ht_t")) { g_vinet_opt_ht_t = value; return 0; }
+  if (name && !strcmp(name, "ht_pre")) { g_vinet_opt_ht_pre = value; return 0; }
+  if (name && !strcmp(name, "ht_t_minhw")) { g_vinet_opt_ht_t_minhw = value; return 0; }
   if (name && !strcmp(name, "splitk")) { g_vinet_opt_splitk = value; return 0; }
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
@@ -270,14 +274,27 @@ static bool use_pp(const VinetConvDesc* d) {
 // pads N least (192 = 2 x 96).
 int g_vinet_opt_ht = 1;         // 0 = off, 1 = heuristic, 2 = every eligible conv (tests)
 int g_vinet_opt_ht_minhw = 28 * 48;
+int g_vinet_opt_ht_t = 1;        // temporal mode of the halo-tile kernel for (3,1,1) / stride-1 convs: 604 -> 647 TF/s plain, 482 -> 514 with a
+                                 // pending affine (reuse is only 2x and the image is re-staged every three K steps); whole step neutral (+0...0.6 %)
+int g_vinet_opt_ht_pre = 0;      // spatial mode on inputs with a pending BatchNorm + ReLU (1 = on).  The kernel itself wins (570 -> 790 TF/s
+                                 // against conv_dma's per-fragment form) but the engine then skips the materialisation pass, and the row-streaming
+                                 // weight gradients of those layers want plain inputs: whole step 613 -> 599 clips/s.  Off.
+int g_vinet_opt_ht_t_minhw = 14 * 24;
+// temporal mode: tline == 1 with three taps, padding 1, unit stride = taps (dt, 0, 0), dt in {-1, 0, 1}
+static bool ht_temporal(const VinetConvDesc* d) {
+  return d->tline == 1 && d->ntaps == 3 && d->tpad == 1 && d->sT == 1;
+}
 static HtShape ht_shape(const VinetConvDesc* d) {
   HtShape h;
+  h.tm = ht_temporal(d) ? 1 : 0;
+  h.pre = d->pre.scale ? 1 : 0;
   h.tw = (d->oW % 32 == 0) ? 32 : 16;
   const int N = d->n_valid > 0 ? d->n_valid : d->y.C;
-  // 96-, 64- or 32-wide column tiles, whichever pads N least (ties: the widest); a 128-wide tile spills (12 B / lane)
+  // 96-, 64- or 32-wide column tiles, whichever pads N least (ties: the widest); a 128-wide tile spills (12 B / lane);
+  // the temporal and PRE forms exist for 96 and 64
   int best = 4, bestpad = 1 << 30;
   const int nts[3] = {6, 4, 2};
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < ((h.tm || h.pre) ? 2 : 3); ++i) {
     const int bn = nts[i] * 16, pad = (N + bn - 1) / bn * bn;
     if (pad < bestpad) { bestpad = pad; best = nts[i]; }
   }
@@ -285,15 +302,21 @@ static HtShape ht_shape(const VinetConvDesc* d) {
   return h;
 }
 static bool use_ht(const VinetConvDesc* d) {
-  if (!g_vinet_opt_ht || !use_dma(d) || d->pre.scale || d->pre.relu || d->tline != 5) return false;
-  if (d->sH != 1 || d->sW != 1 || d->oH != d->x.H || d->oW != d->x.W || d->oW % 16 != 0 || d->ntaps > 64 || d->ntaps < 2) return false;
+  if (!g_vinet_opt_ht || !use_dma(d) || (d->pre.relu && !d->pre.scale)) return false;
+  const bool tm = ht_temporal(d);
+  if (!tm && d->tline != 5) return false;
+  if (d->pre.scale && !(d->pre.relu && d->pre.shift && d->Kp <= 1024)) return false;
+  if (d->sH != 1 || d->sW != 1 || d->oH != d->x.H || d->oW != d->x.W || d->ntaps > 64 || d->ntaps < 2) return false;
+  if (tm ? ((d->oH * d->oW) % 16 != 0 || d->oT != d->x.T) : (d->oW % 16 != 0)) return false;
   if (g_vinet_opt_ht >= 2) return true;
+  if (tm && !(g_vinet_opt_ht_t)) return false;
+  if (!tm && d->pre.scale && !g_vinet_opt_ht_pre) return false;
   // measured (tools/conv_ab.py --ht, 64 clips): wins wherever the 64-channel K chunks are (nearly) full -- 504 -> 995 TF/s on
   // the 192 -> 64 5x3x3 decoder conv, 528 -> 840 on the data gradient of 64 -> 192, 894 -> 1026 on 480 -> 192 (conv_pp before),
   // 331 -> 510 on 64 -> 32 -- and loses where a chunk is half padding (Cin = 32: 410 -> 310; Cin = 96: 608 -> 535)
   const int N = d->y.C;
   const int k64 = (d->Kp + 63) / 64 * 64;
-  return (long)d->oH * d->oW >= g_vinet_opt_ht_minhw && N >= 32 && k64 * 20 <= d->Kp * 23;
+  return (long)d->oH * d->oW >= (tm ? g_vinet_opt_ht_t_minhw : g_vinet_opt_ht_minhw) && N >= 32 && k64 * 20 <= d->Kp * 23;
 }
 
 // ---- split-K for grids that cannot fill the chip (batch-1 inference) ---------------------------
@@ -358,11 +381,19 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   if (d->tline == 3) snprintf(buf, n, vinet_conv_use_tsd(d) ? "conv_tsd_kernel" : "(unsupported)");
   else if (vinet_conv_use_hs(d)) snprintf(buf, n, "conv_hs_kernel");
   else if (vinet_conv_use_ts(d)) snprintf(buf, n, "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
-  else if (use_ht(d)) { const HtShape h = ht_shape(d); snprintf(buf, n, "conv_ht_kernel<%d,%d>", h.nt * 16, h.tw); }
+  else if (use_ht(d)) {
+    const HtShape h = ht_shape(d);
+    if (h.tm) snprintf(buf, n, "conv_ht_kernel<%d,t,%s>", h.nt * 16, h.pre ? "pre" : "plain");
+    else snprintf(buf, n, h.pre ? "conv_ht_kernel<%d,%d,pre>" : "conv_ht_kernel<%d,%d>", h.nt * 16, h.tw);
+  }
   else if (use_pp(d)) snprintf(buf, n, "conv_pp_kernel<%d>", pp_bn(d->y.C));
   else if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
   else snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", t.MT, t.NT, t.WM, t.WN, d->mode);
   return 0;
+}
+
+extern "C" int vinet_conv3d_applies_pre_once(const VinetConvDesc* d) {
+  return d && d->pre.scale && !vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_ht(d) ? 1 : 0;
 }
 
 extern "C" int vinet_conv3d_fuses_dgrad_phases(const VinetConvDesc* d) {
@@ -383,12 +414,20 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
   if (use_ht(d)) {
     const HtShape h = ht_shape(d);
     a.tilesN = vn_div_up(a.N, h.nt * 16);
-    a.ht_tilesH = vn_div_up(d->oH, 256 / h.tw);
-    a.ht_tilesW = vn_div_up(d->oW, h.tw);
-    a.tilesM = (int)((long)d->x.B * d->oT * a.ht_tilesH * a.ht_tilesW);
+    if (h.tm) {      // tiles: 64 positions x 4 output frames
+      a.ht_tilesH = vn_div_up(d->oT, 4);
+      a.ht_tilesW = vn_div_up((long)d->oH * d->oW, 64);
+      a.tilesM = (int)((long)d->x.B * a.ht_tilesH * a.ht_tilesW);
+      a.ht_dTo = make_fastdiv(1);
+    } else {
+      a.ht_tilesH = vn_div_up(d->oH, 256 / h.tw);
+      a.ht_tilesW = vn_div_up(d->oW, h.tw);
+      a.tilesM = (int)((long)d->x.B * d->oT * a.ht_tilesH * a.ht_tilesW);
+      a.ht_dTo = make_fastdiv((uint32_t)d->oT);
+    }
     a.ht_dN = make_fastdiv((uint32_t)a.tilesN); a.ht_dW = make_fastdiv((uint32_t)a.ht_tilesW);
-    a.ht_dH = make_fastdiv((uint32_t)a.ht_tilesH); a.ht_dTo = make_fastdiv((uint32_t)d->oT);
-    return vinet_launch_conv_ht_bf16(h.nt, h.tw, a, (hipStream_t)stream);
+    a.ht_dH = make_fastdiv((uint32_t)a.ht_tilesH);
+    return vinet_launch_conv_ht_bf16(h.nt, h.tw, h.tm, h.pre, a, (hipStream_t)stream);
   }
   if (use_pp(d)) {
     const int bn = pp_bn(a.N);

@@ -33,9 +33,18 @@ int vinet_launch_conv_pp_bf16(int bn, const ConvArgs& a, hipStream_t s) {
   return bn == 192 ? launch_conv_pp_cfg<4, 2, 192>(a, s) : launch_conv_pp_cfg<2, 4, 256>(a, s);
 }
 
-// halo-tile kernel (conv_ht.h): 3x3 spatial taps on plain inputs; nt = 16-column tiles per workgroup, tw = tile width
-int vinet_launch_conv_ht_bf16(int nt, int tw, const ConvArgs& a, hipStream_t s) {
-  if (tw == 32) {
+// halo-tile kernel (conv_ht.h): nt = 16-column tiles per workgroup, tw = tile width (spatial mode), tm = temporal mode
+// ((3,1,1) taps), pre = pending BatchNorm + ReLU applied once per staged element
+int vinet_launch_conv_ht_bf16(int nt, int tw, int tm, int pre, const ConvArgs& a, hipStream_t s) {
+  if (tm) {
+    if (nt == 4) return pre ? launch_conv_ht_cfg<4, 32, 3, true, true>(a, s) : launch_conv_ht_cfg<4, 32, 3, true, false>(a, s);
+    if (nt == 6) return pre ? launch_conv_ht_cfg<6, 32, 2, true, true>(a, s) : launch_conv_ht_cfg<6, 32, 2, true, false>(a, s);
+  } else if (pre) {
+    if (tw == 32 && nt == 4) return launch_conv_ht_cfg<4, 32, 3, false, true>(a, s);
+    if (tw == 32 && nt == 6) return launch_conv_ht_cfg<6, 32, 2, false, true>(a, s);
+    if (tw == 16 && nt == 4) return launch_conv_ht_cfg<4, 16, 3, false, true>(a, s);
+    if (tw == 16 && nt == 6) return launch_conv_ht_cfg<6, 16, 2, false, true>(a, s);
+  } else if (tw == 32) {
     if (nt == 2) return launch_conv_ht_cfg<2, 32, 3>(a, s);
     if (nt == 4) return launch_conv_ht_cfg<4, 32, 3>(a, s);
     if (nt == 6) return launch_conv_ht_cfg<6, 32, 3>(a, s);
@@ -44,6 +53,6 @@ int vinet_launch_conv_ht_bf16(int nt, int tw, const ConvArgs& a, hipStream_t s) 
     if (nt == 4) return launch_conv_ht_cfg<4, 16, 3>(a, s);
     if (nt == 6) return launch_conv_ht_cfg<6, 16, 3>(a, s);
   }
-  vinet_set_error("conv ht bf16: no kernel for nt=%d tw=%d", nt, tw);
+  vinet_set_error("conv ht bf16: no kernel for nt=%d tw=%d tm=%d pre=%d", nt, tw, tm, pre);
   return -1;
 }

@@ -27,9 +27,15 @@
 #pragma once
 #include "conv_dma.h"
 
-template <int NT, int TW, int BSLOTS>
+// TM (temporal mode): the same machinery turned by 90 degrees for the (3,1,1) / stride-1 temporal convs of the SepConv3d
+// blocks (model_utils.py:148) and their data gradients: a workgroup owns 64 positions x 4 consecutive output frames (one
+// frame per wave), the "halo image" is the 6 input frames t0-1 .. t0+4 of those 64 positions (no spatial halo), the three
+// taps are three ROW offsets into it: every activation byte is staged once per 4 output frames instead of three times.
+// PRE: a pending BatchNorm + ReLU of the input (the conv_t of a SepConv3d reads conv_s's raw output) is applied ONCE per
+// staged element, in LDS, by the wave that staged it -- conv_dma's PRE form pays it at every fragment read, i.e. per tap.
+template <int NT, int TW, int BSLOTS, bool TM = false, bool PRE = false>
 struct ConvHtCfg {
-  static constexpr int THREADS = 256, BM = 256, TR = BM / TW, HW = TW + 2, HR = TR + 2;
+  static constexpr int THREADS = 256, BM = 256, TR = TM ? 4 : BM / TW, HW = TM ? 64 : TW + 2, HR = TR + 2;
   static constexpr int NPOS = HR * HW;                  // halo positions
   static constexpr int HPIECES = (NPOS + 7) / 8;        // DMA pieces of 8 positions x 128 B
   static constexpr int HL = (HPIECES + 3) / 4;          // halo DMAs per wave
@@ -37,17 +43,20 @@ struct ConvHtCfg {
   static constexpr int BN = NT * 16;
   static constexpr int BL = NT / 2;                     // weight DMAs per wave and K step (BN / 8 pieces over 4 waves)
   static constexpr int BSLOT_BYTES = BN * 128;
-  static constexpr int KLOOP_BYTES = HALO_BYTES + BSLOTS * BSLOT_BYTES;
+  static constexpr int KLOOP_BYTES = HALO_BYTES + BSLOTS * BSLOT_BYTES;   // PRE: scale[Kp], shift[Kp] (fp32) behind it
   static constexpr int EROW = BN + 4;
   static constexpr int EPI_BYTES = conv_epi_bytes<4, NT, 4, 1>();
-  static constexpr int SMEM = KLOOP_BYTES > EPI_BYTES ? KLOOP_BYTES : EPI_BYTES;
+  static int smem_bytes(int Kp) {
+    const int k = KLOOP_BYTES + (PRE ? 2 * Kp * 4 : 0);
+    return k > EPI_BYTES ? k : EPI_BYTES;
+  }
   static_assert(NT % 2 == 0 && (TW == 32 || TW == 16), "shapes");
   static_assert(BSLOTS >= 2 && BL * (BSLOTS - 2) <= 63, "vmcnt immediate range");
 };
 
-template <int NT, int TW, int BSLOTS>
+template <int NT, int TW, int BSLOTS, bool TM, bool PRE>
 __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
-  using Cfg = ConvHtCfg<NT, TW, BSLOTS>;
+  using Cfg = ConvHtCfg<NT, TW, BSLOTS, TM, PRE>;
   constexpr int HW = Cfg::HW, TR = Cfg::TR, HL = Cfg::HL, BL = Cfg::BL, MT = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo = smem;
@@ -67,9 +76,12 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   const int tw_i = (int)(sp - q1 * (uint32_t)a.ht_tilesW);
   const uint32_t frame = fdiv(q1, a.ht_dH);
   const int th_i = (int)(q1 - frame * (uint32_t)a.ht_tilesH);
+  // spatial: frame = b * To + to, tile (th_i, tw_i) of that frame.  temporal: frame = b, th_i = block of 4 output frames,
+  // tw_i = block of 64 positions (ht_dTo divides by 1)
   const uint32_t bb = fdiv(frame, a.ht_dTo);
-  const int to = (int)(frame - bb * (uint32_t)a.To), b = (int)bb;
+  const int to = TM ? th_i * 4 : (int)(frame - bb * (uint32_t)a.To), b = (int)bb;
   const int h0 = th_i * TR, w0 = tw_i * TW;
+  const int p0 = tw_i * 64, HWtot = a.Hi * a.Wi;     // (temporal mode: first position of the tile, positions per frame)
 
   // ---- this lane's DMA role: row (lane >> 3) of an 8-row piece, LDS slot (lane & 7), source chunk slot ^ row -----------
   const int prow = lane >> 3;
@@ -80,10 +92,16 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   for (int j = 0; j < HL; ++j) {
     const int p = (j * 4 + wave) * 8 + prow;
     const int hr = p / HW, hc = p - hr * HW;
-    const int h = h0 - 1 + hr, w = w0 - 1 + hc;
-    const bool ok = (p < Cfg::NPOS) & ((unsigned)h < (unsigned)a.Hi) & ((unsigned)w < (unsigned)a.Wi);
-    hal_off[j] = ok ? (h * a.Wi + w) * a.ldx + src_chunk * 8 : 0;
-    hal_ok |= (unsigned)ok << j;
+    if constexpr (TM) {     // halo row = frame t0 - 1 + hr (added at issue time: uniform per piece), column = position p0 + hc
+      const bool ok = (p < Cfg::NPOS) & (p0 + hc < HWtot);
+      hal_off[j] = ok ? (p0 + hc) * a.ldx + src_chunk * 8 : 0;
+      hal_ok |= (unsigned)ok << j;
+    } else {
+      const int h = h0 - 1 + hr, w = w0 - 1 + hc;
+      const bool ok = (p < Cfg::NPOS) & ((unsigned)h < (unsigned)a.Hi) & ((unsigned)w < (unsigned)a.Wi);
+      hal_off[j] = ok ? (h * a.Wi + w) * a.ldx + src_chunk * 8 : 0;
+      hal_ok |= (unsigned)ok << j;
+    }
   }
   const char* const xb = a.x + (long)b * a.sBx * 2;
   const long frame_elems = (long)a.Hi * a.Wi * a.ldx;
@@ -103,17 +121,49 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
   // halo image of (temporal offset dt, channel chunk c0)
+  // which of this lane's halo elements are real activations in the image staged last (PRE: the others must stay zero)
+  unsigned hal_live = 0;
   auto issue_halo = [&](int dt, int c0) {
-    const int t = to * a.sT + dt;
-    const unsigned tok = (unsigned)((unsigned)t < (unsigned)a.Ti) & (unsigned)(c0 + src_chunk * 8 < a.Cin);
-    const char* base = xb + ((long)t * frame_elems + c0) * 2;
+    const unsigned cok = (unsigned)(c0 + src_chunk * 8 < a.Cin);
+    hal_live = 0;
 #pragma unroll
     for (int j = 0; j < HL; ++j) {
-      const unsigned ok = tok & ((hal_ok >> j) & 1u);
+      // spatial: one frame (temporal offset dt of the tap group); temporal: piece (j, wave) belongs to frame to - 1 + its halo row
+      const int t = TM ? to - 1 + ((j * 4 + wave) * 8) / HW : to * a.sT + dt;
+      const unsigned ok = cok & (unsigned)((unsigned)t < (unsigned)a.Ti) & ((hal_ok >> j) & 1u);
+      const char* base = xb + ((long)t * frame_elems + c0) * 2;
       const char* src = zero + (((base + (long)hal_off[j] * 2) - zero) & -(long)ok);
       dma(src, halo + (j * 4 + wave) * 1024);
+      hal_live |= ok << j;
     }
   };
+  // PRE: relu(scale * x + shift) on this wave's own pieces of the image, in place (after its DMAs have landed, before the
+  // barrier that publishes the image); padding stays zero
+  float* const aff = (float*)(smem + Cfg::KLOOP_BYTES);
+  auto xform_halo = [&](int c0) {
+    const float* sp_ = aff + c0 + src_chunk * 8;
+    const float4 s0 = *(const float4*)sp_, s1 = *(const float4*)(sp_ + 4);
+    const float4 h0_ = *(const float4*)(sp_ + a.Kp), h1_ = *(const float4*)(sp_ + a.Kp + 4);
+    const f32x2_v sc2[4] = {{s0.x, s0.y}, {s0.z, s0.w}, {s1.x, s1.y}, {s1.z, s1.w}};
+    const f32x2_v sh2[4] = {{h0_.x, h0_.y}, {h0_.z, h0_.w}, {h1_.x, h1_.y}, {h1_.z, h1_.w}};
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      uint4* q = (uint4*)(halo + (j * 4 + wave) * 1024 + lane * 16);
+      const uint4 v = *q;
+      const uint32_t m = (hal_live >> j) & 1u ? 0xffffffffu : 0u;
+      *q = make_uint4(pre_relu_pair(v.x, sc2[0], sh2[0]) & m, pre_relu_pair(v.y, sc2[1], sh2[1]) & m,
+                      pre_relu_pair(v.z, sc2[2], sh2[2]) & m, pre_relu_pair(v.w, sc2[3], sh2[3]) & m);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the raw s_barrier that follows does not wait for LDS stores)
+  };
+  if constexpr (PRE) {
+    for (int c = tid; c < a.Kp; c += 256) {
+      const bool in = c < a.Cin;
+      aff[c] = in ? a.in_scale[c] : 0.f;
+      aff[a.Kp + c] = in ? a.in_shift[c] : 0.f;
+    }
+    __syncthreads();   // (plain loads above are complete before any DMA is counted)
+  }
   // weight tile of (slice, c0) into ring slot `slot`; live == false: the same number of DMAs from the zero page
   auto issue_b = [&](int slot, bool live, int slice, int c0) {
     char* dst = bring + slot * Cfg::BSLOT_BYTES + wave * 1024;
@@ -137,18 +187,32 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   int pl[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int r = TW == 32 ? 2 * wave + (i >> 1) : 4 * wave + i;
-    const int c = TW == 32 ? (i & 1) * 16 : 0;
-    pl[i] = (r + 1) * HW + (c + 1) + (lane & 15);
+    if constexpr (TM) {
+      pl[i] = (wave + 1) * HW + i * 16 + (lane & 15);         // wave = output frame of the tile, fragment i = 16 positions
+    } else {
+      const int r = TW == 32 ? 2 * wave + (i >> 1) : 4 * wave + i;
+      const int c = TW == 32 ? (i & 1) * 16 : 0;
+      pl[i] = (r + 1) * HW + (c + 1) + (lane & 15);
+    }
   }
   // row -> voxel map of this wave for the epilogue: TR / 4 image rows of the tile, TW / 16 row groups each
-  constexpr int WROWS = TR / 4;
+  // (temporal: one "row" = this wave's output frame, four groups of 16 positions, as many of them as the frame still has)
+  constexpr int WROWS = TM ? 1 : TR / 4;
   const int hw0 = h0 + wave * WROWS;
   EpiRows er;
-  er.m0 = (int)((frame * (uint32_t)a.Ho + (uint32_t)hw0) * (uint32_t)a.Wo + (uint32_t)w0);
-  er.ipr = TW / 16;
-  er.rstride = a.Wo;
-  er.nrows = a.Ho - hw0 < 0 ? 0 : (a.Ho - hw0 > WROWS ? WROWS : a.Ho - hw0);
+  if constexpr (TM) {
+    er.m0 = (int)(((uint32_t)b * (uint32_t)a.To + (uint32_t)(to + wave)) * (uint32_t)HWtot + (uint32_t)p0);
+    er.ipr = 4;
+    er.rstride = 0;
+    er.nrows = to + wave < a.To ? 1 : 0;
+    er.ncols = (HWtot - p0) / 16 < 4 ? (HWtot - p0) / 16 : 4;
+  } else {
+    er.m0 = (int)((frame * (uint32_t)a.Ho + (uint32_t)hw0) * (uint32_t)a.Wo + (uint32_t)w0);
+    er.ipr = TW / 16;
+    er.rstride = a.Wo;
+    er.nrows = a.Ho - hw0 < 0 ? 0 : (a.Ho - hw0 > WROWS ? WROWS : a.Ho - hw0);
+    er.ncols = TW / 16;
+  }
   const int kq = lane >> 4;                                           // this lane's 16-byte k group inside a 32-wide K half
   const int bfo0 = (lane & 15) * 128 + (((kq) ^ (lane & 7)) << 4);    // weight fragment rows: n & 7 == lane & 7
   const int bfo1 = (lane & 15) * 128 + (((4 + kq) ^ (lane & 7)) << 4);
@@ -197,8 +261,9 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
     for (int j = 0; j < GT; ++j) {
       const bool in = (t0 + j < a.ntaps) && (nt == j);
       const int4 tp = load_tap(a.taps, t0 + j < a.ntaps ? t0 + j : t0);
-      const bool same = in && tp.x == dt;
-      const unsigned long long e = (unsigned long long)(((tp.w & 0xff) << 8) | ((tp.y * HW + tp.z + 128) & 0xff));
+      const bool same = in && (TM || tp.x == dt);           // temporal mode: every tap is (dt, 0, 0): one group
+      const int off = TM ? tp.x * HW : tp.y * HW + tp.z;     // halo offset of the tap: rows are frames there
+      const unsigned long long e = (unsigned long long)(((tp.w & 0xff) << 8) | ((off + 128) & 0xff));
       if (j < 4) tq0 |= e << (j * 16);
       else if (j < 8) tq1 |= e << ((j - 4) * 16);
       else tq2 = (uint32_t)e;
@@ -221,6 +286,9 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
       int slot = 0, fill = BSLOTS - 1;
       for (int j = 0; j < nt; ++j) {
         wait_vmcnt<BL*(BSLOTS - 2)>();             // halo image (first step) and my weight DMAs of this step have landed
+        if constexpr (PRE) {
+          if (j == 0) xform_halo(c0);
+        }
 #ifdef VINET_CONV_TIMING
         if (j == 0) tm_halo += __builtin_amdgcn_s_memtime() - tm_h0;
 #endif
@@ -255,19 +323,20 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int NT, int TW, int BSLOTS>
+template <int NT, int TW, int BSLOTS, bool TM = false, bool PRE = false>
 static int launch_conv_ht_cfg(const ConvArgs& a, hipStream_t s) {
-  using Cfg = ConvHtCfg<NT, TW, BSLOTS>;
-  auto kern = conv_ht_kernel<NT, TW, BSLOTS>;
+  using Cfg = ConvHtCfg<NT, TW, BSLOTS, TM, PRE>;
+  auto kern = conv_ht_kernel<NT, TW, BSLOTS, TM, PRE>;
   static bool attr_done[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_done[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::smem_bytes(1024));
     if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_ht): %s", hipGetErrorString(e)); return (int)e; }
     attr_done[dev & 63] = true;
   }
-  const long grid = (long)a.tilesN * a.ht_tilesW * a.ht_tilesH * a.To * (a.M / ((long)a.To * a.Ho * a.Wo));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), Cfg::SMEM, s, a);
+  const long Bn = a.M / ((long)a.To * a.Ho * a.Wo);
+  const long grid = (long)a.tilesN * a.ht_tilesW * a.ht_tilesH * (TM ? 1 : a.To) * Bn;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), Cfg::smem_bytes(a.Kp), s, a);
   return vn_launch_status("conv_ht");
 }

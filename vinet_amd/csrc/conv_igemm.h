@@ -103,9 +103,9 @@ VN_DEV void wave_lds_fence() {
 
 // Row -> voxel map of a wave's 16-row groups.  Row-tiled kernels: group i starts at voxel m0 + 16 i (ipr == 0).  Spatial
 // halo tiles (conv_ht.h): a wave owns `ipr` groups per image row, group i starts at m0 + (i / ipr) * rstride + (i % ipr) * 16
-// and is inside the iteration space iff i / ipr < nrows.
+// and is inside the iteration space iff i / ipr < nrows and i % ipr < ncols.
 struct EpiRows {
-  int m0, ipr, rstride, nrows;
+  int m0, ipr, rstride, nrows, ncols;
 };
 
 // `rows` (optional): see EpiRows; nullptr = rows tile_m*BM + ... as usual.  `tile_m` stays the statistics row of the workgroup.
@@ -121,10 +121,10 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   const int n_wave = tile_n * BN + wn * WNC;
   const bool do_stats = a.stats != nullptr;
   const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;   // branch-free ReLU: max(v, floor)
-  const EpiRows er = rows ? *rows : EpiRows{m_wave, 0, 0, 0};
+  const EpiRows er = rows ? *rows : EpiRows{m_wave, 0, 0, 0, 0};
   // first voxel of row group i, and how many of its 16 rows lie inside the iteration space
   auto group_m0 = [&](int i) { return er.ipr ? er.m0 + (i / er.ipr) * er.rstride + (i % er.ipr) * 16 : er.m0 + i * 16; };
-  auto group_rows = [&](int i) { return er.ipr ? ((i / er.ipr) < er.nrows ? 16 : 0) : a.M - (er.m0 + i * 16); };
+  auto group_rows = [&](int i) { return er.ipr ? (((i / er.ipr) < er.nrows && (i % er.ipr) < er.ncols) ? 16 : 0) : a.M - (er.m0 + i * 16); };
   // element offset of voxel m (channel 0) in y: any placement (a stride phase of a data gradient scatters its rows)
   auto voxel_off = [&](int m) {
     if (a.y_linear) return (long)m * a.ldy;
@@ -588,7 +588,7 @@ int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipSt
 int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_pp_bf16(int bn, const ConvArgs& a, hipStream_t s);
-int vinet_launch_conv_ht_bf16(int nt, int tw, const ConvArgs& a, hipStream_t s);
+int vinet_launch_conv_ht_bf16(int nt, int tw, int tm, int pre, const ConvArgs& a, hipStream_t s);
 
 template <typename T, int MT, int NT, int WM, int WN, int MODE>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {

@@ -828,9 +828,8 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     `n_pad`       : store into a channel-padded output (N not a multiple of the vector width).
     """
     lib_dt = ctx.dt
-    if (MATERIALIZE_NT and x.scale is not None and ctx.dt != L.F32 and x.fold is None and not plan.stem and
-            plan.N * plan.ntaps >= MATERIALIZE_NT and x.v.dt == ctx.dt):
-        x = materialize(ctx, x)
+    want_plain = (MATERIALIZE_NT and x.scale is not None and ctx.dt != L.F32 and x.fold is None and not plan.stem and
+                  plan.N * plan.ntaps >= MATERIALIZE_NT and x.v.dt == ctx.dt)
     xv = x.v
     folded = plan.stem and x.fold is not None
     if folded:
@@ -864,6 +863,11 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         d.tline = 2                         # taps (0, kh, 0, kh): ConvPlan.folded_taps
     elif plan.spatial3:
         d.tline = 5                         # 3 x 3 spatial footprint, kt-major tap order: ConvPlan.fwd_taps
+    if want_plain and not ctx.lib.vinet_conv3d_applies_pre_once(C.byref(d)):
+        # (the halo-tile kernel applies a pending BN + ReLU once per staged element: no materialisation pass for its layers)
+        x = materialize(ctx, x)
+        xv = x.v
+        d.x, d.pre = xv.ct(), x.affine()
     M = xv.B * oT * oH * oW
     site = plan.site(xv)
     es = ESIZE[lib_dt]
