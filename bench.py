@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="infer mode: replay a captured hipGraph")
     ap.add_argument("--no-side-stream", action="store_true", help="run wgrad on the main stream (A/B)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-site HIP-event table to stderr")
+    ap.add_argument("--main-priority", type=int, default=0, help="tuning: run the step on a stream of this priority (-1 = high) instead of the default stream")
     return ap.parse_args()
 
 
@@ -186,6 +187,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.main_priority != 0:
+        hp = torch.cuda.Stream(dev, priority=args.main_priority)
+        hp.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(hp)
     # ---- warm-up; the last warm-up step is bracketed site by site to find the dominant kernel site
     graphed = args.mode == "infer" and args.graph
     for i in range(max(args.warmup, 1)):

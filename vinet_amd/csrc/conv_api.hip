@@ -316,7 +316,12 @@ static bool use_ht(const VinetConvDesc* d) {
   // 331 -> 510 on 64 -> 32 -- and loses where a chunk is half padding (Cin = 32: 410 -> 310; Cin = 96: 608 -> 535)
   const int N = d->y.C;
   const int k64 = (d->Kp + 63) / 64 * 64;
-  return (long)d->oH * d->oW >= (tm ? g_vinet_opt_ht_t_minhw : g_vinet_opt_ht_minhw) && N >= 32 && k64 * 20 <= d->Kp * 23;
+  // a grid that cannot fill the chip (batch-1 inference: 84 tiles for the 192 -> 64 decoder conv) stays with conv_dma, which
+  // splits its K loop over workgroups there (561 fps at batch 1 with graph replay; 515 with the halo tiles)
+  const HtShape h = ht_shape(d);
+  const long tiles = (tm ? (long)d->x.B * vn_div_up(d->oT, 4) * vn_div_up((long)d->oH * d->oW, 64)
+                         : (long)d->x.B * d->oT * vn_div_up(d->oH, 256 / h.tw) * vn_div_up(d->oW, h.tw)) * vn_div_up(N, h.nt * 16);
+  return tiles >= 384 && (long)d->oH * d->oW >= (tm ? g_vinet_opt_ht_t_minhw : g_vinet_opt_ht_minhw) && N >= 32 && k64 * 20 <= d->Kp * 23;
 }
 
 // ---- split-K for grids that cannot fill the chip (batch-1 inference) ---------------------------

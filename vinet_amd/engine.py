@@ -42,7 +42,7 @@ STEM_FOLD = os.environ.get("VINET_STEM_FOLD", "1") != "0"   # padded/folded stem
 WGRAD_SIDE_STREAM = True
 # CUs the persistent weight-gradient kernels may occupy while they run beside the main stream (conv_api.hip: wgrad_cus);
 # without a second stream they are alone on the GPU and get all of it
-WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "144"))
+WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "160"))
 _WGRAD_CUS_SET = {}
 _SIDE_STREAMS = {}
 
