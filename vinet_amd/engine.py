@@ -97,6 +97,7 @@ JOINT_ENTRY = int(os.environ.get("VINET_JOINT_ENTRY", "1"))
 # the stem's BN-backward apply pass folded into its weight-gradient kernel (0 = separate pass)
 BN_BWD_FUSE = int(os.environ.get("VINET_BN_BWD_FUSE", "1"))
 # weight gradients of the BN-free (decoder) convs wait on the side stream until the tape reaches the encoder (0 = launch in tape order); +0.5 % on the whole step at 192 clips (550.7 / 551.7 vs 548.2 / 548.2 clips/s, alternating runs on one box)
+SHARE_SKIP_GRAD = os.environ.get("VINET_SHARE_SKIP_GRAD", "1") != "0"
 DEFER_DECODER_WGRAD = int(os.environ.get("VINET_DEFER_DECODER_WGRAD", "1"))
 # packed weight-gradient workspaces owned by the conv plans and re-zeroed by vinet_unpack_wgrad (0 = a torch.zeros per conv and step)
 PERSISTENT_DW = int(os.environ.get("VINET_PERSISTENT_DW", "1"))
@@ -386,8 +387,13 @@ def import_grad_ncdhw(ctx, a, gt):
     a.mark_grad_ready()
 
 
-def materialize(ctx, a, dst=None, out_dt=None):
+def materialize(ctx, a, dst=None, out_dt=None, share_grad=False):
     """apply the pending affine (or just copy / convert) into `dst`; returns a plain Act.
+
+    share_grad: `dst` is a slice of a tensor whose gradient is written (stored) before any other consumer of `a` runs its
+    backward (a decoder skip: the decoder's backward precedes the encoder's).  `a` then takes dst's gradient storage as
+    its own -- the later consumers accumulate into it and a's producer reads it from there -- and backward needs no copy.
+    Only an activation that owns its gradient storage can be re-homed (not a member of a concat).
 
     With a fresh destination of the activation dtype the result SHARES a's gradient storage: the gradient w.r.t. the
     materialised values is the gradient w.r.t. a's post-affine output, which is what a.grad holds (the producer's BN
@@ -403,6 +409,10 @@ def materialize(ctx, a, dst=None, out_dt=None):
     dst.needs_grad = a.needs_grad
     if alias:
         dst.parent, dst.pc0, dst.pt0 = a, 0, None        # identity "slice": grad_view / readiness resolve into a's
+        return dst
+    if (share_grad and SHARE_SKIP_GRAD and ctx.recording and a.needs_grad and a.parent is None and a._grad is None
+            and dst.parent is not None and out.dt == v.dt):
+        a.parent, a.pc0, a.pt0 = dst, 0, None            # a's gradient lives in dst's slice of the concat gradient
         return dst
     if ctx.recording and a.needs_grad:
         def bwd():

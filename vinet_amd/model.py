@@ -111,7 +111,7 @@ class _DecoderConvUp(nn.Module):
         assert (sv.H, sv.W, sv.C) == (2 * zv.H, 2 * zv.W, zv.C), "skip connection shape mismatch"
         cat = E.Act(E.View.alloc(zv.B, zv.T + sv.T, sv.H, sv.W, zv.C, ctx.dt, ctx.device), needs_grad=True)
         E.upsample2x_forward(ctx, z, cat.sub_t(0, zv.T))
-        E.materialize(ctx, skip, cat.sub_t(zv.T, zv.T + sv.T))
+        E.materialize(ctx, skip, cat.sub_t(zv.T, zv.T + sv.T), share_grad=True)
         return cat
 
     def _fwd(self, ctx, y0, y1, y2, y3):
