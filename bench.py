@@ -318,6 +318,8 @@ def main():
         roof.update(traffic=traffic, kernel=dom, launches=domstat["count"], avg_us=avg_s * 1e6,
                     algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=byts,
                     also={"TFLOP/s": flops / avg_s / 1e12, "GB/s": byts / avg_s / 1e9})
+        if args.mode == "train" and engine.WGRAD_SIDE_STREAM:
+            roof["note"] = "per-launch time measured inside the step, where the weight-gradient stream shares the CUs and HBM; bench.py --no-side-stream --profile-all gives the kernel alone"
         if traffic is not None:
             roof["traffic_source"] = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes); (2*FETCH+WRITE)*1024 B, L2-miss traffic incl. Infinity-Cache hits"
             roof["mfma_busy_frac_pmc"] = pmc.get("mfma_busy_frac")

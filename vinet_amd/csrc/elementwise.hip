@@ -1781,6 +1781,84 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s1_twalk_kernel(TView dy, c
   }
 }
 
+// Same walk for bf16 with every load of a plane issued up front: the 9 argmax words AND the 9 gradient vectors of the
+// in-plane neighbour windows are fetched unconditionally (they are L1 / L2 hits for 8 of 9 lanes), 18 independent loads
+// per lane and plane, so a lane pays one memory latency per plane instead of two dependent ones
+// (the conditional gradient loads of the form above left the kernel latency-bound at 1.4 TB/s).  Routing is branch-free:
+// byte code - (kh*3+kw) is 0 / 9 / 18 for the temporal taps to-1 / to / to+1.
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s1_tw2_kernel(TView dy, const uint8_t* __restrict__ argmax, TView dx,
+                                                                   int accumulate, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = dx.C >> 3;
+  const uint32_t col = (uint32_t)(i / G);
+  const int g = (int)(i - (long)col * G);
+  const uint32_t r1 = fdiv(col, dx.dW);
+  const int w = (int)(col - r1 * (uint32_t)dx.W);
+  const uint32_t r2 = fdiv(r1, dx.dH);
+  const int h = (int)(r1 - r2 * (uint32_t)dx.H);
+  const int b = (int)r2;
+  const int T_ = dx.T, H = dx.H, W = dx.W;
+  // lane-relative addresses of the 9 windows (the lane's own voxel where the window does not exist: any valid address)
+  const uint8_t* amp = argmax + ((((long)b * T_) * H + h) * W + w) * (long)dx.C + g * 8;
+  const unsigned short* dyp = (const unsigned short*)dy.p + vox_off(dy, b, 0, h, w) + g * 8;
+  const long am_plane = (long)H * W * dx.C, dy_plane = (long)H * W * dy.ld;
+  uint32_t okmask = 0;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ho = h + 1 - kh, wo = w + 1 - kw;
+      okmask |= (((unsigned)ho < (unsigned)H && (unsigned)wo < (unsigned)W) ? 1u : 0u) << (kh * 3 + kw);
+    }
+  float g_m[8], g_0[8], g_p[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { g_m[e] = 0.f; g_0[e] = 0.f; g_p[e] = 0.f; }
+  for (int to = 0; to <= T_; ++to) {
+    if (to < T_) {
+      unsigned long long am[9];
+      uint4 dv[9];
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        const int dvox = (1 - s / 3) * W + (1 - s % 3);
+        const bool ok = (okmask >> s) & 1u;
+        am[s] = *(const unsigned long long*)(amp + (ok ? dvox * dx.C : 0));
+        dv[s] = *(const uint4*)(dyp + (ok ? dvox * dy.ld : 0));
+      }
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        const unsigned long long a = ((okmask >> s) & 1u) ? am[s] : ~0ull;
+        const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32);
+        const uint32_t q[4] = {dv[s].x, dv[s].y, dv[s].z, dv[s].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t c = (((e < 4) ? alo : ahi) >> (8 * (e & 3))) & 0xffu;
+          const int dlt = (int)c - s;
+          const float v = (e & 1) ? __uint_as_float(q[e >> 1] & 0xffff0000u) : __uint_as_float(q[e >> 1] << 16);
+          g_m[e] += (dlt == 0) ? v : 0.f;
+          g_0[e] += (dlt == 9) ? v : 0.f;
+          g_p[e] += (dlt == 18) ? v : 0.f;
+        }
+      }
+      amp += am_plane;
+      dyp += dy_plane;
+    }
+    const int t = to - 1;
+    if (t >= 0) {
+      unsigned short* dst = (unsigned short*)dx.p + vox_off(dx, b, t, h, w) + g * 8;
+      if (accumulate) {
+        float o[8];
+        ld8<unsigned short>(dst, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g_m[e] += o[e];
+      }
+      st8<unsigned short>(dst, g_m);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { g_m[e] = g_0[e]; g_0[e] = g_p[e]; g_p[e] = 0.f; }
+  }
+}
+
 extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy, const uint8_t* argmax,
                                    const VinetTensor* dx, int32_t accumulate, void* stream) {
   VN_CHECK_ARG(d && dy && dx && argmax && quad_ok(*dy, esize(d->dtype)) && quad_ok(*dx, esize(d->dtype)) &&
@@ -1791,6 +1869,12 @@ extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy
   if (k3s1 && dx->C % 8 == 0 && dx->ld % 8 == 0 && dy->ld % 8 == 0 && dx->sB % 8 == 0 && dy->sB % 8 == 0 &&
       ((uintptr_t)dx->ptr % 16) == 0 && ((uintptr_t)dy->ptr % 16) == 0 && ((uintptr_t)argmax % 8) == 0) {
     const long cols8 = (long)dx->B * dx->H * dx->W * (dx->C / 8);
+    if (g_vinet_opt_pool_twalk != 3 && d->dtype == VINET_BF16 && (g_vinet_opt_pool_twalk >= 2 || (g_vinet_opt_pool_twalk && cols8 >= 65536)) &&
+        (long)dx->H * dx->W * dx->C < (1l << 30) && (long)dx->H * dx->W * dy->ld < (1l << 30)) {   // 3: the conditional-load form (A/B)
+      hipLaunchKernelGGL(maxpool_bwd_k3s1_tw2_kernel, dim3(ew_grid(cols8)), dim3(256), 0, (hipStream_t)stream, make_view(*dy), argmax,
+                         make_view(*dx), accumulate, cols8);
+      return vn_launch_status("maxpool3d_bwd(k3s1 tw2)");
+    }
     if (g_vinet_opt_pool_twalk >= 2 || (g_vinet_opt_pool_twalk && cols8 >= 65536)) {   // 2: force (tests)   // enough columns to fill the chip
       DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_k3s1_twalk_kernel<T>, dim3(ew_grid(cols8)), dim3(256), 0,
                                                  (hipStream_t)stream, make_view(*dy), argmax, make_view(*dx), accumulate, cols8);)
