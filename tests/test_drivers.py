@@ -156,3 +156,96 @@ def test_device_batch_equals_the_reference_transforms(tmp_path):
         assert g.shape == (1,) + tuple(raw[1][0].shape) and np.array_equal(g[0].numpy(), Q.gt_preprocess(raw[1][0].numpy()[None])[0])
     finally:
         L._install_test_double(None)
+
+
+def _crc(a):
+    import zlib
+    import numpy as np
+    return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def _dataset_goldens():
+    import json
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "datasets.json")) as f:
+        return json.load(f)["cases"], np.load(os.path.join(here, "datasets_audio.npz"))
+
+
+def test_sound_dataset_loader_against_the_reference_selection(tmp_path):
+    """dataloader.py:124-233 on the synthetic DIEM tree: lengths, sorted fold list, annotated-clip selection, which frame /
+    map files an item decodes (seeded train draws included), the float64 map values and the windowed audio excerpt --
+    all against what the reference's own class produced on the same tree (tests/golden/make_dataset_goldens.py)"""
+    import numpy as np
+    from tests import dataset_trees as TR
+    from tests.abi_emulator import AbiEmulator
+    from vinet_amd import _lib as L
+    from vinet_amd import dataloader as DL
+    cases, audio = _dataset_goldens()
+    TR.make_sound_tree(str(tmp_path))
+    L._install_test_double(AbiEmulator())
+    try:
+        for mode in ("train", "val", "test"):
+            want = cases["SoundDatasetLoader/" + mode]
+            ds = DL.SoundDatasetLoader(TR.SOUND_T, dataset_name='DIEM', split=1, mode=mode, use_sound=True, path_data=str(tmp_path))
+            assert len(ds) == want["len"] and list(ds.list_indata) == want["list_indata"]
+            assert [list(x) if isinstance(x, tuple) else int(x) for x in ds.list_num_frame] == want["list_num_frame"]
+            assert sorted(ds.audiodata.keys()) == want["audio_videos"] and ds.max_audio_win == 70560
+            batch = DL.DeviceBatch(torch.device("cpu"), "val", audiodata=ds.audiodata, gt_dtype=torch.float64)
+            for it in want["items"]:
+                np.random.seed(100 + it["idx"])
+                clip, gt, ref = ds[it["idx"]]
+                assert clip.dtype == torch.uint8 and list(clip.shape) == it["clip_shape"] and _crc(clip.numpy()) == it["clip_crc"]
+                g = gt.numpy().astype('float')
+                g = g / 255.0 if g.max() > 1.0 else g
+                assert it["gt_dtype"] == "float64"                         # F11: this loader's maps reach the loss as doubles
+                if it["gt_crc"] is not None:
+                    assert list(g.shape) == it["gt_shape"] and _crc(g) == it["gt_crc"]
+                x, gd, af = batch(([clip], [gt], [ref]))
+                assert gd.dtype == torch.float64 and np.allclose(gd[0].numpy(), g, rtol=0, atol=6e-8)
+                assert list(af.shape[1:]) == it["audio_shape"] and np.array_equal(af.view(-1).numpy(), audio[it["audio"]])
+        ns = DL.SoundDatasetLoader(TR.SOUND_T, dataset_name='DIEM', mode="val", path_data=str(tmp_path))
+        assert len(ns) == cases["SoundDatasetLoader/val/no_sound"]["len"] and len(ns[0]) == cases["SoundDatasetLoader/val/no_sound"]["n_out"]
+    finally:
+        L._install_test_double(None)
+
+
+def test_hollywood_ucf_dataset_against_the_reference_selection(tmp_path, monkeypatch):
+    """dataloader.py:310-391: per-mode lengths and starts, front padding of a video shorter than a clip, last-frame vs
+    multi-frame maps with the per-map /255 rule -- against the reference class's output on the same tree"""
+    import os
+    import numpy as np
+    from tests import dataset_trees as TR
+    from tests.abi_emulator import AbiEmulator
+    from vinet_amd import _lib as L
+    from vinet_amd import dataloader as DL
+    cases, _ = _dataset_goldens()
+    TR.make_hollywood_tree(str(tmp_path))
+    real_listdir = os.listdir
+    monkeypatch.setattr(os, "listdir", lambda p: sorted(real_listdir(p)))   # the golden was captured with sorted directory order
+    L._install_test_double(AbiEmulator())
+    try:
+        for mode in ("train", "val"):
+            for mf in (0, 1):
+                want = cases["Hollywood_UCFDataset/%s/mf%d" % (mode, mf)]
+                ds = DL.Hollywood_UCFDataset(str(tmp_path), TR.HOLLY_T, mode=mode, multi_frame=mf)
+                assert len(ds) == want["len"]
+                assert [list(x) if isinstance(x, tuple) else int(x) for x in ds.list_num_frame] == want["list_num_frame"]
+                batch = DL.DeviceBatch(torch.device("cpu"), mode)
+                for it in want["items"]:
+                    np.random.seed(7 + it["idx"])
+                    clip, gt = ds[it["idx"]]
+                    assert list(clip.shape) == it["clip_shape"] and _crc(clip.numpy()) == it["clip_crc"]
+                    x, gd = batch(([clip], [gt]))
+                    assert x.shape == (1, TR.HOLLY_T, 3, 224, 384)
+                    if mode == "val":
+                        maps = gt.numpy()[None] if mf == 0 else gt.numpy()
+                        g = np.stack([(m.astype('float') / 255.0 if m.max() > 1 else m.astype('float')) for m in maps]).astype(np.float32)
+                        g = g[0] if mf == 0 else g
+                        assert it["gt_dtype"] == "torch.float32" and list(g.shape) == it["gt_shape"] and _crc(g) == it["gt_crc"]
+                        assert np.array_equal(gd[0].numpy(), g)
+                    else:
+                        assert tuple(gd.shape[-2:]) == (224, 384)
+    finally:
+        L._install_test_double(None)

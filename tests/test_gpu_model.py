@@ -389,6 +389,27 @@ def test_train_driver_on_a_dhf1k_directory(tmp_path, capsys):
     assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
 
 
+def test_train_driver_on_sound_and_hollywood_directories(tmp_path, capsys):
+    """train.py:101-136 with the other two loaders: SoundDataset (double ground-truth maps, ViNet-8 without the audio
+    branch) and Hollywood_UCFDataset, bytes -> device preprocessing -> train epoch -> validate"""
+    from tests import dataset_trees as TREES
+    from vinet_amd import train as TR
+    TREES.make_sound_tree(str(tmp_path / "sound"))
+    args = TR.build_parser().parse_args(["--dataset", "SoundDataset", "--sound_path_data", str(tmp_path / "sound"), "--sound_datasets", "DIEM",
+                                         "--clip_size", "8", "--batch_size", "2", "--no_epochs", "1", "--no_workers", "0",
+                                         "--log_interval", "1", "--model_val_path", str(tmp_path / "s.pt")])
+    TR.run(args)
+    out = capsys.readouterr().out
+    assert "[ 0, train] avg_loss" in out and "[ 0, val] avg_loss" in out and "nan" not in out
+    TREES.make_hollywood_tree(str(tmp_path / "holly"))
+    args = TR.build_parser().parse_args(["--dataset", "Hollywood_UCFDataset", "--train_path_data", str(tmp_path / "holly"), "--val_path_data",
+                                         str(tmp_path / "holly"), "--clip_size", "8", "--batch_size", "2", "--no_epochs", "1",
+                                         "--no_workers", "0", "--log_interval", "1", "--model_val_path", str(tmp_path / "h.pt")])
+    TR.run(args)
+    out = capsys.readouterr().out
+    assert "[ 0, train] avg_loss" in out and "[ 0, val] avg_loss" in out and "nan" not in out
+
+
 def test_audio_visual_harness_with_avinet(tmp_path):
     """generate_result_audio_visual.py's flow with the real AViNet (32 x 224 x 384 is fixed by the model): files for every
     frame; a forward and a time-flipped call re-computed by hand (oracle excerpt, oracle post-processing)"""

@@ -7,9 +7,10 @@ the seeds (train.py:90-91), the log format (train.py:222,226) and the best-val
 checkpoint rule (train.py:280-290), but is importable (argparse runs in main()),
 uses one process per GPU with an RCCL all-reduce instead of nn.DataParallel
 (train.py:181-185), and can run on synthetic clips (`--dataset synthetic`) because
-the benchmark box has no datasets.  Dataset decoding (dataloader.py) is a "next"
-row of SURVEY.md section 8(f): pass any torch Dataset yielding
-(clip [T,3,H,W], gt [H,W]) through `run(args, train_dataset, val_dataset)`.
+the benchmark box has no datasets.  `--dataset DHF1KDataset | SoundDataset | Hollywood_UCFDataset`
+select the byte-yielding counterparts of the reference's loaders (vinet_amd/dataloader.py; resize / normalise / audio
+windowing run on the device); any torch Dataset yielding (clip [T,3,H,W], gt [H,W]) can be passed through
+`run(args, train_dataset, val_dataset)`.
 
     python -m vinet_amd.train --dataset synthetic --no_epochs 1 --batch_size 8
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m vinet_amd.train ...
@@ -75,6 +76,9 @@ def build_parser():
     # additions of this build
     p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
     p.add_argument('--synthetic_steps', default=20, type=int, help="steps per epoch with --dataset synthetic")
+    p.add_argument('--sound_path_data', default="/ssd_scratch/cvit/samyak/data/", type=str,
+                   help="root of the audio-visual sets (hard-coded in the reference: dataloader.py:127)")
+    p.add_argument('--sound_datasets', default="DIEM,Coutrot_db1,Coutrot_db2,AVAD,ETMD_av,SumMe", type=str)
     p.add_argument('--height', default=224, type=int)
     p.add_argument('--width', default=384, type=int)
     p.add_argument('--s3d_weight', default="./S3D_kinetics400.pt", type=str,
@@ -223,8 +227,25 @@ def run(args, train_dataset=None, val_dataset=None):
         train_dataset = dataloader.DHF1KDataset(args.train_path_data, args.clip_size, mode="train", alternate=args.alternate)
         val_dataset = dataloader.DHF1KDataset(args.val_path_data, args.clip_size, mode="val", alternate=args.alternate)
         collate = dataloader.collate_bytes
+    audiodata, gt_dtype = None, None
+    if train_dataset is None and args.dataset == "SoundDataset":           # train.py:101-132: the six audio-visual sets, concatenated
+        from . import dataloader
+        names = [n for n in args.sound_datasets.split(',') if n]
+        mk = lambda name, mode: dataloader.SoundDatasetLoader(args.clip_size, mode=mode, dataset_name=name, split=args.split,
+                                                              use_sound=args.use_sound, use_vox=args.use_vox, path_data=args.sound_path_data)
+        tr, va = [mk(n, "train") for n in names], [mk(n, "test") for n in names]
+        train_dataset, val_dataset = torch.utils.data.ConcatDataset(tr), torch.utils.data.ConcatDataset(va)
+        audiodata = {}
+        for d in tr + va:
+            audiodata.update(d.audiodata)
+        collate, gt_dtype = dataloader.collate_bytes, torch.float64       # this loader hands the loss double maps (dataloader.py:222-226)
+    elif train_dataset is None and args.dataset not in ("synthetic", "DHF1KDataset"):   # train.py:133-136: Hollywood-2 / UCF-Sports
+        from . import dataloader
+        train_dataset = dataloader.Hollywood_UCFDataset(args.train_path_data, args.clip_size, mode="train")
+        val_dataset = dataloader.Hollywood_UCFDataset(args.val_path_data, args.clip_size, mode="val")
+        collate = dataloader.collate_bytes
     if train_dataset is None:
-        assert args.dataset == "synthetic", "--dataset: synthetic | DHF1KDataset (or pass datasets to run()); the other loaders are out of scope"
+        assert args.dataset == "synthetic", "--dataset: synthetic | DHF1KDataset | SoundDataset | Hollywood_UCFDataset (or pass datasets to run())"
         train_dataset = SyntheticClips(args.synthetic_steps * args.batch_size, args.clip_size, args.height, args.width, args.use_sound)
         val_dataset = SyntheticClips(2 * world, args.clip_size, args.height, args.width, args.use_sound)
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True) if world > 1 else None
@@ -233,8 +254,8 @@ def run(args, train_dataset=None, val_dataset=None):
     val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=1, shuffle=False, num_workers=0, collate_fn=collate)
     if collate is not None:
         from . import dataloader
-        train_loader.device_batch = dataloader.DeviceBatch(device, "train")
-        val_loader.device_batch = dataloader.DeviceBatch(device, "val")
+        train_loader.device_batch = dataloader.DeviceBatch(device, "train", audiodata=audiodata, gt_dtype=gt_dtype)
+        val_loader.device_batch = dataloader.DeviceBatch(device, "val", audiodata=audiodata, gt_dtype=gt_dtype)
     params = parallel.trainable_parameters(model)
     optimizer = optim.Adam(params, lr=args.lr)
     parallel.broadcast_parameters(optimizer)
