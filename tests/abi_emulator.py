@@ -513,7 +513,7 @@ class AbiEmulator:
         d, x, y = _deref(d), _deref(x), _deref(y)
         xa = affine(rd(x, d.dtype), pre, x.C)
         if d.dtype != F32 and pre.scale:
-            # pooling sees the pending affine applied AND rounded to the activation dtype (elementwise.hip: pool_round)
+            # pooling sees the pending affine applied AND rounded to the activation dtype (pool.hip: pool_round)
             xa = _bf2f(_f2bf(np.ascontiguousarray(xa).reshape(-1))).reshape(xa.shape)
         xv = torch.from_numpy(np.ascontiguousarray(xa)).permute(0, 4, 1, 2, 3)
         out, idx = torch.nn.functional.max_pool3d(xv, (d.kT, d.kH, d.kW), (d.sT, d.sH, d.sW), (d.pT, d.pH, d.pW),

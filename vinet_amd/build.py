@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libvinet_hip.so")
-SOURCES = ["conv_api.hip", "conv_bf16.hip", "conv_f32.hip", "conv_wgrad.hip", "wgrad_dma.hip", "wgrad_pp.hip", "wgrad_ts.hip", "conv_ts.hip", "wgrad_hs.hip", "wgrad_rs.hip", "wgrad_tf.hip", "conv_hs.hip", "elementwise.hip", "loss_adam.hip", "postproc.hip", "preproc.hip"]
+SOURCES = ["conv_api.hip", "conv_bf16.hip", "conv_f32.hip", "conv_wgrad.hip", "wgrad_dma.hip", "wgrad_pp.hip", "wgrad_ts.hip", "conv_ts.hip", "wgrad_hs.hip", "wgrad_rs.hip", "wgrad_tf.hip", "conv_hs.hip", "layout.hip", "bn.hip", "pool.hip", "resample.hip", "loss_adam.hip", "postproc.hip", "preproc.hip"]
 HEADERS = ["common.h", "conv_igemm.h", "conv_dma.h", "conv_pp.h", os.path.join(ROOT, "include", "vinet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result", "-ffp-contract=off"]

@@ -1,0 +1,418 @@
+// Layout and packing kernels: conv weights -> packed bf16 / fp32 tiles (single and multi-tensor), packed fp32 weight
+// gradients -> torch layout, NCDHW <-> channels-last import / export, copy with the pending affine (concat, materialise),
+// the skinny (<= 8 output channels) pointwise weight gradient, SoundNet's 1-D unfold, fp32 fill.
+#include "elementwise.h"
+
+// ============================================================================
+// weight packing
+// ============================================================================
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, int N, int Cin, int ntaps, int transpose, int stem,
+                                    int rows, int Kp, int nslices, T* __restrict__ out) {
+  const long total = (long)nslices * rows * Kp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    const int r = (int)((i / Kp) % rows);
+    const int s = (int)(i / ((long)Kp * rows));
+    float v = 0.f;
+    if (stem) {  // out[kh][n][kw*4+c], w[n][c][kh*7+kw]
+      const int kw = k >> 2, c = k & 3;
+      if (kw < 7 && c < Cin) v = w[((long)r * Cin + c) * ntaps + s * 7 + kw];
+    } else if (!transpose) {  // out[t][n][c]
+      if (k < Cin) v = w[((long)r * Cin + k) * ntaps + s];
+    } else {  // out[t][c][n]
+      if (k < N) v = w[((long)k * Cin + r) * ntaps + s];
+    }
+    store1<T>(out + i, v);
+  }
+}
+
+extern "C" int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_t ntaps, int32_t transpose,
+                                  int32_t stem, int32_t dtype, void* out, void* stream) {
+  VN_CHECK_ARG(w && out && N > 0 && Cin > 0 && ntaps > 0, "pack_weights: bad arguments");
+  int rows, Kp, nslices;
+  if (stem) {
+    VN_CHECK_ARG(ntaps == 49 && Cin <= 4 && !transpose, "pack_weights stem: need 1x7x7, Cin<=4");
+    rows = N; Kp = 32; nslices = 7;
+  } else if (!transpose) { rows = N; Kp = (Cin + 31) / 32 * 32; nslices = ntaps; }
+  else { rows = Cin; Kp = (N + 31) / 32 * 32; nslices = ntaps; }
+  const long total = (long)nslices * rows * Kp;
+  int grid = ew_grid(total); if (grid > 8192) grid = 8192;
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, N,
+                                          Cin, ntaps, transpose, stem, rows, Kp, nslices, (T*)out);)
+  return vn_launch_status("pack_weights");
+}
+
+// Multi-tensor form: every weight of the model is re-packed after each optimizer step, 170 launches of a few
+// microseconds each when done one by one.  `table` (device memory) holds 8 int64 per job:
+//   { w pointer, out pointer, N, Cin, ntaps, transpose | stem << 1, first output index (prefix sum), ld | col << 32 }
+// ld != 0 (transposed jobs only): rows of the destination are `ld` elements apart and this job owns columns
+// [col, col + N) of them -- several convs that share an input, packed side by side along K for ONE dgrad.
+// plus one trailing row whose prefix field is the total; one thread per output element, job by binary search.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long* __restrict__ table, int njobs, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = njobs;               // last job with prefix <= i
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (table[mid * 8 + 6] <= i) lo = mid; else hi = mid;
+    }
+    const long* J = table + lo * 8;
+    const float* w = (const float*)J[0];
+    T* out = (T*)J[1];
+    const int N = (int)J[2], Cin = (int)J[3], ntaps = (int)J[4];
+    const int transpose = (int)(J[5] & 1), stem = (int)((J[5] >> 1) & 1);
+    const long e = i - J[6];
+    const int rows = (stem || !transpose) ? N : Cin;
+    const int Kp = stem ? 32 : ((transpose ? N : Cin) + 31) / 32 * 32;
+    const int k = (int)(e % Kp);
+    const int r = (int)((e / Kp) % rows);
+    const int sl = (int)(e / ((long)Kp * rows));
+    float v = 0.f;
+    if (stem) {
+      const int kw = k >> 2, c = k & 3;
+      if (kw < 7 && c < Cin) v = w[((long)r * Cin + c) * ntaps + sl * 7 + kw];
+    } else if (!transpose) {
+      if (k < Cin) v = w[((long)r * Cin + k) * ntaps + sl];
+    } else {
+      if (k < N) v = w[((long)k * Cin + r) * ntaps + sl];
+      const long ld = J[7] & 0xffffffffl;
+      if (ld) {          // side-by-side destination: only the job's own columns are written
+        if (k < N) store1<T>(out + ((long)sl * rows + r) * ld + (J[7] >> 32) + k, v);
+        continue;
+      }
+    }
+    store1<T>(out + e, v);
+  }
+}
+
+extern "C" int vinet_pack_weights_multi(const int64_t* table, int32_t njobs, int64_t total, int32_t dtype, void* stream) {
+  VN_CHECK_ARG(table && njobs > 0 && total > 0, "pack_weights_multi: bad arguments");
+  int grid = ew_grid(total); if (grid > 16384) grid = 16384;
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL(pack_weights_multi_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                          (const long*)table, njobs, (long)total);)
+  return vn_launch_status("pack_weights_multi");
+}
+
+__global__ void unpack_wgrad_kernel(float* __restrict__ dw, int N, int Cin, int ntaps, int stem, int Kp,
+                                    int flags, float* __restrict__ grad) {
+  const int accumulate = flags & 1, clear = flags & 2;
+  const long total = (long)N * Cin * ntaps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % ntaps);
+    const int c = (int)((i / ntaps) % Cin);
+    const int n = (int)(i / ((long)ntaps * Cin));
+    long src;
+    if (stem) { const int kh = t / 7, kw = t % 7; src = ((long)kh * N + n) * 32 + kw * 4 + c; }
+    else src = ((long)t * N + n) * Kp + c;
+    const float v = dw[src];
+    grad[i] = accumulate ? grad[i] + v : v;
+    if (clear) dw[src] = 0.f;      // every packed element is read by exactly one thread: hand the buffer back zeroed
+  }
+  if (clear) {
+    // columns no torch element maps to (channel padding; split-K atomics may have touched them)
+    const int nsl = stem ? 7 : ntaps, kp = stem ? 32 : Kp;
+    const long ptotal = (long)nsl * N * kp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ptotal; i += (long)gridDim.x * blockDim.x) {
+      const int col = (int)(i % kp);
+      const bool valid = stem ? (col < 28 && (col & 3) < Cin) : (col < Cin);
+      if (!valid) dw[i] = 0.f;
+    }
+  }
+}
+
+extern "C" int vinet_unpack_wgrad(float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem,
+                                  int32_t flags, float* grad, void* stream) {
+  VN_CHECK_ARG(dw && grad && N > 0 && Cin > 0 && ntaps > 0, "unpack_wgrad: bad arguments");
+  const int Kp = stem ? 32 : (Cin + 31) / 32 * 32;
+  const long total = (long)N * Cin * ntaps;
+  int grid = ew_grid(total); if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dw, N, Cin, ntaps, stem, Kp,
+                     flags, grad);
+  return vn_launch_status("unpack_wgrad");
+}
+
+// ============================================================================
+// NCDHW <-> channels-last
+// ============================================================================
+template <typename T>
+__global__ void import_ncdhw_kernel(const float* __restrict__ src, long sb, long sc, long st, long sh, long sw, int C,
+                                    TView dst, long nvox) {
+  const long vox = (long)blockIdx.x * blockDim.x + threadIdx.x;   // voxels fastest: coalesced planar reads
+  if (vox >= nvox) return;
+  const int q = blockIdx.y;
+  int b, t, h, w;
+  decode_vox(dst, vox, b, t, h, w);
+  const float* s = src + b * sb + t * st + h * sh + w * sw;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const int c = q * 4 + e; v[e] = c < C ? s[c * sc] : 0.f; }
+  stq<T>((T*)dst.p + vox_off(dst, b, t, h, w) + q * 4, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+extern "C" int vinet_import_ncdhw(const float* src, int64_t sb, int64_t sc, int64_t st, int64_t sh, int64_t sw,
+                                  int32_t C, const VinetTensor* dst, int32_t dst_dtype, void* stream) {
+  VN_CHECK_ARG(src && dst && quad_ok(*dst, esize(dst_dtype)) && C > 0 && C <= dst->C, "import_ncdhw: bad arguments");
+  const long nvox = view_voxels(*dst);
+  DISPATCH_T(dst_dtype, T, hipLaunchKernelGGL(import_ncdhw_kernel<T>, dim3(ew_grid(nvox), dst->C / 4), dim3(256), 0,
+                                              (hipStream_t)stream, src, sb, sc, st, sh, sw, C, make_view(*dst), nvox);)
+  return vn_launch_status("import_ncdhw");
+}
+
+// import into a zero-padded buffer: dst voxel (h, w) <- src(h - pad_top, w - pad_left), zero outside
+template <typename T>
+__global__ void import_pad_kernel(const float* __restrict__ src, long sb, long sc, long st, long sh, long sw, int C,
+                                  int Hs, int Ws, int pad_top, int pad_left, TView dst, long nvox) {
+  const long vox = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vox >= nvox) return;
+  const int q = blockIdx.y;
+  int b, t, h, w;
+  decode_vox(dst, vox, b, t, h, w);
+  const int hs = h - pad_top, ws = w - pad_left;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((unsigned)hs < (unsigned)Hs && (unsigned)ws < (unsigned)Ws) {
+    const float* s = src + b * sb + t * st + hs * sh + ws * sw;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int c = q * 4 + e; if (c < C) v[e] = s[c * sc]; }
+  }
+  stq<T>((T*)dst.p + vox_off(dst, b, t, h, w) + q * 4, make_float4(v[0], v[1], v[2], v[3]));
+}
+
+extern "C" int vinet_import_ncdhw_pad(const float* src, int64_t sb, int64_t sc, int64_t st, int64_t sh, int64_t sw,
+                                      int32_t C, int32_t Hs, int32_t Ws, int32_t pad_top, int32_t pad_left,
+                                      const VinetTensor* dst, int32_t dst_dtype, void* stream) {
+  VN_CHECK_ARG(src && dst && quad_ok(*dst, esize(dst_dtype)) && C > 0 && C <= dst->C && Hs > 0 && Ws > 0 &&
+                   pad_top >= 0 && pad_left >= 0 && pad_top + Hs <= dst->H && pad_left + Ws <= dst->W,
+               "import_ncdhw_pad: bad arguments");
+  const long nvox = view_voxels(*dst);
+  DISPATCH_T(dst_dtype, T, hipLaunchKernelGGL(import_pad_kernel<T>, dim3(ew_grid(nvox), dst->C / 4), dim3(256), 0,
+                                              (hipStream_t)stream, src, sb, sc, st, sh, sw, C, Hs, Ws, pad_top, pad_left,
+                                              make_view(*dst), nvox);)
+  return vn_launch_status("import_ncdhw_pad");
+}
+
+template <typename T>
+__global__ void export_ncdhw_kernel(TView src, Affine pre, float* __restrict__ dst, long sb, long sc, long st, long sh,
+                                    long sw, int accumulate, long nvox) {
+  const long vox = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vox >= nvox) return;
+  const int q = blockIdx.y;
+  int b, t, h, w;
+  decode_vox(src, vox, b, t, h, w);
+  float4 v = ldq<T>((const T*)src.p + vox_off(src, b, t, h, w) + q * 4);
+  v = affine4(v, pre, q * 4);
+  float* d = dst + b * sb + t * st + h * sh + w * sw + (long)(q * 4) * sc;
+  const float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e * sc] = accumulate ? d[e * sc] + o[e] : o[e];
+}
+
+extern "C" int vinet_export_ncdhw(const VinetTensor* src, int32_t src_dtype, VinetAffine pre, float* dst, int64_t sb,
+                                  int64_t sc, int64_t st, int64_t sh, int64_t sw, int32_t accumulate, void* stream) {
+  VN_CHECK_ARG(src && dst && quad_ok(*src, esize(src_dtype)), "export_ncdhw: bad arguments");
+  const long nvox = view_voxels(*src);
+  DISPATCH_T(src_dtype, T, hipLaunchKernelGGL(export_ncdhw_kernel<T>, dim3(ew_grid(nvox), src->C / 4), dim3(256), 0,
+                                              (hipStream_t)stream, make_view(*src), make_affine(pre), dst, sb, sc, st,
+                                              sh, sw, accumulate, nvox);)
+  return vn_launch_status("export_ncdhw");
+}
+
+template <typename TI, typename TO>
+__global__ void copy_affine_kernel(TView src, Affine pre, TView dst, int accumulate, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t vox_u = fdiv((uint32_t)i, src.dQ);
+  const int q = (int)((uint32_t)i - vox_u * (uint32_t)(src.C / 4));
+  const long vox = (long)vox_u;
+  float4 v = ldq<TI>((const TI*)src.p + vox_lin(src, vox) + q * 4);
+  v = affine4(v, pre, q * 4);
+  TO* d = (TO*)dst.p + vox_lin(dst, vox) + q * 4;
+  if (accumulate) { const float4 o = ldq<TO>(d); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+  stq<TO>(d, v);
+}
+
+// 8-channel form (structure of bn_bwd_apply8_kernel): a lane keeps the scale / shift of its 8 channels in registers
+// and streams voxels, 16-byte loads and stores, 4 voxels in flight -- the quad kernel above pays a voxel decode and
+// two coefficient loads per 8 bytes.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void copy_affine8_kernel(TView src, Affine pre, TView dst, int accumulate, long nvox, long vb) {
+  const int G = src.C / 8;
+  const int Gb = G < 256 ? G : 256;
+  const int R = 256 / Gb;
+  const int r = threadIdx.x / Gb;
+  const int g0 = threadIdx.x % Gb;
+  if (r >= R) return;
+  const long v0 = (long)blockIdx.x * vb;
+  long v1 = v0 + vb; if (v1 > nvox) v1 = nvox;
+  for (int g = g0; g < G; g += Gb) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = pre.scale ? pre.scale[g * 8 + e] : 1.f; sh[e] = pre.scale ? pre.shift[g * 8 + e] : 0.f; }
+    constexpr int U = 4;
+    for (long vq = v0 + r; vq < v1; vq += (long)R * U) {
+      float xv[U][8], ov[U][8];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long v = vq + (long)u * R;
+        ok[u] = v < v1;
+        if (ok[u]) {
+          ld8<TI>((const TI*)src.p + vox_lin(src, v) + g * 8, xv[u]);
+          if (accumulate) ld8<TO>((const TO*)dst.p + vox_lin(dst, v) + g * 8, ov[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = pre.scale ? fmaf(xv[u][e], sc[e], sh[e]) : xv[u][e];
+          if (pre.relu) t = fmaxf(t, 0.f);
+          o[e] = accumulate ? t + ov[u][e] : t;
+        }
+        st8<TO>((TO*)dst.p + vox_lin(dst, vq + (long)u * R) + g * 8, o);
+      }
+    }
+  }
+}
+
+extern "C" int vinet_copy_affine(const VinetTensor* src, int32_t src_dtype, VinetAffine pre, const VinetTensor* dst,
+                                 int32_t dst_dtype, int32_t accumulate, void* stream) {
+  VN_CHECK_ARG(src && dst && quad_ok(*src, esize(src_dtype)) && quad_ok(*dst, esize(dst_dtype)) && same_dims(*src, *dst),
+               "copy_affine: bad views");
+  const long total = view_voxels(*src) * (src->C / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const TView sv = make_view(*src), dv = make_view(*dst);
+  const Affine a = make_affine(pre);
+  if (src_dtype == VINET_BF16 && dst_dtype == VINET_BF16 && oct_ok(*src) && oct_ok(*dst) && view_voxels(*src) >= 65536) {
+    const long nvox = view_voxels(*src);
+    const int G = src->C / 8, R = 256 / (G < 256 ? G : 256);
+    long vb = R * 16;
+    while ((nvox + vb - 1) / vb > 16384) vb *= 2;
+    hipLaunchKernelGGL((copy_affine8_kernel<bf16_t, bf16_t>), dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, s, sv, a, dv, accumulate, nvox, vb);
+    return vn_launch_status("copy_affine8");
+  }
+  const dim3 g(ew_grid(total)), blk(256);
+  if (src_dtype == VINET_F32 && dst_dtype == VINET_F32) hipLaunchKernelGGL((copy_affine_kernel<float, float>), g, blk, 0, s, sv, a, dv, accumulate, total);
+  else if (src_dtype == VINET_F32) hipLaunchKernelGGL((copy_affine_kernel<float, bf16_t>), g, blk, 0, s, sv, a, dv, accumulate, total);
+  else if (dst_dtype == VINET_F32) hipLaunchKernelGGL((copy_affine_kernel<bf16_t, float>), g, blk, 0, s, sv, a, dv, accumulate, total);
+  else hipLaunchKernelGGL((copy_affine_kernel<bf16_t, bf16_t>), g, blk, 0, s, sv, a, dv, accumulate, total);
+  return vn_launch_status("copy_affine");
+}
+
+
+// ---- "skinny" weight gradient: a pointwise conv with at most 8 output channels (ViNet's 32 -> 1 head, model.py:279: the
+// channel-padded dy has 8 columns, 7 of them exactly zero) over tens of millions of voxels is a per-channel reduction, not a
+// GEMM: dw[n][c] = sum_v dy[v][n] * x[v][c].  The 64 x 64 MFMA tile spent 0.9 ms (0.8 TF/s) on it; here a lane owns 8 input
+// channels of a strided share of the voxels with an 8 x 8 block of fp32 accumulators, lanes of equal channel group meet by
+// wave shuffles, waves in LDS, and a workgroup adds its 8 x Cin block to dw with one atomic per element.
+__global__ __launch_bounds__(256) void wgrad_skinny_kernel(TView x, TView dy, long nvox, int Kp, float* __restrict__ dw) {
+  __shared__ float red[4][8][64];                  // [wave][group][n * 8 + e]
+  const int G = x.C >> 3;                          // 1, 2, 4 or 8 groups of 8 input channels
+  const int tid = threadIdx.x, g = tid % G, r = tid / G, R = 256 / G;
+  float acc[8][8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[n][e] = 0.f;
+  for (long v = (long)blockIdx.x * R + r; v < nvox; v += (long)gridDim.x * R) {
+    float xv[8], gv[8];
+    ld8<bf16_t>((const bf16_t*)x.p + vox_lin(x, v) + g * 8, xv);
+    ld8<bf16_t>((const bf16_t*)dy.p + vox_lin(dy, v), gv);
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[n][e] = fmaf(gv[n], xv[e], acc[n][e]);
+  }
+  // lanes g, g + G, g + 2G, ... of a wave hold the same channel group
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = acc[n][e];
+      for (int o = 32; o >= G; o >>= 1) a += __shfl_xor(a, o);
+      acc[n][e] = a;
+    }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < G) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][lane][n * 8 + e] = acc[n][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < G * 64; i += 256) {
+    const int gg = i >> 6, ne = i & 63, n = ne >> 3, e = ne & 7;
+    const float a = red[0][gg][ne] + red[1][gg][ne] + red[2][gg][ne] + red[3][gg][ne];
+    atomicAdd(dw + (long)n * Kp + gg * 8 + e, a);
+  }
+}
+
+int g_vinet_opt_wgrad_skinny = 1;   // 0 = off, 2 = every eligible shape (tests)
+
+bool vinet_wgrad_use_skinny(const VinetWgradDesc* d) {
+  if (!g_vinet_opt_wgrad_skinny || d->dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC || d->ntaps != 1 || d->pre.scale || d->pre.relu ||
+      d->bnb_z)
+    return false;
+  const int Cin = d->x.C;
+  const bool shape = d->dy.C == 8 && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) && d->Kp >= Cin && d->sT == 1 && d->sH == 1 && d->sW == 1 &&
+                     d->x.T == d->dy.T && d->x.H == d->dy.H && d->x.W == d->dy.W && oct_ok(d->x) && oct_ok(d->dy);
+  if (!shape) return false;
+  return g_vinet_opt_wgrad_skinny >= 2 || (long)d->dy.B * d->dy.T * d->dy.H * d->dy.W >= (1L << 20);
+}
+
+int vinet_launch_wgrad_skinny(const VinetWgradDesc* d, hipStream_t s) {
+  // taps: a pointwise conv has one tap, (0, 0, 0, slice 0) -- nothing to read from the device-side table
+  const long nvox = view_voxels(d->dy);
+  const int R = 256 / (d->x.C / 8);
+  long blocks = (nvox + R - 1) / R;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(wgrad_skinny_kernel, dim3((unsigned)blocks), dim3(256), 0, s, make_view(d->x), make_view(d->dy), nvox, d->Kp, d->dw);
+  return vn_launch_status("wgrad_skinny");
+}
+
+// ---- 1-D unfold (im2col along T) of a single-channel signal: SoundNet's first conv (model.py:751: Conv2d(1, 16, (64, 1),
+// stride 2, padding 32)) has one input channel and 64 taps -- as a (k,1,1) conv its K axis would be 64 taps x 32 padded
+// channels with one real column in 32.  Unfolded, y[b, m, c] = x[b, s*m - p + c, channel 0] (zero outside), it is a pointwise
+// conv with 64 input channels: 0.58 GB written once per step instead of a 32x padded K loop in forward and weight gradient.
+template <typename T>
+__global__ __launch_bounds__(256) void unfold1d_kernel(TView x, TView y, int stride, int pad, long total8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total8) return;
+  const int G = y.C >> 3;
+  const long row = i / G;                          // b * To + m
+  const int g = (int)(i - row * G);
+  const long b = row / y.T;
+  const int m = (int)(row - b * y.T);
+  const T* src = (const T*)x.p + b * x.sB;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const long pos = (long)m * stride - pad + g * 8 + e;
+    v[e] = (pos >= 0 && pos < x.T) ? load1<T>(src + pos * x.ld) : 0.f;
+  }
+  st8<T>((T*)y.p + b * y.sB + (long)m * y.ld + g * 8, v);
+}
+
+extern "C" int vinet_unfold1d(const VinetTensor* x, const VinetTensor* y, int32_t dtype, int32_t stride, int32_t pad, void* stream) {
+  VN_CHECK_ARG(x && y && (dtype == VINET_F32 || dtype == VINET_BF16) && x->ptr && y->ptr && x->B == y->B && x->H == 1 && x->W == 1 &&
+                   y->H == 1 && y->W == 1 && x->C >= 1 && y->C % 8 == 0 && y->ld % 8 == 0 && y->sB % 8 == 0 &&
+                   ((uintptr_t)y->ptr % 16) == 0 && stride >= 1 && pad >= 0 && y->T == (x->T + 2 * pad - y->C) / stride + 1,
+               "unfold1d: bad views");
+  const long total8 = (long)y->B * y->T * (y->C / 8);
+  DISPATCH_T(dtype, T, hipLaunchKernelGGL(unfold1d_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, make_view(*x),
+                                          make_view(*y), stride, pad, total8);)
+  return vn_launch_status("unfold1d");
+}
+
+__global__ void fill_f32_kernel(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+extern "C" int vinet_fill_f32(float* p, int64_t n, float value, void* stream) {
+  VN_CHECK_ARG(p && n >= 0, "fill_f32: bad arguments");
+  if (n == 0) return 0;
+  int grid = ew_grid(n); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, (long)n, value);
+  return vn_launch_status("fill_f32");
+}

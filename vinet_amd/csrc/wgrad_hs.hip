@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_hs_kernel(const WgradHsArgs
     const int r = l_row + 32 * j;
     l_off[j] = r * 128 + ((l_chunk ^ whs_swz(r)) * 16);
   }
-  // fused BN backward: dz = A*(g*mask) + Bc*z + D with the gate from A*z + sh (elementwise.hip::bn_bwd_apply8_kernel);
+  // fused BN backward: dz = A*(g*mask) + Bc*z + D with the gate from A*z + sh (bn.hip::bn_bwd_apply8_kernel);
   // a thread always handles the same 8 channels
   float cA[8], cB[8], cD[8], cS[8];
   if constexpr (BNB) {
