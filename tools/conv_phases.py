@@ -16,7 +16,11 @@ lib = bind(os.path.join(ROOT, "vinet_amd", "libvinet_hip_timing.so"))
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream().cuda_stream
 print("%-26s %8s %9s %9s %9s %7s   (cycles per workgroup, mean; s_memtime ticks = 100 MHz? see ratio)" % ("site", "blocks", "prologue", "kloop", "epilogue", "chunks"))
+ONLY = os.environ.get("AB_ONLY", "")
 for (name, B, T, H, W, Cin, N, k, s, p) in SITES:
+    if ONLY and ONLY not in name:
+        continue
+    B = int(os.environ.get("AB_BATCH", B))
     oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
     x = torch.randn(B * T * H * W * Cin, device=dev).bfloat16()
     y = torch.empty(B * oT * oH * oW * N, device=dev, dtype=torch.bfloat16)

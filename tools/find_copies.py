@@ -46,6 +46,20 @@ for ev in prof.events():
         cnt[(n, tuple(st[:3]))] += 1
 for (n, st), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:40]:
     print(c, n, " <- ".join(st))
+rt = collections.Counter(); rtt = collections.Counter()
+for ev in prof.events():
+    if ev.name.startswith("hip"):
+        rt[ev.name] += 1; rtt[ev.name] += ev.cpu_time_total
+print("---- runtime API (count, total us)")
+for n, c in rt.most_common(12):
+    print(c, int(rtt[n]), n)
+import time
+for _ in range(2):
+    step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3):
+    step()
+torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) / 3 * 1e3)
 print("---- device-side")
 for n, c in kc.most_common(12):
     print(c, n)
