@@ -183,7 +183,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if parallel.distributed():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -239,7 +239,7 @@ def main():
     t1 = time.perf_counter()
     engine.set_profiler(None)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if parallel.distributed():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)
     if graphed:   # roofline of the dominant kernel from the eager profile call
@@ -364,10 +364,26 @@ def main():
                                      "headline's, which is eager; local_batch_eager: one Python-issued launch per kernel")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result_line = json.dumps(out)
+    else:
+        result_line = None
+    # The JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio when its first communicator
+    # comes up, and a piped C stream is only flushed at exit -- after Python's own buffer, i.e. behind the result.  Every
+    # rank pushes what its C side has buffered out BEFORE the last barrier; rank 0 prints after it.
+    def flush_c_stdio():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+    sys.stdout.flush()
+    flush_c_stdio()
+    if parallel.distributed():
         dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

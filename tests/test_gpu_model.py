@@ -490,7 +490,7 @@ def test_custom_ops_on_device():
     MC.close(xp.grad.permute(0, 4, 1, 2, 3), xq.grad, 1e-5, "pool + upsample op gradient")
 
 
-def _two_rank_worker(rank, world, port, out, backend):
+def _two_rank_worker(rank, world, port, out, backend, force=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -500,6 +500,7 @@ def _two_rank_worker(rank, world, port, out, backend):
     from vinet_amd import model as VM
     from vinet_amd import optim as VO
     from vinet_amd import parallel
+    parallel.FORCE_COLLECTIVES = bool(force)
     L.load()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -539,6 +540,37 @@ def _two_rank_worker(rank, world, port, out, backend):
     torch.save(res, os.path.join(out, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_single_rank_rccl_runs_every_collective_of_the_n_gpu_path(tmp_path):
+    """RCCL itself (backend "nccl"), which refuses two ranks on one device: a ONE-rank process group with
+    parallel.FORCE_COLLECTIVES, so the flat all-reduce, the bucketed all-reduces issued from the tape on the communication
+    stream (event-joined with the main and the weight-gradient streams) and the final waits all go through the RCCL library on
+    the GPU.  A one-rank SUM is the identity: both orders must give the same gradients and parameters; then the bench
+    command line runs the same way (barrier, MAX all-reduce of the elapsed time, bucketed step)."""
+    import socket
+    import subprocess
+    import sys
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(1, port, str(tmp_path), "nccl", True), nprocs=1, join=True)
+    r = torch.load(str(tmp_path / "rank0.pt"))
+    assert "error" not in r, r
+    dg = float((r["bucketed_g"] - r["flat_g"]).abs().max() / (r["flat_g"].abs().max() + 1e-30))
+    dp = float((r["bucketed_p"] - r["flat_p"]).abs().max() / (r["flat_p"].abs().max() + 1e-30))
+    assert dg < 1e-6 and dp < 1e-5, (dg, dp)       # (two runs: the weight-gradient atomics order their fp32 sums differently)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VINET_FORCE_COLLECTIVES="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port + 1 if port < 65000 else port - 1), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--no-sweep", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    _note("single_rank_rccl", dict(bucketed_vs_flat_grad=dg, bucketed_vs_flat_param=dp, bench_clips_per_s=line["value"]))
 
 
 def test_two_ranks_on_one_gpu_bucketed_allreduce(tmp_path):

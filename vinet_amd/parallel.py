@@ -28,6 +28,16 @@ import torch
 import torch.distributed as dist
 
 
+# Functional testing on ONE GPU: treat a single-rank process group as distributed, so that every collective of the N > 1 path
+# (flat broadcast, bucketed all-reduce on the communication stream with its event joins, scalar means) really goes through
+# RCCL.  RCCL refuses two ranks on one device, so this is the only way to execute it without a multi-GPU node.
+FORCE_COLLECTIVES = os.environ.get("VINET_FORCE_COLLECTIVES", "0") == "1"
+
+
+def distributed():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def init_from_env(backend=None):
     """torchrun / torch.distributed.run environment -> (rank, world, local_rank, device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -38,7 +48,7 @@ def init_from_env(backend=None):
     device = torch.device("cuda:%d" % (local % torch.cuda.device_count())) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or os.environ.get("VINET_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
@@ -56,7 +66,7 @@ def shard_batch(global_batch, rank, world):
 
 def broadcast_parameters(optimizer, src=0):
     """make every replica start from rank `src`'s weights (one flat broadcast)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if distributed():
         dist.broadcast(optimizer.flat_p, src=src)
         from . import engine
         engine.bump_weights_epoch()
@@ -64,7 +74,7 @@ def broadcast_parameters(optimizer, src=0):
 
 def allreduce_gradients(optimizer, async_op=False):
     """SUM all-reduce of the flat gradient buffer; the mean is applied inside Adam."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not distributed():
         optimizer.grad_scale = 1.0
         return None
     optimizer.grad_scale = 1.0 / dist.get_world_size()
@@ -72,7 +82,7 @@ def allreduce_gradients(optimizer, async_op=False):
 
 
 def allreduce_scalar_mean(t):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if distributed():
         t = t.detach().clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t /= dist.get_world_size()
@@ -91,7 +101,7 @@ def trainable_parameters(model):
 
 def broadcast_buffers(model, src=0):
     """every replica adopts rank `src`'s buffers (BatchNorm running statistics: 85.5 KB for ViNet-32)"""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if distributed():
         for b in model.buffers():
             dist.broadcast(b, src=src)
 
@@ -139,7 +149,7 @@ class GradientBuckets:
         self.buckets.append((lo, hi, len(members)))
 
     def active(self):
-        return dist.is_initialized() and dist.get_world_size() > 1
+        return distributed()
 
     def begin_step(self):
         from . import engine
