@@ -41,10 +41,25 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("batch %d: host %.2f ms/step issue time, %.2f ms/step wall" % (B, (t1 - t0) * 100, (t2 - t0) * 100))
 pr = cProfile.Profile()
+pr2 = cProfile.Profile()            # the tape's backward runs in autograd's worker thread: its own profile
+orig = E._TapeFn.backward
+
+
+def traced(ctxa, *g):
+    pr2.enable()
+    try:
+        return orig(ctxa, *g)
+    finally:
+        pr2.disable()
+
+
+E._TapeFn.backward = staticmethod(traced)
 pr.enable()
 for _ in range(5):
     step()
 pr.disable()
 torch.cuda.synchronize()
-st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+print("==== forward / main thread")
+pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+print("==== backward (tape) thread")
+pstats.Stats(pr2).sort_stats("tottime").print_stats(24)
