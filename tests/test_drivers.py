@@ -249,3 +249,63 @@ def test_hollywood_ucf_dataset_against_the_reference_selection(tmp_path, monkeyp
                         assert tuple(gd.shape[-2:]) == (224, 384)
     finally:
         L._install_test_double(None)
+
+
+def test_frame_ring_windows_are_views_of_the_newest_frames():
+    """FrameRing: any run of consecutive frames among the newest `capacity` is one contiguous slice of the doubled buffer;
+    windows() returns overlapping zero-copy views"""
+    import random
+    from vinet_amd.generate_result import FrameRing
+    fr = torch.randn(41, 3, 4, 5)
+    for R in (7, 12):
+        ring, pos, T = FrameRing(R, fr.shape[1:], "cpu"), 0, 4
+        random.seed(R)
+        while pos < fr.shape[0]:
+            k = min(random.randint(1, R), fr.shape[0] - pos)
+            ring.push(fr[pos:pos + k])
+            pos += k
+            for first in range(max(0, pos - R), pos - T + 1):
+                n = min(R - T + 1, pos - first - T + 1)
+                w = ring.windows(first, n, T)
+                assert w.data_ptr() >= ring.buf.data_ptr() and w.untyped_storage().data_ptr() == ring.buf.untyped_storage().data_ptr()
+                assert torch.equal(w, torch.stack([fr[first + i:first + i + T] for i in range(n)]))
+
+
+def test_streaming_harness_equals_the_resident_one():
+    """predict_stream (frames arrive in chunks, clips are views into a ring of the newest frames) produces exactly the maps of
+    predict_video (whole video resident, one gather per call) -- and thereby the reference's schedule (the trace golden above):
+    every output frame once, early frames from the time-reversed window"""
+    from tests.abi_emulator import AbiEmulator
+    from vinet_amd import _lib as L
+    from vinet_amd import engine as E
+    from vinet_amd import generate_result as GR
+    from vinet_amd import model as VM
+    from vinet_amd import synth
+    L._install_test_double(AbiEmulator())
+    try:
+        E.set_default_dtype("fp32")
+        m = VM.VideoSaliencyModel(num_clips=8).eval()
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), 3))
+        N, T = 19, 8
+        frames = synth.clip(1, N, 64, 96, 5)[0]                      # [N,3,64,96]
+        want = GR.predict_video(m, frames, T, batch=1)
+        for batch, chunk in ((1, 1), (3, 5), (2, 32)):
+            got = torch.full_like(want, float("nan"))
+            seen = []
+            for outs, maps in GR.predict_stream(m, (frames[c:c + chunk] for c in range(0, N, chunk)), T, batch=batch):
+                for i, mp in zip(outs, maps):
+                    got[i] = mp
+                    seen.append(i)
+            assert sorted(seen) == list(range(N)), (batch, chunk, seen)
+            # one clip per call: bit for bit; several per call: the CPU model's convolutions round differently per batch size
+            assert torch.equal(got, want) if batch == 1 else float((got - want).abs().max()) < 5e-6, (batch, chunk, float((got - want).abs().max()))
+        pp = GR.predict_video(m, frames, T, batch=2, out_size=(45, 80))
+        got = torch.zeros_like(pp)
+        for outs, maps in GR.predict_stream(m, (frames[c:c + 4] for c in range(0, N, 4)), T, batch=2, out_size=(45, 80)):
+            for i, mp in zip(outs, maps):
+                got[i] = mp
+        d = (got.int() - pp.int()).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3          # (uint8 maps: a float ulp can move a byte)
+    finally:
+        L._install_test_double(None)
+        E.set_default_dtype("bf16")

@@ -7,7 +7,9 @@
 starts at them (torch.flip on dim 2).  `predict_video(model, frames)` runs that
 schedule on a [N,3,H,W] tensor of preprocessed frames that stays resident on the
 device (each call gathers its T frames from it: the reference's `snippet` list,
-without re-uploading T-1 of them) and returns [N,H,W] maps -- or, with
+without re-uploading T-1 of them); `predict_stream` runs the same schedule over frames that arrive in chunks, out of a
+ring of the newest frames (`FrameRing`: clips are zero-copy views, device memory independent of the video's length) --
+the directory harness `validate()` uses it.  Both return [N,H,W] maps -- or, with
 `out_size=(H_img, W_img)`, the uint8 maps `process()` writes (generate_result.py:95-104:
 cv2.resize -> 11x11 Gaussian blur -> min-max normalise -> uint8), produced on
 device by vinet_amd.utils.postprocess.  `process()` keeps the reference's name and
@@ -77,6 +79,75 @@ def predict_video(model, frames, T, batch=1, out_size=None, graph=False):
     return maps
 
 
+class FrameRing:
+    """The newest `capacity` preprocessed frames of a video on the device (the sliding window re-uses T-1 of its
+    T frames between calls).  Every frame is stored TWICE, `capacity` slots apart, so any run of up to `capacity`
+    consecutive frames is one contiguous slice of the buffer: a clip -- and a batch of consecutive, overlapping clips
+    (`windows`) -- is a zero-copy strided view that the model's NCDHW import kernel reads in place."""
+
+    def __init__(self, capacity, frame_shape, device, dtype=torch.float32):
+        self.R = int(capacity)
+        self.buf = torch.empty((2 * self.R,) + tuple(frame_shape), dtype=dtype, device=device)
+        self.count = 0                                     # frames pushed so far; the newest is frame count - 1
+
+    def push(self, frames):
+        """frames [k,3,H,W] (k <= capacity), in temporal order"""
+        k = frames.shape[0]
+        assert 0 < k <= self.R
+        slots = (torch.arange(self.count, self.count + k, device=self.buf.device) % self.R)
+        self.buf.index_copy_(0, slots, frames.to(self.buf.dtype))
+        self.buf.index_copy_(0, slots + self.R, frames.to(self.buf.dtype))
+        self.count += k
+
+    def windows(self, first, n, T):
+        """[n,T,3,H,W] view: window i holds frames first + i .. first + i + T - 1 (they overlap: no bytes are copied)"""
+        last = first + n + T - 2
+        assert n >= 1 and last < self.count and first >= self.count - self.R and n + T - 1 <= self.R, "frames no longer (or not yet) in the ring"
+        run = self.buf[first % self.R: first % self.R + n + T - 1]
+        st = run.stride()
+        return run.as_strided((n, T) + tuple(run.shape[1:]), (st[0], st[0]) + tuple(st[1:]))
+
+
+@torch.no_grad()
+def predict_stream(model, chunks, T, batch=1, out_size=None, graph=False):
+    """The schedule of `sliding_window_schedule` over frames that ARRIVE in chunks (an iterable of [k,3,H,W] tensors on the
+    model's device): a FrameRing holds the newest T + k + batch frames, each arriving frame j >= T-1 completes the window
+    [j-T+1 .. j] -- output j, and for j < 2T-2 also output j-T+1 from the same window time-reversed (generate_result.py:60-66)
+    -- and clips are views into the ring.  Yields (output frame indices, maps [len,H,W] or post-processed uint8 maps) per
+    model call; device memory does not grow with the length of the video."""
+    model.eval()
+    step = _Pipeline(model, out_size)
+    ring, graphed, nxt = None, None, T - 1                 # nxt: next window end (= normal output) to run
+
+    def run(clips, outs):
+        nonlocal graphed
+        if graph and clips.shape[0] == batch:
+            if graphed is None:
+                key = ("stream", batch, None if out_size is None else tuple(out_size), T) + tuple(clips.shape[2:])
+                cache = model.__dict__.setdefault("_harness_graphs", {})
+                graphed = cache.get(key)
+                if graphed is None:
+                    from .graph import GraphedInference
+                    graphed = cache[key] = GraphedInference(step, clips.contiguous())
+            return outs, graphed(clips)
+        return outs, step(clips)
+
+    for chunk in chunks:
+        k = chunk.shape[0]
+        if ring is None:
+            ring = FrameRing(T + max(k, 1) + batch, chunk.shape[1:], chunk.device)
+        assert k <= ring.R - T + 1, "a later chunk must not be larger than the first one (+ batch)"
+        ring.push(chunk)
+        while nxt < ring.count:
+            n = min(batch, ring.count - nxt)
+            w = ring.windows(nxt - T + 1, n, T)                               # [n,T,3,H,W]
+            yield run(w.permute(0, 2, 1, 3, 4), list(range(nxt, nxt + n)))
+            nf = max(0, min(nxt + n, 2 * T - 2) - nxt)                         # windows whose reversed clip predicts an early frame
+            if nf:
+                yield run(w[:nf].flip(1).permute(0, 2, 1, 3, 4), list(range(nxt - T + 1, nxt - T + 1 + nf)))
+            nxt += n
+
+
 @torch.no_grad()
 def process(model, clip, path_inpdata, dname, frame_no, args, img_size):
     """generate_result.py:95-104: one model call, cv2.resize to the image's size (img_size = PIL (width, height)),
@@ -126,18 +197,33 @@ def validate(args, model=None, device=None):
         if len(list_frames) < 2 * T - 1:
             print(' more frames are needed')
             continue
-        imgs = [Image.open(os.path.join(img_dir, f)).convert('RGB') for f in list_frames]
-        sizes = set(im.size for im in imgs)
-        assert len(sizes) == 1, "frames of one video must share a size (%s: %s)" % (dname, sorted(sizes))
-        w, h = imgs[0].size
-        u8 = torch.from_numpy(np.stack([np.asarray(im) for im in imgs])).to(dev)           # [N,h,w,3] bytes: the only upload
-        frames = preprocess.frames_to_tensor(u8)                                          # [N,3,224,384]
-        maps = predict_video(model, frames, T, getattr(args, "batch", 1), (h, w), bool(getattr(args, "graph", 0))).cpu().numpy()
-        for i, f in enumerate(list_frames):
-            fp = os.path.join(args.save_path, dname, f)
-            im = Image.fromarray(maps[i])
-            im.save(fp) if fp.split('.')[-1] == "png" else im.save(fp, quality=100)
-            n_saved += 1
+        w, h = Image.open(os.path.join(img_dir, list_frames[0])).size
+        chunk = int(getattr(args, "decode_chunk", 32))
+
+        def decoded():      # decode -> one upload of bytes per chunk -> resize + normalise on the device
+            for c0 in range(0, len(list_frames), chunk):
+                imgs = [Image.open(os.path.join(img_dir, f)).convert('RGB') for f in list_frames[c0:c0 + chunk]]
+                assert all(im.size == (w, h) for im in imgs), "frames of one video must share a size (%s)" % dname
+                yield preprocess.frames_to_tensor(torch.from_numpy(np.stack([np.asarray(im) for im in imgs])).to(dev))
+        pend_i, pend_m = [], []
+
+        def flush():        # one device -> host copy (and one synchronisation) per chunk of maps, not per model call
+            nonlocal n_saved
+            if not pend_i:
+                return
+            host = torch.cat(pend_m).cpu().numpy()
+            for i, m in zip(pend_i, host):
+                fp = os.path.join(args.save_path, dname, list_frames[i])
+                im = Image.fromarray(m)
+                im.save(fp) if fp.split('.')[-1] == "png" else im.save(fp, quality=100)
+                n_saved += 1
+            del pend_i[:], pend_m[:]
+        for outs, maps in predict_stream(model, decoded(), T, getattr(args, "batch", 1), (h, w), bool(getattr(args, "graph", 0))):
+            pend_i.extend(outs)
+            pend_m.append(maps.clone() if getattr(args, "graph", 0) else maps)      # (a replayed graph returns its static output buffer)
+            if len(pend_i) >= chunk:
+                flush()
+        flush()
     return n_saved
 
 
@@ -159,6 +245,8 @@ def build_parser():
     p.add_argument('--synthetic_frames', default=0, type=int, help="run the schedule on N synthetic 224x384 frames and report fps (no files)")
     p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
     p.add_argument('--batch', default=1, type=int)
+    p.add_argument('--stream', default=0, type=int, help="synthetic mode: 1 = the streaming schedule (predict_stream / FrameRing) that the directory harness uses")
+    p.add_argument('--decode_chunk', default=32, type=int, help="frames decoded, uploaded and pre-processed per step of the directory harness")
     p.add_argument('--graph', default=1, type=int, help="1 (default) = replay a captured hipGraph per model call (+ post-processing); 0 = eager launches")
     p.add_argument('--allow_synthetic_weights', default=0, type=int, help="1 = fall back to procedural weights when --file_weight is missing (implied by --synthetic_frames)")
     p.add_argument('--image_size', default="360x640", type=str, help="synthetic mode: HxW of the source images the maps are resized to; 0 = keep the raw maps")
@@ -192,12 +280,18 @@ def main(argv=None):
         return n
     frames = synth.clip(1, args.synthetic_frames, 224, 384, 0)[0].to(dev)
     out_size = None if args.image_size in ("0", "") else tuple(int(v) for v in args.image_size.split("x"))
-    predict_video(m, frames[:2 * args.clip_size - 1], args.clip_size, args.batch, out_size, bool(args.graph))
+    def run(fr):
+        if not args.stream:
+            out = predict_video(m, fr, args.clip_size, args.batch, out_size, bool(args.graph))
+            return out.cpu() if out_size is not None else out              # what the PNG encoder would be handed
+        got = [mp.clone() if args.graph else mp                              # frames arrive 32 at a time, clips are ring views
+               for _, mp in predict_stream(m, (fr[c:c + 32] for c in range(0, fr.shape[0], 32)), args.clip_size, args.batch, out_size, bool(args.graph))]
+        out = torch.cat(got)
+        return out.cpu() if out_size is not None else out
+    run(frames[:2 * args.clip_size - 1])
     torch.cuda.synchronize()
     t0 = time.time()
-    maps = predict_video(m, frames, args.clip_size, args.batch, out_size, bool(args.graph))
-    if out_size is not None:
-        maps = maps.cpu()                                    # what the PNG encoder would be handed
+    maps = run(frames)
     torch.cuda.synchronize()
     n_calls = len(sliding_window_schedule(args.synthetic_frames, args.clip_size))
     print("%d model calls for %d frames in %.3f s -> %.1f fps" % (n_calls, args.synthetic_frames, time.time() - t0, n_calls / (time.time() - t0)))
