@@ -41,9 +41,9 @@ class _Pipeline(torch.nn.Module):
         super().__init__()
         self.model, self.out_size = model, out_size
 
-    def forward(self, clips):
+    def forward(self, clips, *extra):
         from .utils import postprocess
-        y = self.model(clips)
+        y = self.model(clips, *extra)
         return y if self.out_size is None else postprocess(y, self.out_size)
 
 
@@ -109,28 +109,31 @@ class FrameRing:
 
 
 @torch.no_grad()
-def predict_stream(model, chunks, T, batch=1, out_size=None, graph=False):
+def predict_stream(model, chunks, T, batch=1, out_size=None, graph=False, extra=None):
     """The schedule of `sliding_window_schedule` over frames that ARRIVE in chunks (an iterable of [k,3,H,W] tensors on the
     model's device): a FrameRing holds the newest T + k + batch frames, each arriving frame j >= T-1 completes the window
     [j-T+1 .. j] -- output j, and for j < 2T-2 also output j-T+1 from the same window time-reversed (generate_result.py:60-66)
-    -- and clips are views into the ring.  Yields (output frame indices, maps [len,H,W] or post-processed uint8 maps) per
-    model call; device memory does not grow with the length of the video."""
+    -- and clips are views into the ring.  `extra(starts, flipped)` (optional) returns further model inputs for the clips
+    that start at frames `starts` (the audio excerpts of the audio-visual harness; `flipped`: the clips are time-reversed).
+    Yields (output frame indices, maps [len,H,W] or post-processed uint8 maps) per model call; device memory does not grow
+    with the length of the video."""
     model.eval()
     step = _Pipeline(model, out_size)
     ring, graphed, nxt = None, None, T - 1                 # nxt: next window end (= normal output) to run
 
-    def run(clips, outs):
+    def run(clips, outs, starts, flipped):
         nonlocal graphed
+        more = tuple(extra(starts, flipped)) if extra is not None else ()
         if graph and clips.shape[0] == batch:
             if graphed is None:
-                key = ("stream", batch, None if out_size is None else tuple(out_size), T) + tuple(clips.shape[2:])
+                key = ("stream", batch, None if out_size is None else tuple(out_size), T, len(more)) + tuple(clips.shape[2:])
                 cache = model.__dict__.setdefault("_harness_graphs", {})
                 graphed = cache.get(key)
                 if graphed is None:
                     from .graph import GraphedInference
-                    graphed = cache[key] = GraphedInference(step, clips.contiguous())
-            return outs, graphed(clips)
-        return outs, step(clips)
+                    graphed = cache[key] = GraphedInference(step, clips.contiguous(), *[t.contiguous() for t in more])
+            return outs, graphed(clips, *more)
+        return outs, step(clips, *more)
 
     for chunk in chunks:
         k = chunk.shape[0]
@@ -141,10 +144,11 @@ def predict_stream(model, chunks, T, batch=1, out_size=None, graph=False):
         while nxt < ring.count:
             n = min(batch, ring.count - nxt)
             w = ring.windows(nxt - T + 1, n, T)                               # [n,T,3,H,W]
-            yield run(w.permute(0, 2, 1, 3, 4), list(range(nxt, nxt + n)))
+            starts = list(range(nxt - T + 1, nxt - T + 1 + n))
+            yield run(w.permute(0, 2, 1, 3, 4), list(range(nxt, nxt + n)), starts, False)
             nf = max(0, min(nxt + n, 2 * T - 2) - nxt)                         # windows whose reversed clip predicts an early frame
             if nf:
-                yield run(w[:nf].flip(1).permute(0, 2, 1, 3, 4), list(range(nxt - T + 1, nxt - T + 1 + nf)))
+                yield run(w[:nf].flip(1).permute(0, 2, 1, 3, 4), starts[:nf], starts[:nf], True)
             nxt += n
 
 

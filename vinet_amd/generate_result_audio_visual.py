@@ -153,17 +153,36 @@ def validate(args, model=None, device=None):
         if len(list_frames) < 2 * T - 1:
             print(' more frames are needed')
             continue
-        imgs = [Image.open(os.path.join(img_dir, f)).convert('RGB') for f in list_frames]
-        assert len(set(im.size for im in imgs)) == 1, "frames of one video must share a size (%s)" % dname
-        w, h = imgs[0].size
-        frames = preprocess.frames_to_tensor(torch.from_numpy(np.stack([np.asarray(im) for im in imgs])).to(dev))
-        audio_fn = (lambda s: get_audio_feature(dname, audiodata, args, s)) if args.use_sound else None
-        maps = predict_video(model, frames, T, audio_fn, getattr(args, "batch", 1), (h, w)).cpu().numpy()
-        for i, f in enumerate(list_frames):
-            fp = join(args.save_path, dname, f)
-            im = Image.fromarray(maps[i])
-            im.save(fp) if fp.split('.')[-1] == "png" else im.save(fp, quality=100)
-            n_saved += 1
+        w, h = Image.open(os.path.join(img_dir, list_frames[0])).size
+        chunk = int(getattr(args, "decode_chunk", 32))
+
+        def decoded():      # the streaming schedule of generate_result.predict_stream: 32 frames decoded / uploaded / pre-processed at a time
+            for c0 in range(0, len(list_frames), chunk):
+                imgs = [Image.open(os.path.join(img_dir, f)).convert('RGB') for f in list_frames[c0:c0 + chunk]]
+                assert all(im.size == (w, h) for im in imgs), "frames of one video must share a size (%s)" % dname
+                yield preprocess.frames_to_tensor(torch.from_numpy(np.stack([np.asarray(im) for im in imgs])).to(dev))
+
+        def audio(starts, flipped):     # excerpt of the clip that starts at frame s; the time-flipped clip gets the flipped excerpt
+            a = torch.cat([get_audio_feature(dname, audiodata, args, s).to(dev) for s in starts], 0)
+            return (torch.flip(a, [2]) if flipped else a,)
+        pend_i, pend_m = [], []
+
+        def flush():
+            nonlocal n_saved
+            if pend_i:
+                host = torch.cat(pend_m).cpu().numpy()
+                for i, m in zip(pend_i, host):
+                    fp = join(args.save_path, dname, list_frames[i])
+                    im = Image.fromarray(m)
+                    im.save(fp) if fp.split('.')[-1] == "png" else im.save(fp, quality=100)
+                    n_saved += 1
+                del pend_i[:], pend_m[:]
+        for outs, maps in GR.predict_stream(model, decoded(), T, getattr(args, "batch", 1), (h, w), False, audio if args.use_sound else None):
+            pend_i.extend(outs)
+            pend_m.append(maps)
+            if len(pend_i) >= chunk:
+                flush()
+        flush()
     return n_saved
 
 
