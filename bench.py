@@ -33,9 +33,11 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
 TRAIN_WORK = {(32, 224, 384): (675.0, 3014.7), (64, 256, 448): (1800.0, 7994.0), (8, 128, 192): (48.1, 219.0), (8, 224, 384): (168.5, 767.0)}
 STEP_MB_PER_GPU = 1119.6
 SWEEP_BATCHES = (1, 2, 4, 8, 16, 32)
+# forward work per clip (inference): (clip, height, width) -> (GFLOP, MB)
+INFER_WORK = {(32, 224, 384): (229.32, 1004.9), (64, 256, 448): (611.5, 2664.8), (8, 128, 192): (16.36, 73.0), (8, 224, 384): (57.25, 255.5)}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -57,7 +59,9 @@ def parse():
     ap.add_argument("--no-side-stream", action="store_true", help="run wgrad on the main stream (A/B)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-site HIP-event table to stderr")
     ap.add_argument("--main-priority", type=int, default=0, help="tuning: run the step on a stream of this priority (-1 = high) instead of the default stream")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the `inference` and `other_configs` legs the default N = 1 training line carries")
+    ap.add_argument("--spawn", action="store_true", help="go through the self-spawn path (one rank per GPU under torch.distributed.run) even for --gpus 1")
+    return ap.parse_args(argv)
 
 
 def host_cores():
@@ -125,13 +129,155 @@ def cpu_baseline(args):
                        "%d threads, after one warm-up step" % (n, args.mode, args.clip, args.height, args.width, cores))
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-run this script as N ranks (one per GPU, RCCL) under
+    torch.distributed.run, exactly as the driver's multi-GPU command does; the ranks' stdout (rank 0's JSON line) is ours.
+    Refuses (exit code 2) when the node has fewer devices than ranks instead of silently measuring one GPU."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print("bench.py: --gpus %d but %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
-    from vinet_amd import _lib, engine, loss, model, optim, parallel, synth
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        spawn_ranks(args)
+    from vinet_amd import _lib, engine, parallel
     rank, world, local, dev = parallel.init_from_env()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let bench.py spawn them)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if parallel.distributed():
+        assert dist.get_world_size() == world, "process group size differs from WORLD_SIZE"
+        assert dist.get_backend() == "nccl" or os.environ.get("VINET_DIST_BACKEND"), "RCCL (backend nccl) process group expected"
     _lib.load()
+    out = measure(args, rank, world, dev)
+    if rank == 0 and world == 1 and args.mode == "train" and not args.no_extras:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out.update(extras(args, dev))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    result_line = json.dumps(out) if rank == 0 else None
+    # The JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio when its first communicator
+    # comes up, and a piped C stream is only flushed at exit -- after Python's own buffer, i.e. behind the result.  Every
+    # rank pushes what its C side has buffered out BEFORE the last barrier; rank 0 prints after it.
+    def flush_c_stdio():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+    sys.stdout.flush()
+    flush_c_stdio()
+    if parallel.distributed():
+        dist.barrier()
+        dist.destroy_process_group()
+    flush_c_stdio()
+    if result_line is not None:
+        print(result_line, flush=True)
+
+
+def _quiet(args, **kw):
+    """a copy of the parsed arguments for a secondary leg: no sweep, no site table, no CPU baseline"""
+    a = argparse.Namespace(**vars(args))
+    a.no_sweep, a.profile_all, a.no_cpu_baseline, a.no_extras = True, False, True, True
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def extras(args, dev):
+    """The rest of BASELINE.json's metric (`...; inference fps`, generate_result.py:58-73,98) and the secondary configs, timed
+    in the same process after the headline: batch-1 hipGraph fps, batch-64 clips/s, the harness end to end (sliding
+    window + post-processing + bytes to the host), AViNet training (config 4, one GPU) and the 64-frame long clip (config 5,
+    build-defined decoder tail, no reference parity).  Each leg is a few steps; a failing leg reports its error string."""
+    import gc
+    import traceback
+
+    def leg(fn):
+        try:
+            return fn()
+        except Exception as e:       # a secondary leg must never take the headline down with it
+            traceback.print_exc(file=sys.stderr)
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            gc.collect()
+            torch.cuda.empty_cache()
+
+    def infer(batch, graph, steps):
+        r = measure(_quiet(args, mode="infer", batch=batch, graph=graph, steps=steps, warmup=2), 0, 1, dev)
+        gf, mb = INFER_WORK[(args.clip, args.height, args.width)]
+        v = r["value"]
+        return {"value": v, "unit": "fps (one output frame per model call)" if batch == 1 else "clips/s", "batch": batch, "hipgraph": bool(graph),
+                "ms_per_call": r["ms_per_step"], "hbm_frac": v * mb / 1e3 / HBM_PEAK_GBS, "mfma_frac": v * gf / 1e3 / MFMA_BF16_PEAK_TF}
+
+    def harness():
+        import time as _t
+        from vinet_amd import engine, model, synth
+        from vinet_amd.generate_result import predict_stream, sliding_window_schedule
+        engine.set_default_dtype(args.dtype)
+        m = model.VideoSaliencyModel(num_clips=args.clip)
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), 0))
+        m = m.to(dev).eval()
+        n = 6 * args.clip - 1
+        frames = synth.clip(1, n, args.height, args.width, 0)[0].to(dev)
+
+        def run(fr):     # frames arrive 32 at a time, clips are ring views, maps leave the device as bytes
+            got = [mp.clone() for _, mp in predict_stream(m, (fr[c:c + 32] for c in range(0, fr.shape[0], 32)), args.clip, 1, (360, 640), True)]
+            return torch.cat(got).cpu()
+        run(frames[:2 * args.clip - 1])
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        run(frames)
+        torch.cuda.synchronize()
+        calls = len(sliding_window_schedule(n, args.clip))
+        dt = _t.perf_counter() - t0
+        gf, mb = INFER_WORK[(args.clip, args.height, args.width)]
+        return {"value": calls / dt, "unit": "fps", "frames": n, "model_calls": calls, "hbm_frac": calls / dt * mb / 1e3 / HBM_PEAK_GBS,
+                "mfma_frac": calls / dt * gf / 1e3 / MFMA_BF16_PEAK_TF,
+                "what": "vinet_amd.generate_result.predict_stream: sliding window + time-flipped early frames, batch 1, hipGraph replay of "
+                        "model call + resize to 360x640 + 11x11 blur + uint8, maps copied to the host as bytes"}
+
+    def train_cfg(**kw):
+        r = measure(_quiet(args, mode="train", steps=2, warmup=1, **kw), 0, 1, dev)
+        return {"value": r["value"], "unit": "clips/s", "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
+                "whole_step": r["whole_step"], "peak_hbm_gb": r["config"]["peak_hbm_gb"]}
+
+    res = {}
+    if (args.clip, args.height, args.width) in INFER_WORK and args.model == "vinet":
+        res["inference"] = {
+            "batch1_hipgraph": leg(lambda: infer(1, True, 200)),
+            "batch64": leg(lambda: infer(64, False, 6)),
+            "harness_end_to_end": leg(harness),
+            "note": "hbm_frac / mfma_frac: BASELINE.md forward work per clip (%.2f GFLOP, %.1f MB) x rate over 8 TB/s / 2.5 PFLOP/s" % INFER_WORK[(args.clip, args.height, args.width)],
+        }
+    if (args.clip, args.height, args.width) == (32, 224, 384) and args.model == "vinet":
+        res["other_configs"] = {
+            "avinet_32x224x384_b192": leg(lambda: train_cfg(model="avinet", batch=0)),
+            "vinet_64x256x448_b64": leg(lambda: train_cfg(clip=64, height=256, width=448, batch=0)),
+        }
+    return res
+
+
+def measure(args, rank, world, dev):
+    """one configuration: warm-up, dominant-kernel discovery, K timed steps -> the result dict (rank 0; other ranks get the
+    same dict without meaning)"""
+    from vinet_amd import engine, loss, model, optim, parallel, synth
     engine.set_default_dtype(args.dtype)
     engine.WGRAD_SIDE_STREAM = not args.no_side_stream
 
@@ -306,10 +452,13 @@ def main():
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (profiles/pmc_traffic.json; separate --pmc runs, gfx950 FETCH_SIZE correction applied); None if the
         # dominant kernel was not in that profile
-        traffic, pmc = None, None
+        traffic, pmc, pmc_blob = None, None, None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
-                pj = json.load(f)
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json"), "rb") as f:
+                raw = f.read()
+                import hashlib
+                pmc_blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()[:12]
+                pj = json.loads(raw)
                 pmc = pj["kernels"].get(dom.replace(" ", ""))
             if pmc is not None and B == pj.get("batch", 32) and args.mode == "train":
                 traffic = pmc["traffic_bytes_per_launch"]
@@ -323,6 +472,8 @@ def main():
         if traffic is not None:
             roof["traffic_source"] = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes); (2*FETCH+WRITE)*1024 B, L2-miss traffic incl. Infinity-Cache hits"
             roof["mfma_busy_frac_pmc"] = pmc.get("mfma_busy_frac")
+            roof["traffic_source_blob"] = pmc_blob       # git blob id of the counter file this line read (goes stale with the kernels)
+            roof["traffic_source_build"] = pj.get("build")
         per_gpu = value / world
         work = TRAIN_WORK.get((args.clip, args.height, args.width)) if args.mode == "train" else None
         whole = None
@@ -362,28 +513,8 @@ def main():
             out["sweep"] = dict(unit="clips/s", steps_each=args.sweep_steps, local_batch=sweep, local_batch_eager=sweep_eager,
                                 note="local_batch: the step replayed as one hipGraph (vinet_amd.graph.GraphedTrainStep) for batches below the "
                                      "headline's, which is eager; local_batch_eager: one Python-issued launch per kernel")
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
-        result_line = json.dumps(out)
-    else:
-        result_line = None
-    # The JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio when its first communicator
-    # comes up, and a piped C stream is only flushed at exit -- after Python's own buffer, i.e. behind the result.  Every
-    # rank pushes what its C side has buffered out BEFORE the last barrier; rank 0 prints after it.
-    def flush_c_stdio():
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-    sys.stdout.flush()
-    flush_c_stdio()
-    if parallel.distributed():
-        dist.barrier()
-        dist.destroy_process_group()
-    flush_c_stdio()
-    if result_line is not None:
-        print(result_line, flush=True)
+        return out
+    return {}
 
 
 if __name__ == "__main__":

@@ -309,3 +309,49 @@ def test_streaming_harness_equals_the_resident_one():
     finally:
         L._install_test_double(None)
         E.set_default_dtype("bf16")
+
+
+def test_fold_list_parser_and_s3d_key_rule(tmp_path):
+    """generate_result_audio_visual.py:22-30 (three words per line) and the key rule of train.py:144-170"""
+    from vinet_amd import generate_result_audio_visual as AV
+    f = tmp_path / "list.txt"
+    f.write_text("clip_1 120 25\n\nclip_2  80 29.97\n")
+    assert AV.read_sal_text(str(f)) == [("clip_1", "120", "25"), ("clip_2", "80", "29.97")]
+    assert TR._s3d_key("base.0.conv_s.weight") == "base1.0.conv_s.weight"
+    assert TR._s3d_key("base.4.x") == "base1.4.x" and TR._s3d_key("base.5.x") == "base2.0.x"
+    assert TR._s3d_key("base.7.x") == "base2.2.x" and TR._s3d_key("base.8.x") == "base3.0.x"
+    assert TR._s3d_key("base.13.x") == "base3.5.x" and TR._s3d_key("base.14.x") == "base4.0.x"
+    assert TR._s3d_key("module.base.15.branch3.1.bn.bias") == "base4.1.branch3.1.bn.bias"
+    assert TR._s3d_key("fc.0.weight") == "fc.0.weight"
+
+
+def test_device_batch_keeps_one_audio_table_per_dataset():
+    """Coutrot_db1 / Coutrot_db2 style name clashes: two datasets with a video of the SAME folder name and different audio.
+    An item carries its dataset's table key, so the excerpt is cut from its own dataset's waveform (the reference keeps one
+    table per SoundDatasetLoader, dataloader.py:181-186); the waveform cache is bounded."""
+    from tests.abi_emulator import AbiEmulator
+    from vinet_amd import _lib as L
+    from vinet_amd import dataloader as DL
+    from vinet_amd import preprocess as PR
+    L._install_test_double(AbiEmulator())
+    try:
+        n = 3 * PR.MAX_AUDIO_WIN
+        wa = torch.linspace(-1, 1, n).view(1, n).contiguous()
+        wb = (-wa).contiguous()
+        tables = {("Coutrot_db1", "train"): {"clip_1": {"wav": wa}}, ("Coutrot_db2", "train"): {"clip_1": {"wav": wb}}}
+        batch = DL.DeviceBatch(torch.device("cpu"), "train", audio_tables=tables)
+        lo, hi = 1000, 1000 + 20000
+        a = batch._audio(("clip_1", (lo, hi), ("Coutrot_db1", "train")))
+        b = batch._audio(("clip_1", (lo, hi), ("Coutrot_db2", "train")))
+        assert a.shape == (1, PR.MAX_AUDIO_WIN, 1) and torch.equal(a, -b) and float(a.abs().max()) > 0
+        assert torch.equal(a.view(-1), PR.audio_excerpt(wa[0], lo, hi).view(-1))
+        # single-table form (one dataset) still works with two-field references
+        one = DL.DeviceBatch(torch.device("cpu"), "train", audiodata=tables[("Coutrot_db2", "train")])
+        assert torch.equal(one._audio(("clip_1", (lo, hi))), b)
+        # bounded cache
+        batch.WAV_CACHE = 1
+        batch._audio(("clip_1", (lo, hi), ("Coutrot_db1", "train")))
+        assert len(batch._wav) == 1
+        assert torch.equal(batch._audio(("clip_1", None, ("Coutrot_db1", "train"))), torch.zeros(1, PR.MAX_AUDIO_WIN, 1))
+    finally:
+        L._install_test_double(None)

@@ -606,3 +606,103 @@ def test_two_ranks_on_one_gpu_bucketed_allreduce(tmp_path):
     dg = float((r0["bucketed_g"] - r0["flat_g"]).abs().max() / (r0["flat_g"].abs().max() + 1e-30))
     assert dg < 1e-6, "bucketed (overlapped) all-reduce differs from the flat one: %g" % dg
     _note("two_rank_gpu", dict(backend=used, bucketed_vs_flat_grad=dg))
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5 at its full size, 64 x 256 x 448 (no reference exists for it, SURVEY.md F5, and the oracle needs minutes
+    per clip there): size-independent properties of the bf16 path -- output shape, finiteness, range, the loss descends over
+    three steps, inference is deterministic and batch-independent (clip i of a batch of 2 ~ the clip alone, eval-mode BN)."""
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    from vinet_amd import optim as VO
+    E.set_default_dtype("bf16")
+    T, H, W, B = 64, 256, 448, 2
+    m = VM.VideoSaliencyModel(num_clips=T)
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 5))
+    m = m.to(DEV).eval()
+    x = synth.clip(B, T, H, W, 5).permute(0, 2, 1, 3, 4).to(DEV)
+    gt = synth.gt_map(B, H, W, 5).to(DEV)
+    with torch.no_grad():
+        y2 = m(x)
+        y2b = m(x)
+        y1 = m(x[1:2])
+    assert tuple(y2.shape) == (B, H, W) and bool(torch.isfinite(y2).all())
+    assert float(y2.min()) >= 0.0 and float(y2.max()) <= 1.0
+    assert torch.equal(y2, y2b), "inference is not deterministic"
+    # (a batch of 1 may take split-K kernels: another summation order, bf16 round-off -- not another clip's data)
+    assert float((y2[1:2] - y1).abs().max()) < 2e-2, "a clip's map depends on its batch neighbours in eval mode"
+    m.train()
+    opt = VO.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        l = VL.kldiv(m(x), gt)
+        l.backward()
+        opt.step()
+        losses.append(float(l))
+    assert all(v == v for v in losses) and losses[2] < losses[1] < losses[0], losses
+    _note("config5_64x256x448_properties", dict(losses=losses, map_min=float(y2.min()), map_max=float(y2.max())))
+
+
+def test_graphed_train_step_follows_the_eager_trajectory():
+    """GraphedTrainStep's warm-up steps are real steps; everything they advance (parameters, Adam moments and step count,
+    BatchNorm running statistics, num_batches_tracked) is restored before capture, so a run that builds the graph takes the
+    same first steps as an eager run (bf16: identical kernels, atomics-order round-off only)."""
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    from vinet_amd import optim as VO
+    from vinet_amd.graph import GraphedTrainStep
+    E.set_default_dtype("bf16")
+    B, T, H, W = 2, 8, 64, 96
+    x = synth.clip(B, T, H, W, 3).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
+    gt = synth.gt_map(B, H, W, 3).to(DEV)
+    res = {}
+    for mode in ("eager", "graph"):
+        m = VM.VideoSaliencyModel(num_clips=T)
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), 3))
+        m = m.to(DEV).train()
+        opt = VO.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+        p0 = opt.flat_p.clone()
+        rm0 = m.backbone.base1[0].bn_s.running_mean.clone()
+        if mode == "graph":
+            step = GraphedTrainStep(m, opt, VL.kldiv, (x,), gt)
+            assert torch.equal(opt.flat_p, p0) and opt._step == 0 and float(opt.flat_m.abs().max()) == 0.0
+            assert torch.equal(m.backbone.base1[0].bn_s.running_mean, rm0)
+            losses = [float(step((x,), gt)) for _ in range(2)]
+        else:
+            losses = []
+            for _ in range(2):
+                opt.zero_grad()
+                l = VL.kldiv(m(x), gt)
+                l.backward()
+                opt.step()
+                losses.append(float(l))
+        torch.cuda.synchronize()
+        res[mode] = (losses, opt.flat_p.clone(), m.backbone.base1[0].bn_s.running_mean.clone(),
+                     int(m.state_dict()["backbone.base1.0.bn_s.num_batches_tracked"]))
+    (le, pe, re_, ne), (lg, pg, rg, ng) = res["eager"], res["graph"]
+    assert abs(le[0] - lg[0]) < 1e-4 and abs(le[1] - lg[1]) < 2e-3, (le, lg)
+    assert float((pe - pg).abs().max()) < 3e-4          # two Adam steps of lr 1e-4 move a weight by <= 2e-4
+    assert torch.allclose(re_, rg, rtol=1e-3, atol=1e-6) and ne == ng == 2
+
+
+def test_bench_self_spawn_path(tmp_path):
+    """`python bench.py --gpus N` without a launcher re-runs itself as N ranks under torch.distributed.run (one per GPU,
+    backend nccl = RCCL).  With one GPU here: `--spawn` forces that path for N = 1 and VINET_FORCE_COLLECTIVES makes the
+    single rank run every collective of the N > 1 step; asking for more GPUs than the node has is refused (exit code 2)
+    instead of silently measuring one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VINET_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1", "--batch", "4",
+                          "--no-sweep", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1"
+    too_many = torch.cuda.device_count() + 1
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(too_many), "--steps", "1", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 2 and "GPU(s) visible" in bad.stderr, (bad.returncode, bad.stderr[-500:])
+    _note("bench_self_spawn", dict(clips_per_s=line["value"], refused_gpus=too_many))

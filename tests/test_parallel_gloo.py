@@ -215,3 +215,35 @@ def test_trainable_parameters_skip_soundnet_heads():
     allp = sum(p.numel() for p in m.parameters())
     used = sum(p.numel() for p in parallel.trainable_parameters(m))
     assert allp - used == 1024 * 1000 * 8 + 1000 + 1024 * 401 * 8 + 401
+
+
+def test_gradient_buckets_count_each_parameter_once(monkeypatch):
+    """A bucket leaves when every member PARAMETER has reported, not after as many reports as it has members: a parameter
+    that reports twice (a module used twice in forward) must not release the bucket early, and a report behind the
+    bucket's all-reduce is an error (it would add an un-reduced contribution to a summed slice)."""
+    import types
+    from vinet_amd import parallel as P
+    ps = [torch.nn.Parameter(torch.zeros(4)) for _ in range(4)]
+    opt = types.SimpleNamespace(_params=ps, _offs=[0, 4, 8, 12], flat_g=torch.zeros(16), grad_scale=1.0)
+    gb = P.GradientBuckets(opt, bucket_bytes=32)        # two parameters per bucket, last parameters first
+    assert [(lo, hi, n) for lo, hi, n in gb.buckets] == [(8, 16, 2), (0, 8, 2)]
+    sent = []
+    monkeypatch.setattr(P, "distributed", lambda: True)
+    monkeypatch.setattr(P.dist, "get_world_size", lambda: 2)
+    monkeypatch.setattr(gb, "_launch", lambda b, ctx=None: (sent.append(b), gb._launched.__setitem__(b, True)))
+    gb.begin_step()
+    gb._on_param(None, ps[3])
+    assert sent == []
+    gb._on_param(None, ps[2])
+    assert sent == [0]
+    with pytest.raises(AssertionError):
+        gb._on_param(None, ps[3])                       # a second writer of an already reduced slice
+    # a parameter with two writers: announce it, the bucket waits for the second report
+    gb.expect_reports({id(ps[1]): 2})
+    gb.begin_step()
+    sent.clear()
+    gb._on_param(None, ps[1])
+    gb._on_param(None, ps[0])
+    assert sent == []
+    gb._on_param(None, ps[1])
+    assert sent == [1]

@@ -17,7 +17,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libvinet_hip.so")
 SOURCES = ["conv_api.hip", "conv_bf16.hip", "conv_f32.hip", "conv_wgrad.hip", "wgrad_dma.hip", "wgrad_pp.hip", "wgrad_ts.hip", "conv_ts.hip", "wgrad_hs.hip", "wgrad_rs.hip", "wgrad_tf.hip", "conv_hs.hip", "layout.hip", "bn.hip", "pool.hip", "resample.hip", "loss_adam.hip", "postproc.hip", "preproc.hip"]
-HEADERS = ["common.h", "conv_igemm.h", "conv_dma.h", "conv_pp.h", os.path.join(ROOT, "include", "vinet_hip.h")]
+import glob
+# every header of csrc/ and include/ is a dependency of every object (a stale object travelling to the GPU box is worse
+# than a rebuild of 20 files)
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result", "-ffp-contract=off"]
 

@@ -151,8 +151,13 @@ class SoundDatasetLoader(Dataset):
         gt = torch.from_numpy(np.asarray(Image.open(self._map_file(video, first + T)).convert('L')).copy())
         assert int(gt.max()) != 0, (first, video)
         if self.use_sound or self.use_vox:
-            return clip, gt, (video, self.audio_bounds(video, first))
+            # the third field names THIS dataset's audio table: several datasets use the same folder names (clip_1 ...)
+            return clip, gt, (video, self.audio_bounds(video, first), self.table_key)
         return clip, gt
+
+    @property
+    def table_key(self):
+        return (self.dataset_name, self.mode)
 
 
 class Hollywood_UCFDataset(Dataset):
@@ -213,18 +218,31 @@ class DeviceBatch:
     `gt_dtype=torch.float64` reproduces SoundDatasetLoader's double ground truth (it skips the FloatTensor cast the other
     two datasets apply: dataloader.py:217-226 vs 296; the values are the float32 results widened)."""
 
-    def __init__(self, device, mode="train", audiodata=None, gt_dtype=None):
+    WAV_CACHE = 64       # waveforms kept on the device (least recently used first out)
+
+    def __init__(self, device, mode="train", audiodata=None, gt_dtype=None, audio_tables=None):
+        """`audiodata`: ONE dataset's table {video: info}; `audio_tables`: {SoundDatasetLoader.table_key: table} when the
+        batches come from several datasets (train.run concatenates six): an item's third reference field picks its own
+        dataset's table, as the reference keeps one table per SoundDatasetLoader (dataloader.py:181-186)."""
         self.device, self.mode, self.audiodata, self.gt_dtype = device, mode, audiodata or {}, gt_dtype
-        self._wav = {}
+        self.audio_tables = audio_tables or {}
+        from collections import OrderedDict
+        self._wav = OrderedDict()
 
     def _audio(self, ref):
         from . import preprocess as PR
-        video, bounds = ref
+        video, bounds = ref[0], ref[1]
+        tkey = ref[2] if len(ref) > 2 else None
         if bounds is None:
             return torch.zeros(1, PR.MAX_AUDIO_WIN, 1, device=self.device)
-        w = self._wav.get(video)
+        table = self.audio_tables.get(tkey) if tkey in self.audio_tables else self.audiodata
+        ck = (tkey if tkey in self.audio_tables else None, video)
+        w = self._wav.get(ck)
         if w is None:
-            w = self._wav[video] = self.audiodata[video]['wav'][0].contiguous().to(self.device)
+            w = self._wav[ck] = table[video]['wav'][0].contiguous().to(self.device)
+        self._wav.move_to_end(ck)
+        while len(self._wav) > max(1, self.WAV_CACHE):
+            self._wav.popitem(last=False)
         return PR.audio_excerpt(w, bounds[0], bounds[1]).view(1, -1, 1)
 
     def __call__(self, sample):

@@ -25,15 +25,11 @@ from . import preprocess
 
 
 def read_sal_text(txt_file):
-    """generate_result_audio_visual.py:22-30."""
-    test_list = {'names': [], 'nframes': [], 'fps': []}
+    """A fold list (`<video> <frame count> <fps>` per line, generate_result_audio_visual.py:22-30) as a list of
+    (video, frame count, fps) string triples in file order; blank lines are skipped."""
     with open(txt_file, 'r') as f:
-        for line in f:
-            word = line.strip().split()
-            test_list['names'].append(word[0])
-            test_list['nframes'].append(word[1])
-            test_list['fps'].append(word[2])
-    return test_list
+        rows = [ln.split() for ln in f]
+    return [(r[0], r[1], r[2]) for r in rows if r]
 
 
 def load_wav(path):
@@ -54,29 +50,28 @@ def load_wav(path):
 
 
 def make_dataset(annotation_path, audio_path, gt_path, device=None):
-    """generate_result_audio_visual.py:32-86: per video the waveform (scaled by 2**-23, on `device`) and the audio sample
-    range of every frame."""
-    data = read_sal_text(annotation_path)
-    names, fps = data['names'], data['fps']
-    audiodata = {}
-    for i in range(len(names)):
-        if i % 100 == 0:
-            print('dataset loading [{}/{}]'.format(i, len(names)))
-        n_frames = len(os.listdir(join(gt_path, names[i], 'maps')))
-        if n_frames <= 1:
+    """generate_result_audio_visual.py:32-86: per video of the fold list the waveform (scaled by 2**-23, on `device`) and
+    the audio sample range of every frame.  Videos with at most one annotated frame or without a .wav are skipped (and
+    reported with the reference's messages)."""
+    entries = read_sal_text(annotation_path)
+    table = {}
+    for n, (video, _, fps) in enumerate(entries):
+        if n % 100 == 0:
+            print('dataset loading [{}/{}]'.format(n, len(entries)))
+        n_maps = len(os.listdir(join(gt_path, video, 'maps')))
+        if n_maps <= 1:
             print("Less frames")
             continue
-        audio_wav_path = os.path.join(audio_path, names[i], names[i] + '.wav')
-        if not os.path.exists(audio_wav_path):
-            print("Not exists", audio_wav_path)
+        wav_file = join(audio_path, video, video + '.wav')
+        if not os.path.exists(wav_file):
+            print("Not exists", wav_file)
             continue
-        audiowav, Fs = load_wav(audio_wav_path)
-        audiowav = audiowav * (2 ** -23)
-        starts, ends = preprocess.audio_frame_bounds(n_frames, fps[i], Fs, audiowav.shape[1])
-        if device is not None:
-            audiowav = audiowav.to(device)
-        audiodata[names[i]] = {'audiopath': audio_path, 'video_id': names[i], 'Fs': Fs, 'wav': audiowav, 'starts': starts, 'ends': ends}
-    return audiodata
+        wav, rate = load_wav(wav_file)
+        wav = wav * (2 ** -23)
+        starts, ends = preprocess.audio_frame_bounds(n_maps, fps, rate, wav.shape[1])
+        table[video] = {'audiopath': audio_path, 'video_id': video, 'Fs': rate, 'starts': starts, 'ends': ends,
+                        'wav': wav if device is None else wav.to(device)}
+    return table
 
 
 def get_audio_feature(audioind, audiodata, args, start_idx):

@@ -58,14 +58,43 @@ class GraphedTrainStep:
         self.static_in = [t.clone() for t in inputs]
         self.static_gt = gt.clone()
         self._bns = [m for m in model.modules() if hasattr(m, "note_training_step")]
+        # The warm-up steps are REAL steps (they have to be: they build weight packs, tap tables, persistent workspaces, LDS
+        # attributes and autograd's own set-up), so everything they advance is snapshotted and put back: parameters, Adam
+        # moments and step count, BatchNorm running statistics and the lazily counted num_batches_tracked.  A run that
+        # builds the graph then follows the eager trajectory from the first user-visible step.
+        opt = self.opt
+        snap_opt = [t.clone() for t in (opt.flat_p, opt.flat_m, opt.flat_v)] if hasattr(opt, "flat_p") else None
+        snap_step = getattr(opt, "_step", None)
+        snap_sd = None if snap_opt is not None else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items()}
+        snap_par = None if snap_opt is not None else [p.detach().clone() for p in model.parameters()]
+        snap_buf = [(b, b.clone()) for b in model.buffers()]
+        snap_pend = [(bn, bn.__dict__.get("_vinet_pending", 0)) for bn in self._bns]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):          # weight packs, tap tables, persistent workspaces, LDS attributes, autograd's own set-up
                 self._body()
                 self.opt.step()
+            with torch.no_grad():
+                if snap_opt is not None:
+                    for dst, src in zip((opt.flat_p, opt.flat_m, opt.flat_v), snap_opt):
+                        dst.copy_(src)
+                    opt._step = snap_step
+                else:
+                    for p_, v_ in zip(model.parameters(), snap_par):
+                        p_.copy_(v_)
+                for b, v_ in snap_buf:
+                    b.copy_(v_)
+            from . import engine
+            engine.bump_weights_epoch()       # the packs built from the warm-up weights are stale
+        for bn, pend in snap_pend:
+            bn.__dict__["_vinet_pending"] = pend
+            bn.__dict__.setdefault("_vinet_fold", {}).clear()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if snap_sd is not None:
+            import copy
+            opt.load_state_dict(copy.deepcopy(snap_sd))
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_loss = self._body()

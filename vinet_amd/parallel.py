@@ -140,7 +140,8 @@ class GradientBuckets:
                 hi, members = o, []
         if members:
             self._add(0, hi, members)
-        self._works, self._pending, self._launched = [], [], []
+        self._works, self._fired, self._members, self._launched = [], [], [], []
+        self._seen, self._last_ctx = {}, None
         self._comm_streams = {}
 
     def _add(self, lo, hi, members):
@@ -152,20 +153,43 @@ class GradientBuckets:
         return distributed()
 
     def begin_step(self):
+        """ONE backward per begin_step / finish pair: a bucket leaves when every one of its parameters has reported its
+        gradient once (a set of parameter ids, so a parameter whose gradient is written by two tape nodes -- a module used
+        twice in forward -- is counted once, at its LAST report: see _on_param).  Gradient accumulation over several
+        backward() calls must call finish() only after the last one and not use the overlapped form (use
+        allreduce_gradients after the last backward instead)."""
         from . import engine
         self._works = []
-        self._pending = [n for _, _, n in self.buckets]
+        self._members = [n for _, _, n in self.buckets]
+        self._fired = [set() for _ in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._seen, self._last_ctx = {}, None
         if self.active():
             engine.PARAM_GRAD_HOOK = self._on_param
         self.opt.grad_scale = 1.0 / dist.get_world_size() if self.active() else 1.0
 
+    def expect_reports(self, counts):
+        """{id(param): number of tape nodes that write its gradient per backward} for models that use a parameter more than
+        once in forward (none of the ViNet / AViNet modules do): the bucket then waits for the last report."""
+        self._expected = dict(counts)
+
     def _on_param(self, ctx, p):
         b = self.index.get(id(p))
-        if b is None or self._launched[b]:
+        if b is None:
             return
-        self._pending[b] -= 1
-        if self._pending[b] <= 0:
+        # a report behind the bucket's launch would add an un-reduced contribution to an already summed slice
+        assert not self._launched[b], ("gradient of a parameter reported after its bucket's all-reduce was issued: a parameter "
+                                       "written by several tape nodes (or a second backward inside one begin_step/finish "
+                                       "pair) needs GradientBuckets.expect_reports")
+        self._last_ctx = ctx
+        need = getattr(self, "_expected", {}).get(id(p), 1)
+        seen = self._seen.get(id(p), 0) + 1 if need > 1 else 1
+        if need > 1:
+            self._seen[id(p)] = seen
+            if seen < need:
+                return
+        self._fired[b].add(id(p))
+        if len(self._fired[b]) == self._members[b]:
             self._launch(b, ctx)
 
     def _launch(self, b, ctx=None):
@@ -188,14 +212,17 @@ class GradientBuckets:
 
     def finish(self):
         """buckets whose parameters got no (or not every) gradient this step go out now; then the optimizer's stream waits
-        for every bucket"""
+        for every bucket.  Called after backward(): engine.Ctx.run_backward has already made the main stream wait for the
+        weight-gradient side stream, so the leftovers only need the main stream -- they are launched with the last tape
+        context anyway, which joins the side stream explicitly as well."""
         from . import engine
         engine.PARAM_GRAD_HOOK = None
         if not self.active():
             return
         for b in range(len(self.buckets)):
             if not self._launched[b]:
-                self._launch(b)
+                self._launch(b, self._last_ctx)
         for w in self._works:
             w.wait()
         self._works = []
+        self._last_ctx = None

@@ -114,23 +114,37 @@ def build_model(args):
     return model.VideoSaliencyModel(use_upsample=bool(args.decoder_upsample), num_hier=args.num_hier, num_clips=args.clip_size)
 
 
+S3D_STAGE_STARTS = (0, 5, 8, 14)      # first `base.N` index of base1 .. base4 (train.py:146)
+
+
+def _s3d_key(key):
+    """checkpoint key -> BackBoneS3D key: a leading DataParallel `module.` is dropped and `base.N.rest` becomes
+    `base{stage}.{N - first index of that stage}.rest`."""
+    parts = key.split('.')
+    if 'module' in key:
+        parts = parts[1:]
+    if 'base.' in key and len(parts) > 2 and parts[0] == 'base':
+        layer = int(parts[1])
+        stage = max(i for i, first in enumerate(S3D_STAGE_STARTS) if layer >= first)
+        parts = ['base%d' % (stage + 1), str(layer - S3D_STAGE_STARTS[stage])] + parts[2:]
+    return '.'.join(parts)
+
+
 def remap_s3d_kinetics(weight_dict, backbone):
-    """S3D Kinetics-400 checkpoint -> BackBoneS3D keys: `base.N.*` -> `base{1..4}.M.*` with the
-    split points [0, 5, 8, 14] (train.py:141-172)."""
-    model_dict = backbone.state_dict()
-    sn_list = [0, 5, 8, 14]
-    for name, param in weight_dict.items():
-        if 'module' in name:
-            name = '.'.join(name.split('.')[1:])
-        if 'base.' in name:
-            bn = int(name.split('.')[1])
-            sn = max(s for s in sn_list if bn >= s)
-            name = 'base%d.%d.' % (sn_list.index(sn) + 1, bn - sn) + '.'.join(name.split('.')[2:])
-        if name in model_dict and param.size() == model_dict[name].size():
-            model_dict[name].copy_(param)
+    """Load an S3D Kinetics-400 checkpoint into BackBoneS3D (the key rule of train.py:141-172): tensors whose mapped key
+    exists with the same shape are taken, the others are reported like the reference does and left at their init."""
+    target = backbone.state_dict()
+    taken = 0
+    for key, tensor in weight_dict.items():
+        mapped = _s3d_key(key)
+        slot = target.get(mapped)
+        if slot is not None and tuple(slot.shape) == tuple(tensor.shape):
+            slot.copy_(tensor)
+            taken += 1
         else:
-            print(' name/size? ' + name)
-    backbone.load_state_dict(model_dict)
+            print(' name/size? ' + mapped)
+    backbone.load_state_dict(target)
+    return taken
 
 
 def train_epoch(model, optimizer, loader, epoch, device, args, world=1):
@@ -235,9 +249,7 @@ def run(args, train_dataset=None, val_dataset=None):
                                                               use_sound=args.use_sound, use_vox=args.use_vox, path_data=args.sound_path_data)
         tr, va = [mk(n, "train") for n in names], [mk(n, "test") for n in names]
         train_dataset, val_dataset = torch.utils.data.ConcatDataset(tr), torch.utils.data.ConcatDataset(va)
-        audiodata = {}
-        for d in tr + va:
-            audiodata.update(d.audiodata)
+        audiodata = {d.table_key: d.audiodata for d in tr + va}     # one table per dataset and mode (names repeat across datasets)
         collate, gt_dtype = dataloader.collate_bytes, torch.float64       # this loader hands the loss double maps (dataloader.py:222-226)
     elif train_dataset is None and args.dataset not in ("synthetic", "DHF1KDataset"):   # train.py:133-136: Hollywood-2 / UCF-Sports
         from . import dataloader
@@ -254,8 +266,8 @@ def run(args, train_dataset=None, val_dataset=None):
     val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=1, shuffle=False, num_workers=0, collate_fn=collate)
     if collate is not None:
         from . import dataloader
-        train_loader.device_batch = dataloader.DeviceBatch(device, "train", audiodata=audiodata, gt_dtype=gt_dtype)
-        val_loader.device_batch = dataloader.DeviceBatch(device, "val", audiodata=audiodata, gt_dtype=gt_dtype)
+        train_loader.device_batch = dataloader.DeviceBatch(device, "train", audio_tables=audiodata, gt_dtype=gt_dtype)
+        val_loader.device_batch = dataloader.DeviceBatch(device, "val", audio_tables=audiodata, gt_dtype=gt_dtype)
     params = parallel.trainable_parameters(model)
     optimizer = optim.Adam(params, lr=args.lr)
     parallel.broadcast_parameters(optimizer)
@@ -265,12 +277,15 @@ def run(args, train_dataset=None, val_dataset=None):
         if sampler is not None:
             sampler.set_epoch(epoch)
         train_epoch(model, optimizer, train_loader, epoch, device, args, world)
+        # replicas keep their own BatchNorm statistics during an epoch (as under the reference's DataParallel, whose
+        # replica-0 statistics survive); every replica adopts rank 0's BEFORE validation, so all ranks validate -- and
+        # rank 0 saves -- the same model, and the validation loss that picks the checkpoint is the mean over ranks
+        parallel.broadcast_buffers(model)
         val_loss = validate(model, val_loader, epoch, device, args)
+        val_loss = float(parallel.allreduce_scalar_mean(torch.tensor(float(val_loss), dtype=torch.float64, device=device)))
         if epoch == 0:
             val_loss = np.inf
             best_loss = val_loss
-        if world > 1:
-            parallel.broadcast_buffers(model)      # replicas keep their own BatchNorm statistics during an epoch; rank 0's are saved
         if val_loss <= best_loss and rank == 0:
             best_loss = val_loss
             print('[{:2d},  save, {}]'.format(epoch, args.model_val_path))
