@@ -265,10 +265,13 @@ HT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("mfma32", [1, 0], ids=["32x32x16", "16x16x32"])
 @pytest.mark.parametrize("case", HT_CASES, ids=[c[0] for c in HT_CASES])
-def test_conv3d_halo_tile(case):
+def test_conv3d_halo_tile(case, mfma32):
+    """both matrix-instruction forms of the halo-tile kernel: conv_ht32.h (v_mfma_f32_32x32x16_bf16, option ht32) and
+    conv_ht.h (16x16x32, the default)"""
     lib = _lib()
-    assert lib.vinet_set_option(b"ht", 2) == 0
+    assert lib.vinet_set_option(b"ht", 2) == 0 and lib.vinet_set_option(b"ht32", mfma32) == 0
     try:
         ex = dict(case[7])
         ex.setdefault("tline", 5)
@@ -277,6 +280,7 @@ def test_conv3d_halo_tile(case):
         assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_ht_kernel<"), buf.value
     finally:
         lib.vinet_set_option(b"ht", 1)
+        lib.vinet_set_option(b"ht32", 0)
 
 
 # split-K (grids too small for the chip): long-K decoder shape, placement through a concat slice, padded fp32
@@ -1468,7 +1472,8 @@ def _exact_targets():
         t.append(("tstream-" + c[0], test_conv3d_tstream, dict(case=c)))
     for c in HT_CASES:
         if not c[7].get("out_f32"):
-            t.append(("halo-" + c[0], test_conv3d_halo_tile, dict(case=c)))
+            t.append(("halo32-" + c[0], test_conv3d_halo_tile, dict(case=c, mfma32=1)))
+            t.append(("halo16-" + c[0], test_conv3d_halo_tile, dict(case=c, mfma32=0)))
     for ksp in [(7, 2, 3), (3, 2, 1), (5, 3, 2)]:
         for acc in (0, 1):
             t.append(("tsd-k%ds%dp%d-acc%d" % (ksp + (acc,)), test_conv3d_tstream_dgrad_fused, dict(ksp=ksp, acc=acc)))

@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--stats", action="store_true", help="forward convs also write BN statistics partials (training epilogue)")
     ap.add_argument("--only", default="", help="substring filter on site names")
     ap.add_argument("--ht", action="store_true", help="A/B of the halo-tile kernel (conv_ht.h) against the default dispatch on the 3x3-spatial sites")
+    ap.add_argument("--default", action="store_true", help="one variant per library: its own dispatch, no option overrides (A/B of two builds)")
+    ap.add_argument("--acc", action="store_true", help="accumulate into y (the epilogue of a data gradient that joins an existing gradient)")
     args = ap.parse_args()
     libs = [(os.path.basename(p), bind(p)) for p in (args.lib or [L.LIB_PATH])]
     dev = torch.device("cuda:0")
@@ -92,12 +94,17 @@ def main():
             variants.append((ln + ":wdma-noperm", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=0), False))
             variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), True))
         libs = []
+    if args.default:
+        for ln, lib in libs:
+            variants.append((ln + ":default", lib, dict(), False))
+        libs = []
     if args.ht:
         for ln, lib in libs:
             variants.append((ln + ":default", lib, dict(ht=0), False))
-            variants.append((ln + ":ht", lib, dict(ht=2), False))
-            variants.append((ln + ":default+pre", lib, dict(ht=0), True))
-            variants.append((ln + ":ht+pre", lib, dict(ht=2), True))
+            variants.append((ln + ":ht16", lib, dict(ht=2, ht32=0), False))
+            variants.append((ln + ":ht32", lib, dict(ht=2, ht32=1), False))
+            variants.append((ln + ":ht16+pre", lib, dict(ht=2, ht32=0), True))
+            variants.append((ln + ":ht32+pre", lib, dict(ht=2, ht32=1), True))
         libs = []
     for ln, lib in libs:
         variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=0, n64_tile=0, n192_tile=0, n128_tile=0), False))
@@ -144,6 +151,8 @@ def main():
             d.pre = L.CAffine(sc.data_ptr(), sh.data_ptr(), 1) if pre else L.CAffine(None, None, 0)
             if args.stats:
                 d.stats = stats.data_ptr()
+            if args.acc:
+                d.accumulate = 1
             if k[1:] == (3, 3):
                 d.tline = 5
             elif k[1:] == (1, 1) and k[0] > 1:

@@ -12,11 +12,13 @@ import torch
 from tools.conv_ab import SITES, bind
 from vinet_amd import _lib as L
 
-lib = bind(os.path.join(ROOT, "vinet_amd", "libvinet_hip_timing.so"))
+lib = bind(os.path.join(ROOT, "vinet_amd", os.environ.get("VINET_TIMING_LIB", "libvinet_hip_timing.so")))
 lib.vinet_set_option(b"ht", 2)
+lib.vinet_set_option(b"ht32", int(os.environ.get("VINET_HT32", "1")))
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream().cuda_stream
 Bn = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+STATS = os.environ.get("VINET_PHASES_STATS", "0") == "1"
 print("%-26s %8s %9s %9s %9s %9s   (s_memtime ticks per workgroup, mean)" % ("site", "blocks", "prologue", "kloop", "epilogue", "halo-wait"))
 for (name, B, T, H, W, Cin, N, k, s, p) in SITES:
     if not (k[1:] == (3, 3) and W % 16 == 0):

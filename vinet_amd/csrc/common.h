@@ -155,6 +155,16 @@ VN_DEV int4 load_tap(const int4* taps, int i) {
 VN_DEV void mfma_bf16_acc(f32x4_v& acc, const bf16x8_v& a, const bf16x8_v& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+// the same product TRANSPOSED (operands swapped: rows of the result tile = rows of b): a lane then holds four consecutive
+// columns of ONE row of a x b^T -- four consecutive channels of a voxel in the conv kernels (conv_igemm.h: conv_epilogue)
+VN_DEV void mfma_bf16_acc_t(f32x4_v& acc, const bf16x8_v& a, const bf16x8_v& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+}
+VN_DEV uint32_t cvt_pk_bf16_f32(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
 // wait states between the last MFMA (8 passes) and a non-MFMA reader of its result
 VN_DEV void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
 // wait states between a VALU write of an MFMA A/B operand and the MFMA that reads it

@@ -135,7 +135,7 @@ static bool use_pp(const VinetConvDesc* d);
 static bool use_ht(const VinetConvDesc* d);
 struct HtShape { int nt, tw, tm, pre; };
 static HtShape ht_shape(const VinetConvDesc* d);
-extern int g_vinet_opt_ht, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
+extern int g_vinet_opt_ht, g_vinet_opt_ht32, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
 bool vinet_conv_use_ts(const VinetConvDesc* d);
 bool vinet_conv_use_hs(const VinetConvDesc* d);
 bool vinet_conv_use_tsd(const VinetConvDesc* d);
@@ -215,6 +215,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "tperm")) { g_vinet_opt_tperm = value; return 0; }
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
   if (name && !strcmp(name, "ht")) { g_vinet_opt_ht = value; return 0; }
+  if (name && !strcmp(name, "ht32")) { g_vinet_opt_ht32 = value; return 0; }
   if (name && !strcmp(name, "ht_minhw")) { g_vinet_opt_ht_minhw = value; return 0; }
   if (name && !strcmp(name, "ht_t")) { g_vinet_opt_ht_t = value; return 0; }
   if (name && !strcmp(name, "ht_pre")) { g_vinet_opt_ht_pre = value; return 0; }
@@ -273,6 +274,7 @@ static bool use_pp(const VinetConvDesc* d) {
 // multiple of 16.  Shape: tile width 32 when W allows it, else 16; column tile = the narrowest of 64 / 96 / 128 that
 // pads N least (192 = 2 x 96).
 int g_vinet_opt_ht = 1;         // 0 = off, 1 = heuristic, 2 = every eligible conv (tests)
+int g_vinet_opt_ht32 = 0;       // 1 = halo-tile kernels on v_mfma_f32_32x32x16_bf16 (conv_ht32.h): correct, measured SLOWER
 int g_vinet_opt_ht_minhw = 28 * 48;
 int g_vinet_opt_ht_t = 1;        // temporal mode of the halo-tile kernel for (3,1,1) / stride-1 convs: 604 -> 647 TF/s plain, 482 -> 514 with a
                                  // pending affine (reuse is only 2x and the image is re-staged every three K steps); whole step neutral (+0...0.6 %)

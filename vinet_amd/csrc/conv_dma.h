@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        mfma_bf16_acc(acc[i][j], af[i], bfr[j]);
+        mfma_bf16_acc_t(acc[i][j], af[i], bfr[j]);
 #endif
   };
 
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = m_wave + i * 16 + (lane >> 4) * 4 + r, n = n_wave + j * 16 + (lane & 15);
+          const int m = m_wave + i * 16 + (lane & 15), n = n_wave + j * 16 + (lane >> 4) * 4 + r;   // (transposed tiles: conv_epilogue)
           if (m < a.M && n < a.N) a.ws[((long)blockIdx.y * a.M + m) * a.N + n] = acc[i][j][r];
         }
     return;

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mfma_bf16_acc(acc[i][j], af[kk][i], bfr[kk][j]);
+        for (int j = 0; j < NT; ++j) mfma_bf16_acc_t(acc[i][j], af[kk][i], bfr[kk][j]);
   };
 
   // ---- pipeline ----------------------------------------------------------------------------------------------------------
@@ -312,14 +312,14 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   const float* dbg_ptr = a.out_shift;
   ConvArgs a2 = a;
   a2.out_shift = nullptr; a2.out_scale = nullptr;
-  conv_epilogue<MT, NT, 4, 1>(a2, acc, smem, (int)sp, tile_n, &er);
+  conv_epilogue<MT, NT, 4, 1>(a2, acc, smem, (int)sp, tile_n, er);
   if (tid == 0 && dbg_ptr) {   // tuning build only: out_shift doubles as a [grid][4] float dump
     const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
     float* dbg = (float*)dbg_ptr + (long)blockIdx.x * 4;
     dbg[0] = (float)(tm1 - tm0); dbg[1] = (float)(tm2 - tm1); dbg[2] = (float)(tm3 - tm2); dbg[3] = (float)tm_halo;
   }
 #else
-  conv_epilogue<MT, NT, 4, 1>(a, acc, smem, (int)sp, tile_n, &er);
+  conv_epilogue<MT, NT, 4, 1>(a, acc, smem, (int)sp, tile_n, er);
 #endif
 }
 

@@ -108,20 +108,61 @@ struct EpiRows {
   int m0, ipr, rstride, nrows, ncols;
 };
 
-// `rows` (optional): see EpiRows; nullptr = rows tile_m*BM + ... as usual.  `tile_m` stays the statistics row of the workgroup.
+// ---- epilogue, second generation (round 3) ---------------------------------------------------------------------------
+// The K loops issue their MFMAs with the operands SWAPPED (weights as the A operand), so the accumulators arrive
+// transposed:   acc[i][j][r] = D[ m = 16 i + (lane & 15) ][ n = 16 j + 4 (lane >> 4) + r ]
+// i.e. a lane holds 4 CONSECUTIVE CHANNELS of one voxel per 16x16 tile instead of 4 voxels of one channel.  What that buys
+// (the epilogue was VALU-issue bound: 20k cycles per 256 x 96 tile, as long as the nine K steps of a 64-channel 3x3 conv):
+//   * no LDS transposition at all on the bf16 path: two v_cvt_pk_bf16_f32 pack the lane's 4 channels of a tile, one
+//     v_permlane16_swap_b32 per dword between the tiles of TWO row groups hands every lane 8 consecutive channels of one
+//     voxel (rows 0 / 2 of the wave keep group 2k, rows 1 / 3 take group 2k + 1), one 16-byte store per lane and tile pair --
+//     instead of 8 two-byte LDS writes with their address arithmetic, two wave-level fences, a ds_read_b128 and the store;
+//   * ReLU is one v_pk_max_i16 per packed pair (as signed 16-bit integers every negative bf16 is < 0);
+//   * per-channel constants are 4 registers per column tile (float4 loads) instead of one per tile and lane;
+//   * BN partial sums: a lane owns its 4 channels' (sum, sum^2) over the row groups, then four DPP row_ror adds reduce the 16
+//     lanes of a row (one voxel each) -- the old layout needed a cross-row shuffle pair per column tile.
+// The accumulate form (data gradients joining an existing gradient) swaps the fp32 values instead (one rounding of
+// old + new, as before); the general path (fp32 output, sigmoid head, channel counts that are no multiple of 8) still goes
+// through a wave-private LDS tile, written 4 channels (one ds_write_b128) at a time.
+// odd rows of x <-> even rows of y (rows = 16 lanes).  The operands come straight out of inline-asm VALU instructions, which
+// the compiler's hazard recogniser cannot see: gfx950 wants 2 wait states between a VALU write and a permlane swap reading it.
+VN_DEV void permlane16_swap(uint32_t& x, uint32_t& y) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+}
+VN_DEV void permlane16_swap_f(float& x, float& y) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+}
+// sum over the 16 lanes of a row (every lane of the row receives the total)
+VN_DEV float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+VN_DEV uint32_t pk_relu_bf16(uint32_t u) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(u));
+  return r;
+}
+
+// `rows` (optional): see EpiRows; default = rows tile_m*BM + ... as usual.  `tile_m` stays the statistics row of the workgroup.
 template <int MT, int NT, int WARPS_M, int WARPS_N>
-VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem, int tile_m, int tile_n, const EpiRows* rows = nullptr) {
+VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem, int tile_m, int tile_n, const EpiRows rows = EpiRows{0, -1, 0, 0, 0}) {
   constexpr int BM = 16 * MT * WARPS_M, BN = 16 * NT * WARPS_N;
+  static_assert(MT % 2 == 0, "row groups are handled in pairs");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   constexpr int WNC = NT * 16, EROW = WNC + 4;
+  const int p = lane & 15, q = lane >> 4;              // my voxel inside a row group, my channel quad inside a column tile
   float* Ew = (float*)smem + wave * (16 * EROW);
   float* red = (float*)(smem + conv_epi_bytes<MT, NT, WARPS_M, WARPS_N>() - WARPS_M * BN * 2 * 4);
   const int m_wave = tile_m * BM + wm * MT * 16;
   const int n_wave = tile_n * BN + wn * WNC;
   const bool do_stats = a.stats != nullptr;
-  const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;   // branch-free ReLU: max(v, floor)
-  const EpiRows er = rows ? *rows : EpiRows{m_wave, 0, 0, 0, 0};
+  const bool relu = a.act == VINET_ACT_RELU;
+  const float relu_floor = relu ? 0.f : -INFINITY;   // branch-free ReLU: max(v, floor)
+  const EpiRows er = rows.ipr >= 0 ? rows : EpiRows{m_wave, 0, 0, 0, 0};      // (ipr == -1: the default row-tiled map)
   // first voxel of row group i, and how many of its 16 rows lie inside the iteration space
   auto group_m0 = [&](int i) { return er.ipr ? er.m0 + (i / er.ipr) * er.rstride + (i % er.ipr) * 16 : er.m0 + i * 16; };
   auto group_rows = [&](int i) { return er.ipr ? (((i / er.ipr) < er.nrows && (i % er.ipr) < er.ncols) ? 16 : 0) : a.M - (er.m0 + i * 16); };
@@ -132,253 +173,208 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
     return (long)b * a.sBy + ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) * (long)a.ldy;
   };
-
-  // per-column epilogue constants and running BN partial sums (accumulated row group by row
-  // group below, so only ONE 16-row group of the accumulator is live in VGPRs at a time:
-  // a 128-register accumulator tile leaves no room for a whole-tile first pass)
-  float s_sum[NT], s_sq[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) { s_sum[j] = 0.f; s_sq[j] = 0.f; }
   const bool sigm = a.act == VINET_ACT_SIGMOID;
-  const bool fast = a.vec_ok && !a.out_f32 && !a.accumulate && a.y_linear;
-
-  // ---- the fast path proper: bf16 rows of whole 8-channel groups, 16-byte aligned --------------------------------------
-  // The epilogue is VALU-issue bound (s_memtime: 20k cycles per 256 x 96 tile, as long as the nine K steps of a 64-channel
-  // 3x3 conv), so this path spends as few instructions per element as the job allows: values are rounded to bf16 by
-  // v_cvt_pk_bf16_f32 BEFORE the LDS transposition (statistics are taken from the fp32 values first); the staging tile
-  // is bf16 and holds up to four row groups (64 rows x all columns of the wave), so one pair of wave-level fences serves
-  // 64 rows and the column constants are scalars of the outer loop, not arrays that live beside a 128-register
-  // accumulator; one conflict-free ds_read_b128 = 8 channels of one voxel; stores are 16 bytes per lane (half as many
-  // store instructions: the store queue, not bandwidth, paces a write burst).
-  // (any output placement: a stride phase of a data gradient scatters its rows over a longer tensor)
-  const bool fast8 = a.vec_ok && !a.out_f32 && !sigm && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (a.sBy & 7) == 0 && (((uintptr_t)a.y) & 15) == 0;
-  if (fast8 && !a.accumulate && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (a.sBy & 7) == 0 &&
-      (((uintptr_t)a.y) & 15) == 0) {
-    constexpr int GP = MT < 4 ? MT : 4;               // row groups per staging pass
-    constexpr int EROWH = WNC + 8;                    // staging row stride in bf16 (16-byte multiple; rows 4 apart sit 16 banks apart)
-    constexpr int VPR8 = WNC / 8, IT8 = (GP * 16 * VPR8 + 63) / 64;
-    static_assert(MT % GP == 0, "row groups per pass");
-    bf16_t* Eh = (bf16_t*)smem + wave * (GP * 16 * EROWH);
+  const bool has_aff = a.out_scale != nullptr || a.out_shift != nullptr;
+  // per-channel constants of my quad in column tile j
+  auto quad_consts = [&](int j, float (&sc)[4], float (&sh)[4], bool (&cok)[4]) {
+    const int n0 = n_wave + j * 16 + q * 4;
 #pragma unroll
-    for (int pass = 0; pass < MT / GP; ++pass) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n_wave + j * 16 + (lane & 15);
-        const bool nokj = n < a.Nw;
-        const float scj = (a.out_scale && nokj) ? a.out_scale[n] : 1.f;
-        const float shj = (a.out_shift && nokj) ? a.out_shift[n] : 0.f;
-        float ss = s_sum[j], qq = s_sq[j];
-#pragma unroll
-        for (int ii = 0; ii < GP; ++ii) {
-          const int i = pass * GP + ii;
-          const int mlim = group_rows(i);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = (lane >> 4) * 4 + r;
-            float av;      // explicit read: the accumulator stays in the AGPR file until this very use
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av) : "a"(acc[i][j][r]));
-            const float v = fmaf(av, scj, shj);
-            const float vs = (nokj && row < mlim) ? v : 0.f;
-            ss += vs; qq += vs * vs;
-            const float o = fmaxf(v, relu_floor);
-            uint32_t pk;
-            asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(pk) : "v"(o));
-            Eh[(ii * 16 + row) * EROWH + j * 16 + (lane & 15)] = (bf16_t)pk;
-          }
-        }
-        s_sum[j] = ss; s_sq[j] = qq;
-        __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: hoisted accumulator reads of later tiles spill
-      }
-      wave_lds_fence();
-      auto item = [&](int k, bool& ok, long& off, uint4& v) {
-        const int e = lane + 64 * k;
-        const int rrow = e / VPR8, cc = (e - rrow * VPR8) * 8;     // staging row (0 .. GP*16), first of 8 channels
-        const int i = pass * GP + (rrow >> 4), rr = rrow & 15;
-        v = *(const uint4*)&Eh[rrow * EROWH + cc];
-        ok = e < GP * 16 * VPR8 && n_wave + cc < a.N && rr < group_rows(i);
-        off = voxel_off(group_m0(i) + rr) + n_wave + cc;
-      };
-#pragma unroll
-      for (int k = 0; k < IT8; ++k) {
-        bool ok; long off; uint4 v;
-        item(k, ok, off, v);
-        if (ok) *(uint4*)((bf16_t*)a.y + off) = v;
-      }
-      wave_lds_fence();
+    for (int r = 0; r < 4; ++r) {
+      cok[r] = n0 + r < a.Nw;
+      sc[r] = (a.out_scale && cok[r]) ? a.out_scale[n0 + r] : 1.f;
+      sh[r] = (a.out_shift && cok[r]) ? a.out_shift[n0 + r] : 0.f;
     }
-  } else if (fast8 && a.accumulate) {
-    // y += result (the data gradients that join an existing gradient): ONE rounding, of old + new in fp32 -- so the staging
-    // tile stays fp32, half as many row groups per pass; the old values are fetched two stores ahead (more spill the 128-register tiles)
-    constexpr int GP = MT < 4 ? (MT < 2 ? 1 : MT / 2) : 2;
-    constexpr int EROWF = WNC + 4;
-    constexpr int VPR8 = WNC / 8, IT8 = (GP * 16 * VPR8 + 63) / 64, CH = IT8 < 2 ? IT8 : 2;
-    static_assert(MT % GP == 0, "row groups per pass");
-    float* Ef = (float*)smem + wave * (GP * 16 * EROWF);
+  };
+  // my row's (voxel's) share of the statistics of column tile j -> the workgroup's reduction table
+  auto put_stats = [&](int j, float (&ss)[4], float (&qq)[4]) {
 #pragma unroll
-    for (int pass = 0; pass < MT / GP; ++pass) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n_wave + j * 16 + (lane & 15);
-        const bool nokj = n < a.Nw;
-        const float scj = (a.out_scale && nokj) ? a.out_scale[n] : 1.f;
-        const float shj = (a.out_shift && nokj) ? a.out_shift[n] : 0.f;
-        float ss = s_sum[j], qq = s_sq[j];
-#pragma unroll
-        for (int ii = 0; ii < GP; ++ii) {
-          const int i = pass * GP + ii;
-          const int mlim = group_rows(i);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = (lane >> 4) * 4 + r;
-            float av;
-            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av) : "a"(acc[i][j][r]));
-            const float v = fmaf(av, scj, shj);
-            const float vs = (nokj && row < mlim) ? v : 0.f;
-            ss += vs; qq += vs * vs;
-            Ef[(ii * 16 + row) * EROWF + j * 16 + (lane & 15)] = fmaxf(v, relu_floor);
-          }
-        }
-        s_sum[j] = ss; s_sq[j] = qq;
-      }
-      wave_lds_fence();
-#pragma unroll
-      for (int k0 = 0; k0 < IT8; k0 += CH) {
-        bool ok[CH]; long off[CH]; uint4 q[CH]; int rd[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int e = lane + 64 * (k0 + c);
-          const int rrow = e / VPR8, cc = (e - rrow * VPR8) * 8;
-          const int i = pass * GP + (rrow >> 4), rr = rrow & 15;
-          ok[c] = (k0 + c < IT8) && e < GP * 16 * VPR8 && n_wave + cc < a.N && rr < group_rows(i);
-          off[c] = voxel_off(group_m0(i) + rr) + n_wave + cc;
-          rd[c] = rrow * EROWF + cc;
-          q[c] = ok[c] ? *(const uint4*)((const bf16_t*)a.y + off[c]) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const float4 v0 = *(const float4*)&Ef[ok[c] ? rd[c] : 0], v1 = *(const float4*)&Ef[ok[c] ? rd[c] + 4 : 0];
-          const float vf[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          const uint32_t qw[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
-          uint32_t ow[4];
-#pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            const float lo = vf[2 * h] + __uint_as_float(qw[h] << 16);
-            const float hi = vf[2 * h + 1] + __uint_as_float(qw[h] & 0xffff0000u);
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(ow[h]) : "v"(lo), "v"(hi));
-          }
-          if (ok[c]) *(uint4*)((bf16_t*)a.y + off[c]) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        }
-      }
-      wave_lds_fence();
-    }
-  } else {
-  float sc[NT], sh[NT];
-  bool nok[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n_wave + j * 16 + (lane & 15);
-    nok[j] = n < a.Nw;
-    sc[j] = (a.out_scale && nok[j]) ? a.out_scale[n] : 1.f;
-    sh[j] = (a.out_shift && nok[j]) ? a.out_shift[n] : 0.f;
-  }
-  constexpr int VPR = WNC / 4;             // 4-channel vectors per tile row
-  constexpr int ITERS = (16 * VPR) / 64;   // store instructions per lane per row group
-  static_assert((16 * VPR) % 64 == 0, "row group must divide over the wave");
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int r = 0; r < 4; ++r) { ss[r] = row16_sum(ss[r]); qq[r] = row16_sum(qq[r]); }
+    if (p == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = group_m0(i) + (lane >> 4) * 4 + r;
-        const bool mok = (lane >> 4) * 4 + r < group_rows(i);
-        float av;
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av) : "a"(acc[i][j][r]));
-        const float v = fmaf(av, sc[j], sh[j]);
-        const float vs = (nok[j] && mok) ? v : 0.f;
-        s_sum[j] += vs; s_sq[j] += vs * vs;
-        float o = fmaxf(v, relu_floor);
-        if (sigm) o = 1.f / (1.f + __expf(-o));
-        Ew[((lane >> 4) * 4 + r) * EROW + j * 16 + (lane & 15)] = o;
+        const int col = wn * WNC + j * 16 + q * 4 + r;
+        red[(wm * BN + col) * 2 + 0] = ss[r];
+        red[(wm * BN + col) * 2 + 1] = qq[r];
       }
-    wave_lds_fence();
-    if (fast) {
+    }
+  };
+  bool rok[MT];                                        // is my voxel of row group i inside the iteration space
 #pragma unroll
-      for (int k = 0; k < ITERS; ++k) {
-        const int e = lane + 64 * k;
-        const int rr = e / VPR, cc = (e % VPR) * 4;
-        const int m = group_m0(i) + rr;
-        const bool mok = rr < group_rows(i);
-        const int n = n_wave + cc;
-        const float4 v = *(const float4*)&Ew[rr * EROW + cc];
-        if (mok && n < a.N)
-          *(uint2*)((bf16_t*)a.y + (long)m * a.ldy + n) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+  for (int i = 0; i < MT; ++i) rok[i] = p < group_rows(i);
+
+  const bool fast8 = a.vec_ok && !a.out_f32 && !sigm && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (a.sBy & 7) == 0 && (((uintptr_t)a.y) & 15) == 0;
+  if (fast8) {
+    // after the swap my 16 bytes are channels n8 .. n8 + 7 of voxel p in row group 2k + (q & 1)
+    constexpr int NP = MT / 2;
+    long voff[NP];
+    bool vok[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int ig = 2 * k + (q & 1);
+      vok[k] = p < group_rows(ig);
+      voff[k] = vok[k] ? voxel_off(group_m0(ig) + p) : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float sc[4], sh[4], ss[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
+      bool cok[4];
+      quad_consts(j, sc, sh, cok);
+      const int n8 = n_wave + j * 16 + (q >> 1) * 8;
+      const bool nok8 = n8 < a.N;
+      uint4 old[NP];
+      if (a.accumulate) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+          old[k] = (vok[k] && nok8) ? *(const uint4*)((const bf16_t*)a.y + voff[k] + n8) : make_uint4(0, 0, 0, 0);
       }
-    } else {
-      for (int e = lane; e < 16 * VPR; e += 64) {
-        const int rr = e / VPR, cc = (e % VPR) * 4;
-        const int m = group_m0(i) + rr;
-        const bool mok = rr < group_rows(i);
-        const int n = n_wave + cc;
-        if (mok && n < a.N) {
-          const float4 v = *(const float4*)&Ew[rr * EROW + cc];
-          long off;
-          if (a.y_linear) {
-            off = (long)m * a.ldy + n;
-          } else {
-            int b, to, ho, wo;
-            decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
-            off = (long)b * a.sBy +
-                  ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) * (long)a.ldy + n;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        float v0[4], v1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {      // explicit reads: the accumulator stays in the AGPR file until this very use
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v0[r]) : "a"(acc[2 * k][j][r]));
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v1[r]) : "a"(acc[2 * k + 1][j][r]));
+        }
+        if (has_aff) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v0[r] = fmaf(v0[r], sc[r], sh[r]); v1[r] = fmaf(v1[r], sc[r], sh[r]); }
+        }
+        if (do_stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float t0 = (rok[2 * k] && cok[r]) ? v0[r] : 0.f, t1 = (rok[2 * k + 1] && cok[r]) ? v1[r] : 0.f;
+            ss[r] += t0; qq[r] = fmaf(t0, t0, qq[r]);
+            ss[r] += t1; qq[r] = fmaf(t1, t1, qq[r]);
           }
-          float o[4] = {v.x, v.y, v.z, v.w};
-          if (a.vec_ok) {
-            if (a.out_f32) {
-              float* dst = (float*)a.y + off;
-              if (a.accumulate) { const float4 q = *(const float4*)dst; o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
-              *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-              bf16_t* dst = (bf16_t*)a.y + off;
-              if (a.accumulate) {
-                const uint2 q = *(const uint2*)dst;
-                o[0] += __uint_as_float(q.x << 16); o[1] += __uint_as_float(q.x & 0xffff0000u);
-                o[2] += __uint_as_float(q.y << 16); o[3] += __uint_as_float(q.y & 0xffff0000u);
-              }
-              *(uint2*)dst = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-            }
-          } else {
+        }
+        if (!a.accumulate) {
+          uint32_t x0 = cvt_pk_bf16_f32(v0[0], v0[1]), x1 = cvt_pk_bf16_f32(v0[2], v0[3]);
+          uint32_t y0 = cvt_pk_bf16_f32(v1[0], v1[1]), y1 = cvt_pk_bf16_f32(v1[2], v1[3]);
+          if (relu) { x0 = pk_relu_bf16(x0); x1 = pk_relu_bf16(x1); y0 = pk_relu_bf16(y0); y1 = pk_relu_bf16(y1); }
+          permlane16_swap(x0, y0);
+          permlane16_swap(x1, y1);
+          if (vok[k] && nok8) *(uint4*)((bf16_t*)a.y + voff[k] + n8) = make_uint4(x0, x1, y0, y1);
+        } else {
+          // y += result: ONE rounding, of old + new in fp32
 #pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) {
-              if (n + e2 < a.N) {
-                if (a.out_f32) {
-                  float* dst = (float*)a.y + off + e2;
-                  *dst = a.accumulate ? *dst + o[e2] : o[e2];
-                } else {
-                  bf16_t* dst = (bf16_t*)a.y + off + e2;
-                  *dst = f2bf(a.accumulate ? bf2f(*dst) + o[e2] : o[e2]);
+          for (int r = 0; r < 4; ++r) {
+            v0[r] = fmaxf(v0[r], relu_floor); v1[r] = fmaxf(v1[r], relu_floor);
+            permlane16_swap_f(v0[r], v1[r]);
+          }
+          const uint32_t ow[4] = {old[k].x, old[k].y, old[k].z, old[k].w};
+          uint32_t o[4];
+          o[0] = cvt_pk_bf16_f32(v0[0] + __uint_as_float(ow[0] << 16), v0[1] + __uint_as_float(ow[0] & 0xffff0000u));
+          o[1] = cvt_pk_bf16_f32(v0[2] + __uint_as_float(ow[1] << 16), v0[3] + __uint_as_float(ow[1] & 0xffff0000u));
+          o[2] = cvt_pk_bf16_f32(v1[0] + __uint_as_float(ow[2] << 16), v1[1] + __uint_as_float(ow[2] & 0xffff0000u));
+          o[3] = cvt_pk_bf16_f32(v1[2] + __uint_as_float(ow[3] << 16), v1[3] + __uint_as_float(ow[3] & 0xffff0000u));
+          if (vok[k] && nok8) *(uint4*)((bf16_t*)a.y + voff[k] + n8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+      if (do_stats) put_stats(j, ss, qq);
+      __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: hoisted accumulator reads of later tiles spill
+    }
+  } else {
+    // ---- general path: fp32 output, sigmoid, odd channel counts; one row group at a time through a wave-private LDS tile
+    // (statistics first, one column tile at a time: 8 running sums live instead of 8 per column tile beside the staging loop)
+    if (do_stats) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float sc[4], sh[4], ss[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
+        bool cok[4];
+        quad_consts(j, sc, sh, cok);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float av;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av) : "a"(acc[i][j][r]));
+            const float v = fmaf(av, sc[r], sh[r]);
+            const float vs = (cok[r] && rok[i]) ? v : 0.f;
+            ss[r] += vs; qq[r] += vs * vs;
+          }
+        put_stats(j, ss, qq);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const bool fast = a.vec_ok && !a.out_f32 && !a.accumulate && a.y_linear;
+    constexpr int VPR = WNC / 4;             // 4-channel vectors per tile row
+    constexpr int ITERS = (16 * VPR) / 64;   // store instructions per lane per row group
+    static_assert((16 * VPR) % 64 == 0, "row group must divide over the wave");
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float sc[4], sh[4], o[4];
+        bool cok[4];
+        quad_consts(j, sc, sh, cok);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float av;
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(av) : "a"(acc[i][j][r]));
+          const float v = fmaf(av, sc[r], sh[r]);
+          o[r] = fmaxf(v, relu_floor);
+          if (sigm) o[r] = 1.f / (1.f + __expf(-o[r]));
+        }
+        *(float4*)&Ew[p * EROW + j * 16 + q * 4] = make_float4(o[0], o[1], o[2], o[3]);
+      }
+      wave_lds_fence();
+      if (fast) {
+#pragma unroll
+        for (int k = 0; k < ITERS; ++k) {
+          const int e = lane + 64 * k;
+          const int rr = e / VPR, cc = (e % VPR) * 4;
+          const int m = group_m0(i) + rr;
+          const bool mok = rr < group_rows(i);
+          const int n = n_wave + cc;
+          const float4 v = *(const float4*)&Ew[rr * EROW + cc];
+          if (mok && n < a.N)
+            *(uint2*)((bf16_t*)a.y + (long)m * a.ldy + n) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+        }
+      } else {
+        for (int e = lane; e < 16 * VPR; e += 64) {
+          const int rr = e / VPR, cc = (e % VPR) * 4;
+          const int m = group_m0(i) + rr;
+          const bool mok = rr < group_rows(i);
+          const int n = n_wave + cc;
+          if (mok && n < a.N) {
+            const float4 v = *(const float4*)&Ew[rr * EROW + cc];
+            const long off = voxel_off(m) + n;
+            float o[4] = {v.x, v.y, v.z, v.w};
+            if (a.vec_ok) {
+              if (a.out_f32) {
+                float* dst = (float*)a.y + off;
+                if (a.accumulate) { const float4 q4 = *(const float4*)dst; o[0] += q4.x; o[1] += q4.y; o[2] += q4.z; o[3] += q4.w; }
+                *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+              } else {
+                bf16_t* dst = (bf16_t*)a.y + off;
+                if (a.accumulate) {
+                  const uint2 q2 = *(const uint2*)dst;
+                  o[0] += __uint_as_float(q2.x << 16); o[1] += __uint_as_float(q2.x & 0xffff0000u);
+                  o[2] += __uint_as_float(q2.y << 16); o[3] += __uint_as_float(q2.y & 0xffff0000u);
+                }
+                *(uint2*)dst = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+              }
+            } else {
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) {
+                if (n + e2 < a.N) {
+                  if (a.out_f32) {
+                    float* dst = (float*)a.y + off + e2;
+                    *dst = a.accumulate ? *dst + o[e2] : o[e2];
+                  } else {
+                    bf16_t* dst = (bf16_t*)a.y + off + e2;
+                    *dst = f2bf(a.accumulate ? bf2f(*dst) + o[e2] : o[e2]);
+                  }
                 }
               }
             }
           }
         }
       }
+      wave_lds_fence();   // all lanes have read this row group before the next one overwrites it
     }
-    wave_lds_fence();   // all lanes have read this row group before the next one overwrites it
   }
-
-  }   // (general path)
   if (do_stats) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float ss = s_sum[j], qq = s_sq[j];
-      ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
-      qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
-      if (lane < 16) {
-        const int col = wn * WNC + j * 16 + lane;
-        red[(wm * BN + col) * 2 + 0] = ss;
-        red[(wm * BN + col) * 2 + 1] = qq;
-      }
-    }
     __syncthreads();    // cross-wave hand-off of the per-wave column sums
     if (tid < BN) {
       const int n = tile_n * BN + tid;
@@ -543,7 +539,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // (weights as A: transposed tile, see conv_epilogue)
     } else {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
@@ -557,7 +553,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
     }
   };

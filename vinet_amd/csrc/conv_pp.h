@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < QM; ++i)
 #pragma unroll
-        for (int jj = 0; jj < QN; ++jj) mfma_bf16_acc(acc[h * QM + i][j * QN + jj], af[i][s], bf[jj][s]);
+        for (int jj = 0; jj < QN; ++jj) mfma_bf16_acc_t(acc[h * QM + i][j * QN + jj], af[i][s], bf[jj][s]);
     __builtin_amdgcn_s_setprio(0);
   };
 

@@ -62,6 +62,8 @@ class GraphedTrainStep:
         # attributes and autograd's own set-up), so everything they advance is snapshotted and put back: parameters, Adam
         # moments and step count, BatchNorm running statistics and the lazily counted num_batches_tracked.  A run that
         # builds the graph then follows the eager trajectory from the first user-visible step.
+        import gc
+        gc.collect()          # plans of models that died earlier leave the weight-pack registry now, not in the middle of the capture
         opt = self.opt
         snap_opt = [t.clone() for t in (opt.flat_p, opt.flat_m, opt.flat_v)] if hasattr(opt, "flat_p") else None
         snap_step = getattr(opt, "_step", None)
@@ -96,8 +98,16 @@ class GraphedTrainStep:
             import copy
             opt.load_state_dict(copy.deepcopy(snap_sd))
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_loss = self._body()
+        # (a garbage collection inside the capture could drop plans from the pack registry, whose job table would then be
+        # rebuilt -- a host-to-device copy -- in the captured region)
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.static_loss = self._body()
+        finally:
+            if was_enabled:
+                gc.enable()
 
     def _body(self):
         self.opt.zero_grad()
