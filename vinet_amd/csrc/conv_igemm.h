@@ -67,9 +67,9 @@ VN_DEV int conv_tile_perm(const ConvArgs& a, int i) {
 // LDS the epilogue needs behind a K loop (every kernel sizes its dynamic LDS with max(K loop, this))
 template <int MT, int NT, int WARPS_M, int WARPS_N>
 constexpr int conv_epi_bytes() {
-  constexpr int W = WARPS_M * WARPS_N, WNC = NT * 16, BN = WNC * WARPS_N, GP = MT < 4 ? MT : 4;
-  constexpr int general = W * 16 * (WNC + 4) * 4, fast8 = W * GP * 16 * (WNC + 8) * 2;
-  return (general > fast8 ? general : fast8) + WARPS_M * BN * 2 * 4;
+  constexpr int W = WARPS_M * WARPS_N, WNC = NT * 16, BN = WNC * WARPS_N;
+  // general path: one wave-private fp32 row group (the bf16 fast path stages nothing) + statistics table: 4 partial rows per wave row
+  return W * 16 * (WNC + 4) * 4 + 4 * WARPS_M * BN * 2 * 4;
 }
 
 template <typename T, int MT, int NT, int WARPS_M, int WARPS_N>
@@ -140,6 +140,12 @@ VN_DEV float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
   return v;
 }
+// the same after two rotations only: lane p holds the sum over lanes {p, p + 4, p + 8, p + 12} of its row
+VN_DEV float row16_sum4(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  return v;
+}
 VN_DEV uint32_t pk_relu_bf16(uint32_t u) {
   uint32_t r;
   asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(u));
@@ -156,7 +162,7 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   constexpr int WNC = NT * 16, EROW = WNC + 4;
   const int p = lane & 15, q = lane >> 4;              // my voxel inside a row group, my channel quad inside a column tile
   float* Ew = (float*)smem + wave * (16 * EROW);
-  float* red = (float*)(smem + conv_epi_bytes<MT, NT, WARPS_M, WARPS_N>() - WARPS_M * BN * 2 * 4);
+  float* red = (float*)(smem + conv_epi_bytes<MT, NT, WARPS_M, WARPS_N>() - 4 * WARPS_M * BN * 2 * 4);
   const int m_wave = tile_m * BM + wm * MT * 16;
   const int n_wave = tile_n * BN + wn * WNC;
   const bool do_stats = a.stats != nullptr;
@@ -186,22 +192,26 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     }
   };
   // my row's (voxel's) share of the statistics of column tile j -> the workgroup's reduction table
+  // (two DPP rotations leave lanes p = 0..3 of a row with four distinct partial sums: 4 partial rows per wave in the table,
+  //  added up by the last phase -- half the DPP adds of a full row reduction)
   auto put_stats = [&](int j, float (&ss)[4], float (&qq)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { ss[r] = row16_sum(ss[r]); qq[r] = row16_sum(qq[r]); }
-    if (p == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = wn * WNC + j * 16 + q * 4 + r;
-        red[(wm * BN + col) * 2 + 0] = ss[r];
-        red[(wm * BN + col) * 2 + 1] = qq[r];
-      }
+    for (int r = 0; r < 4; ++r) { ss[r] = row16_sum4(ss[r]); qq[r] = row16_sum4(qq[r]); }
+    if (p < 4) {
+      const int col = wn * WNC + j * 16 + q * 4;
+      float* dst = red + ((long)(wm * 4 + p) * BN + col) * 2;
+      *(float4*)dst = make_float4(ss[0], qq[0], ss[1], qq[1]);
+      *(float4*)(dst + 4) = make_float4(ss[2], qq[2], ss[3], qq[3]);
     }
   };
   bool rok[MT];                                        // is my voxel of row group i inside the iteration space
 #pragma unroll
   for (int i = 0; i < MT; ++i) rok[i] = p < group_rows(i);
 
+  // every row group of this wave and every column of its tile inside the iteration space (wave-uniform)?
+  bool all_in = n_wave + WNC <= a.Nw;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) all_in = all_in && group_rows(i) >= 16;
   const bool fast8 = a.vec_ok && !a.out_f32 && !sigm && (a.N & 7) == 0 && (a.ldy & 7) == 0 && (a.sBy & 7) == 0 && (((uintptr_t)a.y) & 15) == 0;
   if (fast8) {
     // after the swap my 16 bytes are channels n8 .. n8 + 7 of voxel p in row group 2k + (q & 1)
@@ -240,11 +250,19 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
           for (int r = 0; r < 4; ++r) { v0[r] = fmaf(v0[r], sc[r], sh[r]); v1[r] = fmaf(v1[r], sc[r], sh[r]); }
         }
         if (do_stats) {
+          if (all_in) {      // (wave-uniform: no masks)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float t0 = (rok[2 * k] && cok[r]) ? v0[r] : 0.f, t1 = (rok[2 * k + 1] && cok[r]) ? v1[r] : 0.f;
-            ss[r] += t0; qq[r] = fmaf(t0, t0, qq[r]);
-            ss[r] += t1; qq[r] = fmaf(t1, t1, qq[r]);
+            for (int r = 0; r < 4; ++r) {
+              ss[r] += v0[r]; qq[r] = fmaf(v0[r], v0[r], qq[r]);
+              ss[r] += v1[r]; qq[r] = fmaf(v1[r], v1[r], qq[r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float t0 = (rok[2 * k] && cok[r]) ? v0[r] : 0.f, t1 = (rok[2 * k + 1] && cok[r]) ? v1[r] : 0.f;
+              ss[r] += t0; qq[r] = fmaf(t0, t0, qq[r]);
+              ss[r] += t1; qq[r] = fmaf(t1, t1, qq[r]);
+            }
           }
         }
         if (!a.accumulate) {
@@ -381,7 +399,7 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
       if (n < a.N) {
         float ss = 0.f, qq = 0.f;
 #pragma unroll
-        for (int w2 = 0; w2 < WARPS_M; ++w2) { ss += red[(w2 * BN + tid) * 2]; qq += red[(w2 * BN + tid) * 2 + 1]; }
+        for (int w2 = 0; w2 < 4 * WARPS_M; ++w2) { ss += red[(w2 * BN + tid) * 2]; qq += red[(w2 * BN + tid) * 2 + 1]; }
         a.stats[((long)tile_m * 2 + 0) * a.N + n] = ss;
         a.stats[((long)tile_m * 2 + 1) * a.N + n] = qq;
       }
