@@ -74,7 +74,12 @@ def _tot(agg, name):
 
 
 step_traffic = int((2 * _tot(fe, "FETCH_SIZE") + _tot(wr, "WRITE_SIZE")) * 1024 / 2)
-json.dump(dict(source="profiles/%s_pmc_summary.json" % tag, batch=batch, step_traffic_bytes=step_traffic, kernels=short),
+import subprocess
+try:
+    build = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+except OSError:
+    build = None
+json.dump(dict(source="profiles/%s_pmc_summary.json" % tag, build=build, batch=batch, step_traffic_bytes=step_traffic, kernels=short),
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("step traffic %.1f GB" % (step_traffic / 1e9))
 for r in rows[:14]:
