@@ -683,7 +683,9 @@ def test_graphed_train_step_follows_the_eager_trajectory():
                      int(m.state_dict()["backbone.base1.0.bn_s.num_batches_tracked"]))
     (le, pe, re_, ne), (lg, pg, rg, ng) = res["eager"], res["graph"]
     assert abs(le[0] - lg[0]) < 1e-4 and abs(le[1] - lg[1]) < 2e-3, (le, lg)
-    assert float((pe - pg).abs().max()) < 3e-4          # two Adam steps of lr 1e-4 move a weight by <= 2e-4
+    # Adam moves a weight by ~lr per step whatever the gradient's size: where bf16 round-off (atomics order) flips the sign of a
+    # vanishing gradient, two steps of lr 1e-4 put the runs up to 4e-4 apart -- on a handful of weights, not on average
+    assert float((pe - pg).abs().max()) < 4.2e-4 and float((pe - pg).abs().mean()) < 2e-5
     assert torch.allclose(re_, rg, rtol=1e-3, atol=1e-6) and ne == ng == 2
 
 

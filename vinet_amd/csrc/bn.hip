@@ -183,6 +183,80 @@ __global__ __launch_bounds__(256) void channel_reduce8_kernel(TView x, TView dz,
     }
   }
 }
+// Register-lean bf16 form of channel_reduce8_kernel<bf16_t, 1> (round 3).  The generic form unpacks its 4 x 2 loads of
+// 16 bytes into 64 floats before it uses them: 170 VGPRs, two waves per SIMD -- and ONE beside a resident weight-gradient
+// workgroup (the persistent wgrad kernels of the second stream hold 2 x 168...254 of a SIMD's 512 registers), which is why
+// BatchNorm backward ran at 2.7 TB/s inside the step against 5.0 alone.  Here the loads stay packed (4 registers each) until
+// the voxel is consumed; same arithmetic, same order of operations per lane, same partials contract.
+template <int U>
+__global__ __launch_bounds__(256) void bn_bwd_reduce8_bf16_kernel(TView x, TView dz, Affine fwd, const float* mean,
+                                                                  const float* invstd, long nvox, long vb,
+                                                                  float* __restrict__ partials) {
+  const int G = x.C / 8;
+  const int Gb = G < 256 ? G : 256;
+  const int R = 256 / Gb;
+  const int r = threadIdx.x / Gb;
+  const int g0 = threadIdx.x % Gb;
+  __shared__ float red[256 * 16];
+  const long v0 = vb ? (long)blockIdx.x * vb : (long)blockIdx.x * R * U;
+  long v1 = vb ? v0 + vb : nvox; if (v1 > nvox) v1 = nvox;
+  const long vstep = vb ? (long)R * U : (long)gridDim.x * R * U;
+  const bool relu = fwd.relu != 0;
+  for (int g = g0; g < G; g += Gb) {
+    float s[8], p[8], mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; p[e] = 0.f; mu[e] = 0.f; is[e] = 1.f; sc[e] = 1.f; sh[e] = 0.f; }
+    if (r < R) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { mu[e] = mean[g * 8 + e]; is[e] = invstd[g * 8 + e]; }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = fwd.scale ? fwd.scale[g * 8 + e] : 1.f; sh[e] = fwd.shift ? fwd.shift[g * 8 + e] : 0.f; }
+      }
+      for (long vq = v0 + r; vq < v1; vq += vstep) {
+        uint4 xr[U], gr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long v = vq + (long)u * R;
+          const long vc = v < v1 ? v : vq;                 // clamped: the load is unconditional, the use is not
+          xr[u] = *(const uint4*)((const bf16_t*)x.p + vox_lin(x, vc) + g * 8);
+          gr[u] = *(const uint4*)((const bf16_t*)dz.p + vox_lin(dz, vc) + g * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (vq + (long)u * R >= v1) continue;
+          const uint32_t xw[4] = {xr[u].x, xr[u].y, xr[u].z, xr[u].w}, gw[4] = {gr[u].x, gr[u].y, gr[u].z, gr[u].w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xv = __uint_as_float((e & 1) ? (xw[e >> 1] & 0xffff0000u) : (xw[e >> 1] << 16));
+            float gg = __uint_as_float((e & 1) ? (gw[e >> 1] & 0xffff0000u) : (gw[e >> 1] << 16));
+            if (relu && !(fmaf(xv, sc[e], sh[e]) > 0.f)) gg = 0.f;
+            s[e] += gg;
+            p[e] += gg * (xv - mu[e]) * is[e];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (r < R) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = s[e]; red[threadIdx.x * 16 + 8 + e] = p[e]; }
+    }
+    __syncthreads();
+    if (r == 0) {
+      for (int rr = 1; rr < R; ++rr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += red[(rr * Gb + g0) * 16 + e]; p[e] += red[(rr * Gb + g0) * 16 + 8 + e]; }
+      float* o = partials + (long)blockIdx.x * 2 * x.C + g * 8;
+      *(float4*)o = make_float4(s[0], s[1], s[2], s[3]);
+      *(float4*)(o + 4) = make_float4(s[4], s[5], s[6], s[7]);
+      *(float4*)(o + x.C) = make_float4(p[0], p[1], p[2], p[3]);
+      *(float4*)(o + x.C + 4) = make_float4(p[4], p[5], p[6], p[7]);
+    }
+  }
+}
+int g_vinet_opt_bn_lean = 1;    // register-lean bf16 BatchNorm-backward kernels (0 = the generic 8-channel forms)
+
 static inline int stats_rows_for(long nvox) {
   long rows = (nvox + 63) / 64;
   if (rows > 1024) rows = 1024;
@@ -269,6 +343,15 @@ static int launch_channel_reduce(const VinetTensor* x, const VinetTensor* dz, in
   const int rows = stats_rows_for(nvox);
   const long vb = (nvox + rows - 1) / rows;
   const TView xv = make_view(*x), dv = dz ? make_view(*dz) : xv;
+  if (MODE == 1 && g_vinet_opt_bn_lean && dtype == VINET_BF16 && dz && oct_ok(*x) && oct_ok(*dz)) {
+    if (g_vinet_opt_bn_lean == 2)
+      hipLaunchKernelGGL(bn_bwd_reduce8_bf16_kernel<2>, dim3(rows), dim3(256), 0, (hipStream_t)stream, xv, dv, make_affine(fwd), mean,
+                         invstd, nvox, g_vinet_opt_reduce_il ? 0 : vb, partials);
+    else
+      hipLaunchKernelGGL(bn_bwd_reduce8_bf16_kernel<4>, dim3(rows), dim3(256), 0, (hipStream_t)stream, xv, dv, make_affine(fwd), mean,
+                         invstd, nvox, g_vinet_opt_reduce_il ? 0 : vb, partials);
+    return vn_launch_status("bn_bwd_reduce8_bf16");
+  }
   if (oct_ok(*x) && (!dz || oct_ok(*dz))) {
     DISPATCH_T(dtype, T, hipLaunchKernelGGL((channel_reduce8_kernel<T, MODE>), dim3(rows), dim3(256), 0,
                                             (hipStream_t)stream, xv, dv, make_affine(fwd), mean, invstd, nvox, g_vinet_opt_reduce_il ? 0 : vb, partials);)
@@ -405,6 +488,61 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(TView dz, TView x, A
   }
 }
 
+// register-lean bf16 form of bn_bwd_apply8_kernel (162 VGPRs there): packed loads, one voxel unpacked at a time
+template <int U>
+__global__ __launch_bounds__(256) void bn_bwd_apply8_bf16_kernel(TView dz, TView x, Affine fwd, const float* mean, const float* invstd,
+                                                                 const float* c1, const float* c2, TView dx, long nvox, long vb) {
+  const int G = x.C / 8;
+  const int Gb = G < 256 ? G : 256;
+  const int R = 256 / Gb;
+  const int r = threadIdx.x / Gb;
+  const int g0 = threadIdx.x % Gb;
+  if (r >= R) return;
+  const long v0 = (long)blockIdx.x * vb;
+  long v1 = v0 + vb; if (v1 > nvox) v1 = nvox;
+  const bool relu = fwd.relu != 0;
+  for (int g = g0; g < G; g += Gb) {
+    float A[8], Bc[8], D[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = g * 8 + e;
+      const float sc = fwd.scale[c], k = sc * invstd[c] * c2[c];
+      A[e] = sc; Bc[e] = -k; D[e] = fmaf(k, mean[c], -sc * c1[c]);
+      sh[e] = fwd.shift[c];
+    }
+    for (long vq = v0 + r; vq < v1; vq += (long)R * U) {
+      uint4 xr[U], gr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long v = vq + (long)u * R;
+        const long vc = v < v1 ? v : vq;
+        xr[u] = *(const uint4*)((const bf16_t*)x.p + vox_lin(x, vc) + g * 8);
+        gr[u] = *(const uint4*)((const bf16_t*)dz.p + vox_lin(dz, vc) + g * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (vq + (long)u * R >= v1) continue;
+        const uint32_t xw[4] = {xr[u].x, xr[u].y, xr[u].z, xr[u].w}, gw[4] = {gr[u].x, gr[u].y, gr[u].z, gr[u].w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          float o2[2];
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const int e = 2 * h + k2;
+            const float xv = __uint_as_float(k2 ? (xw[h] & 0xffff0000u) : (xw[h] << 16));
+            float gg = __uint_as_float(k2 ? (gw[h] & 0xffff0000u) : (gw[h] << 16));
+            if (relu && !(fmaf(xv, A[e], sh[e]) > 0.f)) gg = 0.f;
+            o2[k2] = fmaf(A[e], gg, fmaf(Bc[e], xv, D[e]));
+          }
+          ow[h] = pack2bf(o2[0], o2[1]);
+        }
+        *(uint4*)((bf16_t*)dx.p + vox_lin(dx, vq + (long)u * R) + g * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+      }
+    }
+  }
+}
+
 extern "C" int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,
                                   const float* mean, const float* invstd, const float* c1, const float* c2,
                                   const VinetTensor* dx, void* stream) {
@@ -416,6 +554,15 @@ extern "C" int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_ra
     const int G = dz->C / 8, R = 256 / (G < 256 ? G : 256);
     long vb = R * 16;                                  // 4 rounds of 4 voxels per lane
     while ((nvox + vb - 1) / vb > 16384) vb *= 2;
+    if (g_vinet_opt_bn_lean && dtype == VINET_BF16) {
+      if (g_vinet_opt_bn_lean == 2)
+        hipLaunchKernelGGL(bn_bwd_apply8_bf16_kernel<2>, dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, (hipStream_t)stream,
+                           make_view(*dz), make_view(*x_raw), make_affine(fwd), mean, invstd, c1, c2, make_view(*dx), nvox, vb);
+      else
+        hipLaunchKernelGGL(bn_bwd_apply8_bf16_kernel<4>, dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, (hipStream_t)stream,
+                           make_view(*dz), make_view(*x_raw), make_affine(fwd), mean, invstd, c1, c2, make_view(*dx), nvox, vb);
+      return vn_launch_status("bn_bwd_apply8_bf16");
+    }
     DISPATCH_T(dtype, T, hipLaunchKernelGGL(bn_bwd_apply8_kernel<T>, dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0,
                                             (hipStream_t)stream, make_view(*dz), make_view(*x_raw), make_affine(fwd), mean,
                                             invstd, c1, c2, make_view(*dx), nvox, vb);)

@@ -148,6 +148,7 @@ extern int g_vinet_opt_wgrad_hs;
 extern int g_vinet_opt_wgrad_rs;
 extern int g_vinet_opt_wgrad_tf;
 extern int g_vinet_opt_wgrad_skinny;
+extern int g_vinet_opt_bn_lean;
 
 extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   if (!d) return -1;
@@ -216,6 +217,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
   if (name && !strcmp(name, "ht")) { g_vinet_opt_ht = value; return 0; }
   if (name && !strcmp(name, "ht32")) { g_vinet_opt_ht32 = value; return 0; }
+  if (name && !strcmp(name, "bn_lean")) { g_vinet_opt_bn_lean = value; return 0; }
   if (name && !strcmp(name, "ht_minhw")) { g_vinet_opt_ht_minhw = value; return 0; }
   if (name && !strcmp(name, "ht_t")) { g_vinet_opt_ht_t = value; return 0; }
   if (name && !strcmp(name, "ht_pre")) { g_vinet_opt_ht_pre = value; return 0; }
