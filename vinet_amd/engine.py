@@ -44,6 +44,8 @@ WGRAD_SIDE_STREAM = True
 # without a second stream they are alone on the GPU and get all of it
 WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "160"))
 _WGRAD_CUS_SET = {}
+# weight-gradient streams the jobs are dealt over round robin (1 = one side stream)
+N_SIDE_STREAMS = int(os.environ.get("VINET_SIDE_STREAMS", "1"))
 _SIDE_STREAMS = {}
 
 
@@ -101,6 +103,14 @@ SHARE_SKIP_GRAD = os.environ.get("VINET_SHARE_SKIP_GRAD", "1") != "0"
 DEFER_DECODER_WGRAD = int(os.environ.get("VINET_DEFER_DECODER_WGRAD", "1"))
 # packed weight-gradient workspaces owned by the conv plans and re-zeroed by vinet_unpack_wgrad (0 = a torch.zeros per conv and step)
 PERSISTENT_DW = int(os.environ.get("VINET_PERSISTENT_DW", "1"))
+
+
+# VINET_ABLATE="vinet_conv3d_wgrad,vinet_bn_bwd_reduce,tag:dgrad": entry points (or call-site tags) whose launches are skipped -- how much
+# of the step does a kernel family really cost once the overlap of the two streams is taken into account (tools/ablate.sh)
+_ABLATE = set(a for a in os.environ.get("VINET_ABLATE", "").split(",") if a and not a.startswith("tag:"))
+_ABLATE_TAGS = [a[4:] for a in os.environ.get("VINET_ABLATE", "").split(",") if a.startswith("tag:")]
+if _ABLATE_TAGS:
+    _ABLATE.add("\0tags")
 
 
 def set_profiler(p):
@@ -273,6 +283,8 @@ class Ctx:
         return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.device)
 
     def call(self, name, *args, tag=None, work=None):
+        if _ABLATE and (name in _ABLATE or (tag is not None and any(a in tag for a in _ABLATE_TAGS))):
+            return          # tuning only (VINET_ABLATE): the launch is skipped, results are garbage, the step time is the point
         prof = PROFILER
         if prof is not None and self.device.type == "cuda" and prof.want(tag or name):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -289,14 +301,20 @@ class Ctx:
         if self.tape is not None:
             self.tape.append(fn)
 
-    def side_stream(self):
-        """second stream of this device (None on the CPU test double)"""
+    def side_stream(self, k=0):
+        """k-th weight-gradient stream of this device (None on the CPU test double)"""
         if not WGRAD_SIDE_STREAM or self.device.type != "cuda":
             return None
-        st = _SIDE_STREAMS.get(self.device.index)
+        st = _SIDE_STREAMS.get((self.device.index, k))
         if st is None:
-            st = _SIDE_STREAMS[self.device.index] = torch.cuda.Stream(self.device)
+            st = _SIDE_STREAMS[(self.device.index, k)] = torch.cuda.Stream(self.device)
         return st
+
+    def side_streams(self):
+        """every weight-gradient stream in use (N_SIDE_STREAMS of them; empty without a GPU)"""
+        if self.side_stream() is None:
+            return []
+        return [self.side_stream(k) for k in range(N_SIDE_STREAMS)]
 
     def keep(self, *tensors):
         """hold tensors that a side-stream kernel reads or writes until run_backward has joined the streams: the caching
@@ -322,7 +340,8 @@ class Ctx:
         self.flush_deferred()
         if getattr(self, "side_used", False):
             # the optimizer (and every buffer release that follows) is ordered after the side stream
-            torch.cuda.current_stream(self.device).wait_stream(self.side_stream())
+            for st in self.side_streams():
+                torch.cuda.current_stream(self.device).wait_stream(st)
         self._side_keep = []
         self.tape = []
 
@@ -1037,7 +1056,8 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             _param_grad(w_)          # (allocated on the main stream, not inside the side-stream context)
 
         def wgrad_job():
-            side = ctx.side_stream()
+            ctx._side_rr = (getattr(ctx, "_side_rr", -1) + 1) % N_SIDE_STREAMS
+            side = ctx.side_stream(ctx._side_rr)
             main_ptr = ctx.stream
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(ctx.device))   # dy (and everything before it) is ready

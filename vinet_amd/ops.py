@@ -80,7 +80,8 @@ def _standalone_backward(x, dy, weight, stride, padding, want_dx, want_dw):
     E._conv_backward(ctx, plan, xa, res, None, L.ACT_NONE, False, {}, M)
     ctx.flush_deferred()
     if getattr(ctx, "side_used", False):
-        torch.cuda.current_stream(ctx.device).wait_stream(ctx.side_stream())
+        for st in ctx.side_streams():
+            torch.cuda.current_stream(ctx.device).wait_stream(st)
     dx = None
     if want_dx:
         g = xa.grad_view()

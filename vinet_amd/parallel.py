@@ -202,8 +202,7 @@ class GradientBuckets:
             if comm is None:
                 comm = self._comm_streams[dev.index] = torch.cuda.Stream(dev)
             comm.wait_stream(torch.cuda.current_stream(dev))              # BatchNorm / bias gradients and everything before them
-            side = ctx.side_stream() if ctx is not None else None
-            if side is not None:
+            for side in (ctx.side_streams() if ctx is not None else []):
                 comm.wait_stream(side)                                    # the weight-gradient kernels launched so far
             with torch.cuda.stream(comm):
                 self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
