@@ -567,7 +567,9 @@ def test_single_rank_rccl_runs_every_collective_of_the_n_gpu_path(tmp_path):
     assert "error" not in r, r
     dg = float((r["bucketed_g"] - r["flat_g"]).abs().max() / (r["flat_g"].abs().max() + 1e-30))
     dp = float((r["bucketed_p"] - r["flat_p"]).abs().max() / (r["flat_p"].abs().max() + 1e-30))
-    assert dg < 1e-6 and dp < 1e-5, (dg, dp)       # (two runs: the weight-gradient atomics order their fp32 sums differently)
+    # (two runs: the weight-gradient atomics order their fp32 sums differently; where that flips the sign of a vanishing
+    #  gradient, Adam's step of lr = 1e-4 puts one weight 2e-4 apart -- relative to max |p| ~ 3 that is < 1e-4)
+    assert dg < 1e-6 and dp < 1e-4, (dg, dp)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VINET_FORCE_COLLECTIVES="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port + 1 if port < 65000 else port - 1), HSA_ENABLE_IPC_MODE_LEGACY="0")

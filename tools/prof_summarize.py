@@ -64,6 +64,12 @@ for r in rows:
     k = k.replace("conv_wgrad_pp_kernel<plain,3>", "conv_wgrad_pp_kernel<plain,192>").replace("conv_wgrad_pp_kernel<plain,4>", "conv_wgrad_pp_kernel<plain,256>")
     k = re.sub(r"^channel_reduce8_kernel<\w+,1>$", "vinet_bn_bwd_reduce", k)
     k = re.sub(r"^bn_bwd_apply8_kernel<\w+>$", "vinet_bn_bwd_apply", k)
+    # row-streaming weight gradients: the library names them by image width (vinet_conv3d_wgrad_kernel_name)
+    k = {"conv_wgrad_rsm_kernel<3,48>": "conv_wgrad_rs_kernel<W48>", "conv_wgrad_rsm_kernel<3,24>": "conv_wgrad_rs_kernel<W24>",
+         "conv_wgrad_rs_kernel<3>": "conv_wgrad_rs_kernel<W96>", "conv_wgrad_rs_kernel<6>": "conv_wgrad_rs_kernel<W192>",
+         "conv_wgrad_rs_kernel<2>": "conv_wgrad_rs_kernel<W64>", "conv_wgrad_rs_kernel<1>": "conv_wgrad_rs_kernel<W32>"}.get(k, k)
+    k = re.sub(r"^bn_bwd_reduce8_bf16_kernel<\d+>$", "vinet_bn_bwd_reduce", k)
+    k = re.sub(r"^bn_bwd_apply8_bf16_kernel<\d+>$", "vinet_bn_bwd_apply", k)
     m = re.match(r"conv_wgrad_dma_kernel<(\d+),(\d+),(\d+),(\d+),(\w+)>", k)
     if m:
         k = "conv_wgrad_dma_kernel<%s,%s,%s,%s>" % (m[1], m[2], m[3], m[5])
