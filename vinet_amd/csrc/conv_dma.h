@@ -245,11 +245,18 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
+      {
+        // (transposed tiles, conv_epilogue: a lane holds 4 consecutive columns of one row -> one 16-byte store where it can)
+        const int m = m_wave + i * 16 + (lane & 15), n = n_wave + j * 16 + (lane >> 4) * 4;
+        float* dst = a.ws + ((long)blockIdx.y * a.M + m) * a.N + n;
+        if (m < a.M && n + 3 < a.N && (a.N & 3) == 0) {
+          *(float4*)dst = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        } else if (m < a.M) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m_wave + i * 16 + (lane & 15), n = n_wave + j * 16 + (lane >> 4) * 4 + r;   // (transposed tiles: conv_epilogue)
-          if (m < a.M && n < a.N) a.ws[((long)blockIdx.y * a.M + m) * a.N + n] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) dst[r] = acc[i][j][r];
         }
+      }
     return;
   }
   conv_epilogue<MT, NT, WARPS_M, WARPS_N>(a, acc, smem, tile_m, tile_n);
