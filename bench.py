@@ -415,13 +415,16 @@ def measure(args, rank, world, dev):
         from vinet_amd.graph import GraphedTrainStep
         sweep, sweep_eager = {}, {}
         import gc
+        gc.collect()
+        torch.cuda.empty_cache()      # the headline's 200 GB of cached blocks: a smaller batch must not have to fight them for memory
         for b in SWEEP_BATCHES:
             if b >= B:
                 continue
             xs = x[:b].contiguous()
             ins = (xs, inputs[1][:b].contiguous()) if av else (xs,)
             gs = gt[:b].contiguous()
-            train_step(ins, gs)
+            for _ in range(2):        # (two warm-up steps: the allocator's block set of this batch size is complete after the second)
+                train_step(ins, gs)
             torch.cuda.synchronize()
             t0s = time.perf_counter()
             for _ in range(args.sweep_steps):

@@ -221,6 +221,12 @@ int vinet_pack_weights_multi(const int64_t* table, int32_t njobs, int64_t total,
  * meets vinet_conv3d_wgrad's "zero on entry" contract at the next step without a fill launch. */
 int vinet_unpack_wgrad(float* dw, int32_t N, int32_t Cin, int32_t ntaps, int32_t stem, int32_t flags,
                        float* grad, void* stream);
+/* Multi-tensor vinet_unpack_wgrad: the weight gradients of a whole backward pass (train.py:216; 84 Conv3d weights of
+ * ViNet-32, model.py / model_utils.py) handed to their `.grad` tensors in one launch.  `table` is DEVICE memory:
+ * (njobs + 1) rows of 8 int64 { dw (packed fp32), grad (torch layout fp32), N, Cin, ntaps, stem, first PACKED index, 0 },
+ * the last row carrying only the total number of packed elements in its prefix field (a job has nsl * N * Kp of them:
+ * nsl = 7 / Kp = 32 for the stem, ntaps / rup(Cin, 32) otherwise).  `flags` as vinet_unpack_wgrad, for every job. */
+int vinet_unpack_wgrad_multi(const int64_t* table, int32_t njobs, int64_t total, int32_t flags, void* stream);
 
 /* ------------------------------------------------------------------------
  * Layout / dtype conversion at the module boundary.

@@ -351,6 +351,14 @@ class AbiEmulator:
             D[:, :N, :] = 0
         return 0
 
+    def vinet_unpack_wgrad_multi(self, table, njobs, total, flags, stream):
+        tab = np.ctypeslib.as_array((C.c_int64 * (8 * (njobs + 1))).from_address(table)).reshape(njobs + 1, 8)
+        assert int(tab[njobs, 6]) == total
+        for j in range(njobs):
+            dw, grad, N, Cin, ntaps, stem = (int(v) for v in tab[j, :6])
+            self.vinet_unpack_wgrad(dw, N, Cin, ntaps, stem, flags, grad, stream)
+        return 0
+
     # -- layout ----------------------------------------------------------------
     def vinet_import_ncdhw(self, src, sb, sc, st, sh, sw, Cc, dst, dst_dtype, stream):
         dst = _deref(dst)

@@ -906,6 +906,21 @@ def test_pack_unpack(dt):
         gs = Pair(torch.zeros(64 * 3 * 49))
         run_both("vinet_unpack_wgrad", lambda s: [dws.ptr(s), 64, 3, 49, 1, 0, gs.ptr(s), _stream() if s == "gpu" else 0])
         _cmp(gs.get("gpu"), gs.get("cpu"), 1e-6, "unpack stem")
+        # both jobs in one launch (vinet_unpack_wgrad_multi): accumulate + hand the workspaces back zeroed
+        dw2, dws2 = Pair(_rand("udw2", (nt * N * 32,), 6)), Pair(_rand("udws2", (7 * 64 * 32,), 7))
+        g2, gs2 = Pair(_rand("ug2", (N * Cin * nt,), 8)), Pair(_rand("ugs2", (64 * 3 * 49,), 9))
+
+        def table(s):
+            rows = [[dw2.ptr(s), g2.ptr(s), N, Cin, nt, 0, 0, 0], [dws2.ptr(s), gs2.ptr(s), 64, 3, 49, 1, nt * N * 32, 0],
+                    [0, 0, 0, 0, 0, 0, nt * N * 32 + 7 * 64 * 32, 0]]
+            t = torch.tensor(rows, dtype=torch.int64)
+            return t.cuda() if s == "gpu" else t
+        tabs = {}
+        run_both("vinet_unpack_wgrad_multi", lambda s: [tabs.setdefault(s, table(s)).data_ptr(), 2, nt * N * 32 + 7 * 64 * 32, 3, _stream() if s == "gpu" else 0])
+        _cmp(g2.get("gpu"), g2.get("cpu"), 1e-6, "multi unpack")
+        _cmp(gs2.get("gpu"), gs2.get("cpu"), 1e-6, "multi unpack stem")
+        assert float(dw2.get("gpu").abs().max()) == 0.0 and float(dws2.get("gpu").abs().max()) == 0.0
+        assert float(dw2.get("cpu").abs().max()) == 0.0 and float(dws2.get("cpu").abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dt", DTS)

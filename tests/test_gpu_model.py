@@ -660,7 +660,7 @@ def test_graphed_train_step_follows_the_eager_trajectory():
     x = synth.clip(B, T, H, W, 3).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
     gt = synth.gt_map(B, H, W, 3).to(DEV)
     res = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "eager2", "graph"):
         m = VM.VideoSaliencyModel(num_clips=T)
         m.load_state_dict(synth.synth_state_dict(m.state_dict(), 3))
         m = m.to(DEV).train()
@@ -685,9 +685,11 @@ def test_graphed_train_step_follows_the_eager_trajectory():
                      int(m.state_dict()["backbone.base1.0.bn_s.num_batches_tracked"]))
     (le, pe, re_, ne), (lg, pg, rg, ng) = res["eager"], res["graph"]
     assert abs(le[0] - lg[0]) < 1e-4 and abs(le[1] - lg[1]) < 2e-3, (le, lg)
-    # Adam moves a weight by ~lr per step whatever the gradient's size: where bf16 round-off (atomics order) flips the sign of a
-    # vanishing gradient, two steps of lr 1e-4 put the runs up to 4e-4 apart -- on a handful of weights, not on average
-    assert float((pe - pg).abs().max()) < 4.2e-4 and float((pe - pg).abs().mean()) < 2e-5
+    # Adam moves a weight by ~lr per step whatever the gradient's size: where bf16 round-off (the order of the weight-gradient
+    # atomics) flips the sign of a vanishing gradient, two steps of lr 1e-4 put two runs up to 4e-4 apart.  The yardstick is
+    # therefore a SECOND EAGER run: the graphed run must be no further from the eager one than eager runs are from each other.
+    noise = float((pe - res["eager2"][1]).abs().mean())
+    assert float((pe - pg).abs().max()) < 4.2e-4 and float((pe - pg).abs().mean()) <= 1.5 * noise + 5e-6, (noise, float((pe - pg).abs().mean()))
     assert torch.allclose(re_, rg, rtol=1e-3, atol=1e-6) and ne == ng == 2
 
 

@@ -102,6 +102,7 @@ SIGNATURES = {
     "vinet_gt_preprocess": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
     "vinet_set_option": [C.c_char_p, _i32],
     "vinet_pack_weights_multi": [_vp, _i32, _i64, _i32, _vp],
+    "vinet_unpack_wgrad_multi": [_vp, _i32, _i64, _i32, _vp],
     "vinet_fill_f32": [_vp, _i64, _f32, _vp],
     "vinet_abi_version": [],
     "vinet_last_error": [],

@@ -132,6 +132,47 @@ extern "C" int vinet_unpack_wgrad(float* dw, int32_t N, int32_t Cin, int32_t nta
   return vn_launch_status("unpack_wgrad");
 }
 
+// every weight gradient of a backward pass in ONE launch (84 vinet_unpack_wgrad launches per ViNet-32 step otherwise): the
+// threads walk the PACKED elements of all jobs, so transfer and hand-back-zeroed are one loop
+__global__ __launch_bounds__(256) void unpack_wgrad_multi_kernel(const long* __restrict__ table, int njobs, long total, int flags) {
+  const int accumulate = flags & 1, clear = flags & 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = njobs;               // last job with prefix <= i
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (table[mid * 8 + 6] <= i) lo = mid; else hi = mid;
+    }
+    const long* J = table + lo * 8;
+    float* dw = (float*)J[0];
+    float* grad = (float*)J[1];
+    const int N = (int)J[2], Cin = (int)J[3], ntaps = (int)J[4], stem = (int)J[5];
+    const long e = i - J[6];
+    const int Kp = stem ? 32 : (Cin + 31) / 32 * 32;
+    const int k = (int)(e % Kp);
+    const int n = (int)((e / Kp) % N);
+    const int sl = (int)(e / ((long)Kp * N));
+    long dst = -1;
+    if (stem) {
+      const int kw = k >> 2, c = k & 3;
+      if (kw < 7 && c < Cin) dst = ((long)n * Cin + c) * ntaps + sl * 7 + kw;
+    } else if (k < Cin) {
+      dst = ((long)n * Cin + k) * ntaps + sl;
+    }
+    if (dst >= 0) {
+      const float v = dw[e];
+      grad[dst] = accumulate ? grad[dst] + v : v;
+    }
+    if (clear) dw[e] = 0.f;
+  }
+}
+
+extern "C" int vinet_unpack_wgrad_multi(const int64_t* table, int32_t njobs, int64_t total, int32_t flags, void* stream) {
+  VN_CHECK_ARG(table && njobs > 0 && total > 0, "unpack_wgrad_multi: bad arguments");
+  int grid = ew_grid(total); if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(unpack_wgrad_multi_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long*)table, njobs, (long)total, flags);
+  return vn_launch_status("unpack_wgrad_multi");
+}
+
 // ============================================================================
 // NCDHW <-> channels-last
 // ============================================================================

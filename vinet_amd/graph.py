@@ -108,6 +108,8 @@ class GraphedTrainStep:
         finally:
             if was_enabled:
                 gc.enable()
+        for bn, pend in snap_pend:           # (the captured call ran the Python forward once: its host-side step count does not count)
+            bn.__dict__["_vinet_pending"] = pend
 
     def _body(self):
         self.opt.zero_grad()

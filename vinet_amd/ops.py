@@ -76,9 +76,10 @@ def _standalone_backward(x, dy, weight, stride, padding, want_dx, want_dw):
     res = E.Act(_view(dy))
     res._grad, res.grad_ready = res.v, True
     M = dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3]
-    ctx._deferred, ctx._side_keep, ctx.side_used = [], [], False
+    ctx._deferred, ctx._side_keep, ctx.side_used, ctx._unpack_jobs = [], [], False, []
     E._conv_backward(ctx, plan, xa, res, None, L.ACT_NONE, False, {}, M)
     ctx.flush_deferred()
+    ctx.flush_unpack()
     if getattr(ctx, "side_used", False):
         for st in ctx.side_streams():
             torch.cuda.current_stream(ctx.device).wait_stream(st)
