@@ -713,3 +713,37 @@ def test_bench_self_spawn_path(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode == 2 and "GPU(s) visible" in bad.stderr, (bad.returncode, bad.stderr[-500:])
     _note("bench_self_spawn", dict(clips_per_s=line["value"], refused_gpus=too_many))
+
+
+def test_weight_gradient_stream_does_not_change_the_gradients():
+    """The second HIP stream (weight gradients beside the data-gradient chain, decoder jobs deferred to the encoder's backward,
+    one multi-job unpack at the end) is a schedule, not arithmetic: the gradients must equal those of the one-stream, per-conv
+    schedule (the accumulation order of the fp32 atomics is the only freedom)."""
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    from vinet_amd import optim as VO
+    E.set_default_dtype("bf16")
+    B, T, H, W = 2, 16, 64, 96
+    x = synth.clip(B, T, H, W, 9).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
+    gt = synth.gt_map(B, H, W, 9).to(DEV)
+    grads = {}
+    saved = (E.WGRAD_SIDE_STREAM, E.DEFER_DECODER_WGRAD, E.MULTI_UNPACK)
+    try:
+        for name, (side, defer, multi) in dict(two_streams=(True, 1, 1), one_stream=(False, 0, 0), two_streams_in_order=(True, 0, 0)).items():
+            E.WGRAD_SIDE_STREAM, E.DEFER_DECODER_WGRAD, E.MULTI_UNPACK = side, defer, multi
+            m = VM.VideoSaliencyModel(num_clips=T)
+            m.load_state_dict(synth.synth_state_dict(m.state_dict(), 9))
+            m = m.to(DEV).train()
+            opt = VO.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+            for _ in range(2):          # (the second pass runs with every cache warm and the persistent workspaces handed back zeroed)
+                opt.zero_grad()
+                VL.kldiv(m(x), gt).backward()
+            torch.cuda.synchronize()
+            grads[name] = opt.flat_g.clone()
+    finally:
+        E.WGRAD_SIDE_STREAM, E.DEFER_DECODER_WGRAD, E.MULTI_UNPACK = saved
+    ref = grads["one_stream"]
+    for name in ("two_streams", "two_streams_in_order"):
+        rel = float((grads[name] - ref).norm() / ref.norm())
+        assert rel < 1e-5, "%s: gradients differ from the one-stream schedule by %.3e" % (name, rel)
+    _note("wgrad_stream_equivalence", {k: float((v - ref).norm() / ref.norm()) for k, v in grads.items()})

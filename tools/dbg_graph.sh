@@ -1,1 +1,1 @@
-for e in "X=1" "NO_SIDE=1" "VINET_SHARE_SKIP_GRAD=0" "VINET_JOINT_ENTRY=0" "VINET_DEFER_DECODER_WGRAD=0" "VINET_PERSISTENT_DW=0" "VINET_BN_BWD_FUSE=0" "VINET_MULTI_UNPACK=0" "VINET_OPT=bn_lean=0"; do echo "== $e"; env $e SHOW=0 python tools/dbg_graph.py 2>&1 | grep -E "grad diff|parameters differ"; done
+for c in 1024 832 480 192 64 32; do echo "== defer only Cin=$c"; VINET_DBG_DEFER_IN_CAPTURE=$c SHOW=0 python tools/dbg_graph.py 2>&1 | grep -E "parameters differ"; done

@@ -1117,9 +1117,10 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                 try:
                     kp = plan.kp(False)
                     nsl = 7 if plan.stem else plan.ntaps
-                    # persistent workspace, handed back zeroed by the unpack kernel; a channel-padded head (rows past
-                    # plan.N are never unpacked) takes a fresh zero-filled one
-                    persistent = PERSISTENT_DW and Ny == plan.N
+                    # persistent workspace, handed back zeroed by the unpack kernel
+                    # (a channel-padded head -- rows past plan.N are never unpacked, so whatever accumulates there over the steps is
+                    #  never read -- keeps a persistent workspace too: no allocation and no fill on the weight-gradient stream)
+                    persistent = bool(PERSISTENT_DW)
                     dw = plan.dw_workspace(ctx, nsl * Ny * kp) if persistent else ctx.f32(nsl * Ny * kp, zero=True)
                     wd = _wgrad_desc(ctx, plan, x, dy, dw)
                     if fused_bnb is not None:
@@ -1153,7 +1154,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         # stream, without deferral, and with the deferred jobs flushed at the END of backward).  Eager execution of the same
         # launch order is bit-stable and passes the gradient parity tests, so the captured graph's cross-stream edges are
         # what differs; until that is understood a captured step launches its weight gradients in tape order.
-        if DEFER_DECODER_WGRAD and bn is None and ctx.side_stream() is not None and not ctx.capturing:
+        if DEFER_DECODER_WGRAD and bn is None and ctx.side_stream() is not None and (not ctx.capturing or os.environ.get("VINET_DBG_DEFER_IN_CAPTURE") in ("1", str(plan.Cin))):
             ctx._deferred.append(wgrad_job)
         else:
             ctx.flush_deferred()
