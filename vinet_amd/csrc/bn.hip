@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void channel_reduce8_kernel(TView x, TView dz,
 // workgroup (the persistent wgrad kernels of the second stream hold 2 x 168...254 of a SIMD's 512 registers), which is why
 // BatchNorm backward ran at 2.7 TB/s inside the step against 5.0 alone.  Here the loads stay packed (4 registers each) until
 // the voxel is consumed; same arithmetic, same order of operations per lane, same partials contract.
-template <int U>
-__global__ __launch_bounds__(256) void bn_bwd_reduce8_bf16_kernel(TView x, TView dz, Affine fwd, const float* mean,
+template <int U, int WPE>
+__global__ __launch_bounds__(256, WPE) void bn_bwd_reduce8_bf16_kernel(TView x, TView dz, Affine fwd, const float* mean,
                                                                   const float* invstd, long nvox, long vb,
                                                                   float* __restrict__ partials) {
   const int G = x.C / 8;
@@ -345,10 +345,10 @@ static int launch_channel_reduce(const VinetTensor* x, const VinetTensor* dz, in
   const TView xv = make_view(*x), dv = dz ? make_view(*dz) : xv;
   if (MODE == 1 && g_vinet_opt_bn_lean && dtype == VINET_BF16 && dz && oct_ok(*x) && oct_ok(*dz)) {
     if (g_vinet_opt_bn_lean == 2)
-      hipLaunchKernelGGL(bn_bwd_reduce8_bf16_kernel<2>, dim3(rows), dim3(256), 0, (hipStream_t)stream, xv, dv, make_affine(fwd), mean,
+      hipLaunchKernelGGL((bn_bwd_reduce8_bf16_kernel<2, 6>), dim3(rows), dim3(256), 0, (hipStream_t)stream, xv, dv, make_affine(fwd), mean,
                          invstd, nvox, g_vinet_opt_reduce_il ? 0 : vb, partials);
     else
-      hipLaunchKernelGGL(bn_bwd_reduce8_bf16_kernel<4>, dim3(rows), dim3(256), 0, (hipStream_t)stream, xv, dv, make_affine(fwd), mean,
+      hipLaunchKernelGGL((bn_bwd_reduce8_bf16_kernel<4, 4>), dim3(rows), dim3(256), 0, (hipStream_t)stream, xv, dv, make_affine(fwd), mean,
                          invstd, nvox, g_vinet_opt_reduce_il ? 0 : vb, partials);
     return vn_launch_status("bn_bwd_reduce8_bf16");
   }
@@ -489,8 +489,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(TView dz, TView x, A
 }
 
 // register-lean bf16 form of bn_bwd_apply8_kernel (162 VGPRs there): packed loads, one voxel unpacked at a time
-template <int U>
-__global__ __launch_bounds__(256) void bn_bwd_apply8_bf16_kernel(TView dz, TView x, Affine fwd, const float* mean, const float* invstd,
+template <int U, int WPE>
+__global__ __launch_bounds__(256, WPE) void bn_bwd_apply8_bf16_kernel(TView dz, TView x, Affine fwd, const float* mean, const float* invstd,
                                                                  const float* c1, const float* c2, TView dx, long nvox, long vb) {
   const int G = x.C / 8;
   const int Gb = G < 256 ? G : 256;
@@ -556,10 +556,10 @@ extern "C" int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_ra
     while ((nvox + vb - 1) / vb > 16384) vb *= 2;
     if (g_vinet_opt_bn_lean && dtype == VINET_BF16) {
       if (g_vinet_opt_bn_lean == 2)
-        hipLaunchKernelGGL(bn_bwd_apply8_bf16_kernel<2>, dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((bn_bwd_apply8_bf16_kernel<2, 6>), dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, (hipStream_t)stream,
                            make_view(*dz), make_view(*x_raw), make_affine(fwd), mean, invstd, c1, c2, make_view(*dx), nvox, vb);
       else
-        hipLaunchKernelGGL(bn_bwd_apply8_bf16_kernel<4>, dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((bn_bwd_apply8_bf16_kernel<4, 4>), dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, (hipStream_t)stream,
                            make_view(*dz), make_view(*x_raw), make_affine(fwd), mean, invstd, c1, c2, make_view(*dx), nvox, vb);
       return vn_launch_status("bn_bwd_apply8_bf16");
     }
