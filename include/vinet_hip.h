@@ -127,6 +127,9 @@ typedef struct VinetConvDesc {
                            taps of equal dt are contiguous in the table (ConvPlan.fwd_taps order and every stride phase of
                            its data gradient): lets plain-input layers take the halo-tile kernel (conv_ht.h), which
                            stages the activation patch once per (dt, 64 channels) instead of once per tap.
+                           6 = pointwise: ntaps == 1 and the tap is (0, 0, 0, slice 0) (a 1x1x1 / stride-1 conv or its data
+                           gradient): lets large problems take the wave-streaming kernel (conv_pw.h), which keeps the
+                           weight tile in LDS and feeds the activations to the matrix cores straight from registers.
                            0 = no promise. */
   int32_t tpad;
 } VinetConvDesc;

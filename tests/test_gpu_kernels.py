@@ -283,6 +283,40 @@ def test_conv3d_halo_tile(case, mfma32):
         lib.vinet_set_option(b"ht32", 0)
 
 
+# the pointwise streaming kernel (conv_pw.h), forced on small grids: 32- / 64- / 96-column weight tiles with padded and partial
+# column tiles (N = 176, 288, 40), 1 / 2 / 6 / 8 / 9 K steps with a channel tail inside the last one (Cin = 176, 40), row tails,
+# pending BatchNorm + ReLU (NaN-page padding), statistics (one row per workgroup), affine / ReLU epilogue,
+# channel- and T-sliced views on both sides, and two grids large enough that every wave walks several tiles (ring across tiles)
+PW_CASES = [
+    ("pw_256_288_pre_stats", (2, 4, 14, 24), 256, 288, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(pre=True, stats=True)),
+    ("pw_288_256", (2, 3, 7, 9), 288, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), {}),
+    ("pw_64_64_relu", (2, 3, 7, 9), 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(stats=True, act=1, epi=True)),
+    ("pw_192_176_slices", (2, 2, 6, 8), 192, 176, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(pre=True, stats=True, in_ld=368, in_coff=112,
+                                                                                   out_ld=480, out_coff=32)),
+    ("pw_cin176_relu", (1, 3, 9, 11), 176, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(act=1)),
+    ("pw_cin40_n40_pre", (1, 2, 9, 7), 40, 40, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(pre=True, stats=True)),
+    ("pw_32_32", (2, 1, 8, 12), 32, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(epi_shift=True)),
+    ("pw_tslices", (2, 3, 5, 7), 64, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(in_ttotal=5, in_toff=1, out_ttotal=4, out_toff=1, stats=True)),
+    ("pw_many_tiles_k8", (2, 8, 56, 96), 256, 288, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(pre=True, stats=True)),
+    ("pw_many_tiles_k2", (3, 8, 56, 96), 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(epi=True)),
+    ("pw_many_tiles_k1", (3, 8, 56, 96), 32, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(stats=True, act=1)),
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=[c[0] for c in PW_CASES])
+def test_conv3d_pointwise_stream(case):
+    lib = _lib()
+    assert lib.vinet_set_option(b"pw", 2) == 0
+    try:
+        ex = dict(case[7])
+        ex["tline"] = 6
+        d0 = _run_conv_case(case[:7] + (ex,), E.BF16, forced=True)
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_pw_kernel<"), buf.value
+    finally:
+        lib.vinet_set_option(b"pw", 1)
+
+
 # split-K (grids too small for the chip): long-K decoder shape, placement through a concat slice, padded fp32
 # head, a T-sliced input, a pending affine, a chunk count that does not divide over the splits
 SPLITK_CASES = [
@@ -421,7 +455,8 @@ def _run_conv_case(case, dt, forced=False, want_y=False):
     Ny = (E.EG[dt] if head else N)
     odt = E.F32 if ex.get("out_f32") else dt
     omT, ooT = ex.get("om", (1, 0))
-    yp, ymk = view_pair(B, oT * omT, oH, oW, Ny, odt, "y" + name, 2, ld=ex.get("out_ld"), c_off=ex.get("out_coff", 0))
+    yp, ymk = view_pair(B, oT * omT, oH, oW, Ny, odt, "y" + name, 2, ld=ex.get("out_ld"), c_off=ex.get("out_coff", 0),
+                        t_total=ex.get("out_ttotal"), t_off=ex.get("out_toff", 0))
     Kp = E.rup(Cin, 32)
     ntaps = k[0] * k[1] * k[2]
     wmaster = _rand("w" + name, (N, Cin, ntaps), 3, 1.0 / math.sqrt(Cin * ntaps))
@@ -470,7 +505,8 @@ def _run_conv_case(case, dt, forced=False, want_y=False):
         bm = _lib().vinet_conv3d_tile_m(C.byref(d0))
         assert forced or bm == AbiEmulator().vinet_conv3d_tile_m(d0)
         r = _lib().vinet_conv3d_stats_rows(C.byref(d0))
-        assert r >= (M + bm - 1) // bm and (forced or r == AbiEmulator().vinet_conv3d_stats_rows(d0))
+        assert (r >= (M + bm - 1) // bm or ex.get("tline") == 6) and (forced or r == AbiEmulator().vinet_conv3d_stats_rows(d0))   # (pointwise: one row per workgroup)
+        assert r <= rows
         rc = AbiEmulator().vinet_conv3d_stats_rows(d0)
         sg = stats.get("gpu")[:r * 2 * N].view(r, 2, N).double().sum(0)
         sc = stats.get("cpu")[:rc * 2 * N].view(rc, 2, N).double().sum(0)
@@ -1489,6 +1525,8 @@ def _exact_targets():
         if not c[7].get("out_f32"):
             t.append(("halo32-" + c[0], test_conv3d_halo_tile, dict(case=c, mfma32=1)))
             t.append(("halo16-" + c[0], test_conv3d_halo_tile, dict(case=c, mfma32=0)))
+    for c in PW_CASES:
+        t.append(("pw-" + c[0], test_conv3d_pointwise_stream, dict(case=c)))
     for ksp in [(7, 2, 3), (3, 2, 1), (5, 3, 2)]:
         for acc in (0, 1):
             t.append(("tsd-k%ds%dp%d-acc%d" % (ksp + (acc,)), test_conv3d_tstream_dgrad_fused, dict(ksp=ksp, acc=acc)))

@@ -56,6 +56,18 @@ SITES = [
     ("3c b2 32->96 1x3x3", 8, 16, 28, 48, 32, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("dec5 64->32 2x3x3/2", 8, 4, 112, 192, 64, 32, (2, 3, 3), (2, 1, 1), (0, 1, 1)),
     ("dg dec5 32->64 /ph", 8, 2, 112, 192, 32, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    # more pointwise layers and their data gradients (--pw)
+    ("3b entry 192->176 pw", 8, 16, 28, 48, 192, 176, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("3b dg 176->192 pw", 8, 16, 28, 48, 176, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("2b 64->64 pw", 8, 16, 56, 96, 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("3c b3 256->64 pw", 8, 16, 28, 48, 256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("3c b3 dg 64->256 pw", 8, 16, 28, 48, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("3b b3 192->32 pw", 8, 16, 28, 48, 192, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("3b b3 dg 32->192 pw", 8, 16, 28, 48, 32, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("4b entry 480->304 pw", 8, 8, 14, 24, 480, 304, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("4b dg 304->480 pw", 8, 8, 14, 24, 304, 480, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("4c b3 512->64 pw", 8, 8, 14, 24, 512, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("4c b3 dg 64->512 pw", 8, 8, 14, 24, 64, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
 ]
 
 
@@ -78,6 +90,7 @@ def main():
     ap.add_argument("--stats", action="store_true", help="forward convs also write BN statistics partials (training epilogue)")
     ap.add_argument("--only", default="", help="substring filter on site names")
     ap.add_argument("--ht", action="store_true", help="A/B of the halo-tile kernel (conv_ht.h) against the default dispatch on the 3x3-spatial sites")
+    ap.add_argument("--pw", action="store_true", help="A/B of the pointwise streaming kernel (conv_pw.h) against the default dispatch on the 1x1x1 sites")
     ap.add_argument("--default", action="store_true", help="one variant per library: its own dispatch, no option overrides (A/B of two builds)")
     ap.add_argument("--acc", action="store_true", help="accumulate into y (the epilogue of a data gradient that joins an existing gradient)")
     args = ap.parse_args()
@@ -97,6 +110,13 @@ def main():
     if args.default:
         for ln, lib in libs:
             variants.append((ln + ":default", lib, dict(), False))
+        libs = []
+    if args.pw:
+        for ln, lib in libs:
+            variants.append((ln + ":default", lib, dict(pw=0), False))
+            variants.append((ln + ":pw", lib, dict(pw=2, pw_maxtn=99), False))
+            variants.append((ln + ":default+pre", lib, dict(pw=0), True))
+            variants.append((ln + ":pw+pre", lib, dict(pw=2, pw_maxtn=99), True))
         libs = []
     if args.ht:
         for ln, lib in libs:
@@ -121,6 +141,8 @@ def main():
     print("%-26s" % "site" + "".join("%22s" % (v[0][-21:].replace("libvinet_hip", "")) for v in variants) + "   (ms | TF/s)")
     for (name, B, T, H, W, Cin, N, k, s, p) in SITES:
         if args.only and args.only not in name:
+            continue
+        if args.pw and k != (1, 1, 1):
             continue
         if args.ht and not ((k[1:] == (3, 3) and W % 16 == 0) or (k == (3, 1, 1) and (H * W) % 16 == 0)):
             continue
@@ -153,7 +175,9 @@ def main():
                 d.stats = stats.data_ptr()
             if args.acc:
                 d.accumulate = 1
-            if k[1:] == (3, 3):
+            if k == (1, 1, 1):
+                d.tline = 6
+            elif k[1:] == (3, 3):
                 d.tline = 5
             elif k[1:] == (1, 1) and k[0] > 1:
                 d.tline, d.tpad = 1, p[0]

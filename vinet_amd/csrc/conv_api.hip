@@ -133,7 +133,10 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
 
 static bool use_pp(const VinetConvDesc* d);
 static bool use_ht(const VinetConvDesc* d);
+static bool use_pw(const VinetConvDesc* d);
 struct HtShape { int nt, tw, tm, pre; };
+struct PwShape { int nt, tilesN, gm, tpw; };
+static PwShape pw_shape(const VinetConvDesc* d);
 static HtShape ht_shape(const VinetConvDesc* d);
 extern int g_vinet_opt_ht, g_vinet_opt_ht32, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
 bool vinet_conv_use_ts(const VinetConvDesc* d);
@@ -163,6 +166,7 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
 extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
   if (!d) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_pw(d)) return pw_shape(d).gm;   // one row per persistent workgroup
   if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_ht(d)) {
     const HtShape h = ht_shape(d);
     if (h.tm) return (int)((long)d->x.B * vn_div_up(d->oT, 4) * vn_div_up((long)d->oH * d->oW, 64));
@@ -173,6 +177,8 @@ extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
 }
 
 int g_vinet_opt_dma = 1;
+int g_vinet_opt_pw_maxtn = 4;   // pointwise kernel: at most this many column tiles (each re-reads x)
+int g_vinet_opt_pw = 1;        // pointwise streaming kernel (conv_pw.h) for 1x1x1 convs and their data gradients (2 = also on small grids: tests)
 extern int g_vinet_opt_splitk;
 int g_vinet_opt_n64_tile = 0;   // tuning: 64-wide layers on 128x64 (1) or 64x64 (2) tiles instead of 256x64
 int g_vinet_opt_pool_blk = 1;   // 1x3x3/s(1,2,2) max-pool backward per 2x2 input block
@@ -201,6 +207,8 @@ int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad
 
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
+  if (name && !strcmp(name, "pw")) { g_vinet_opt_pw = value; return 0; }
+  if (name && !strcmp(name, "pw_maxtn")) { g_vinet_opt_pw_maxtn = value; return 0; }
   if (name && !strcmp(name, "pool_blk")) { g_vinet_opt_pool_blk = value; return 0; }
   if (name && !strcmp(name, "up_blk")) { g_vinet_opt_up_blk = value; return 0; }
   if (name && !strcmp(name, "n128_tile")) { g_vinet_opt_n128_tile = value; return 0; }
@@ -244,6 +252,53 @@ static bool use_dma(const VinetConvDesc* d) {
   const bool pre_ok = !d->pre.scale || (d->pre.relu && d->pre.shift && d->Kp <= 1024);
   return g_vinet_opt_dma && d->dtype == VINET_BF16 && d->mode == VINET_CONV_GENERIC && pre_ok &&
          !(d->pre.relu && !d->pre.scale);
+}
+
+// conv_pw.h: the caller promises (tline == 6) a single tap (0, 0, 0, slice 0); unit strides, dense placement, bf16 in and out,
+// channel counts in whole 16-byte groups, a weight tile (32 / 64 / 96 columns x Kp) that leaves room for two workgroups per CU
+static PwShape pw_shape(const VinetConvDesc* d) {
+  PwShape h;
+  const int N = d->y.C;
+  const long lds_max = 80 * 1024;      // two workgroups per CU
+  auto fits = [&](int nt) {            // ConvPwCfg<nt>::smem_bytes
+    return (long)nt * 16 * (d->Kp * 2 + 16) + 2L * nt * 16 * 4 + (d->pre.scale ? 2L * d->Kp * 4 : 0) + 4L * nt * 16 * 8 + 4L * 32 * nt * 16 * 2 <= lds_max;
+  };
+  int best = 0, bestpad = 1 << 30;
+  const int nts[3] = {6, 4, 2};
+  for (int i = 0; i < 3; ++i) {
+    if (!fits(nts[i])) continue;
+    const int bn = nts[i] * 16, pad = (N + bn - 1) / bn * bn;
+    if (pad < bestpad) { bestpad = pad; best = nts[i]; }
+  }
+  h.nt = best;
+  h.tilesN = best ? (N + best * 16 - 1) / (best * 16) : 0;
+  const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  const long nwt = (M + 63) / 64;
+  // tiles per wave: at least ~8 workgroups per CU-slot in the grid (the dispatcher balances them over whatever the second
+  // stream leaves free), at most 16 (the weight tile is staged once per 4 x 16 tiles = 4096 rows: under 5 % of the row traffic)
+  long tpw = best ? nwt / (4L * 4096 / h.tilesN) : 1;
+  tpw = tpw < 1 ? 1 : (tpw > 16 ? 16 : tpw);
+  h.tpw = (int)tpw;
+  const long gm = (nwt + 4 * tpw - 1) / (4 * tpw);
+  h.gm = (int)(gm < 1 ? 1 : gm);
+  return h;
+}
+static bool use_pw(const VinetConvDesc* d) {
+  if (!g_vinet_opt_pw || !use_dma(d) || d->tline != 6 || d->ntaps != 1) return false;
+  if (d->sT != 1 || d->sH != 1 || d->sW != 1 || d->omT != 1 || d->omH != 1 || d->omW != 1 || d->ooT || d->ooH || d->ooW) return false;
+  if (d->oT != d->x.T || d->oH != d->x.H || d->oW != d->x.W || d->y.T != d->oT || d->y.H != d->oH || d->y.W != d->oW) return false;
+  if (d->out_dtype != VINET_BF16 || (d->act != VINET_ACT_NONE && d->act != VINET_ACT_RELU) || d->accumulate) return false;
+  if (d->y.C % 8 || d->y.ld % 8 || d->y.sB % 8 || ((uintptr_t)d->y.ptr) % 16 || d->x.sB % 8) return false;
+  const PwShape h = pw_shape(d);
+  if (!h.nt) return false;
+  if (g_vinet_opt_pw >= 2) return true;
+  // a grid that cannot fill the chip stays with conv_dma (which splits its K loop over workgroups there).  Every column tile
+  // re-reads x (from L2 at best): measured at 192 clips (tools/conv_ab.py --pw, profiles/r3_pw_ab.txt) the kernel wins with up
+  // to four column tiles at Cin <= 288 (256 -> 288: 1.58 -> 1.48 ms plain, 1.86 -> 1.51 with a pending affine; 192 -> 176:
+  // 0.90 -> 0.82; 64 -> 64: 0.87 -> 0.79 = the HBM roofline) and with any number of tiles at Cin <= 64 (64 -> 512: 0.22 -> 0.16),
+  // and loses where a 512-channel input leaves room for a 32- / 64-column weight tile only (512 -> 256: 0.24 -> 0.53)
+  const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  return M >= 64L * 2048 && d->Kp <= 320 && (h.tilesN <= g_vinet_opt_pw_maxtn || d->Kp <= 64);
 }
 
 // tile width of the ping-pong kernel: 256 or 192, whichever pads N less (ties: 256)
@@ -333,7 +388,7 @@ int g_vinet_opt_splitk = 1;     // 0 = off; n >= 2 = tuning: minimum K chunks (o
 struct SplitK { int splits, per; long bytes; };
 static SplitK splitk_plan(const VinetConvDesc* d) {
   SplitK p{1, 0, 0};
-  if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || use_ht(d) || vinet_conv_use_ts(d) || vinet_conv_use_hs(d) || d->stats || d->accumulate) return p;
+  if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || use_ht(d) || use_pw(d) || vinet_conv_use_ts(d) || vinet_conv_use_hs(d) || d->stats || d->accumulate) return p;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const int nchunks = d->ntaps * (d->Kp / 32);
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, nchunks);
@@ -390,6 +445,7 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   if (d->tline == 3) snprintf(buf, n, vinet_conv_use_tsd(d) ? "conv_tsd_kernel" : "(unsupported)");
   else if (vinet_conv_use_hs(d)) snprintf(buf, n, "conv_hs_kernel");
   else if (vinet_conv_use_ts(d)) snprintf(buf, n, "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
+  else if (use_pw(d)) snprintf(buf, n, "conv_pw_kernel<%d,%s>", pw_shape(d).nt * 16, d->pre.scale ? "pre" : "plain");
   else if (use_ht(d)) {
     const HtShape h = ht_shape(d);
     if (h.tm) snprintf(buf, n, "conv_ht_kernel<%d,t,%s>", h.nt * 16, h.pre ? "pre" : "plain");
@@ -420,6 +476,13 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
   if (rc) return rc;
   if (vinet_conv_use_hs(d)) return vinet_launch_conv_hs(d, (hipStream_t)stream);
   if (vinet_conv_use_ts(d)) return vinet_launch_conv_ts(d, (hipStream_t)stream);
+  if (use_pw(d)) {
+    const PwShape h = pw_shape(d);
+    a.tilesN = h.tilesN;
+    a.tilesM = h.gm;
+    a.chunks_per_split = h.tpw;
+    return vinet_launch_conv_pw_bf16(h.nt, a, (hipStream_t)stream);
+  }
   if (use_ht(d)) {
     const HtShape h = ht_shape(d);
     a.tilesN = vn_div_up(a.N, h.nt * 16);

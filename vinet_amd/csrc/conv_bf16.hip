@@ -3,6 +3,7 @@
 #include "conv_pp.h"
 #include "conv_ht.h"
 #include "conv_ht32.h"
+#include "conv_pw.h"
 
 #define CASE(MT_, NT_, WM_, WN_)                                                            \
   if (t.MT == MT_ && t.NT == NT_ && t.WM == WM_ && t.WN == WN_)                             \
@@ -75,5 +76,15 @@ int vinet_launch_conv_ht_bf16(int nt, int tw, int tm, int pre, const ConvArgs& a
     if (nt == 6) return launch_conv_ht_cfg<6, 16, 3>(a, s);
   }
   vinet_set_error("conv ht bf16: no kernel for nt=%d tw=%d tm=%d pre=%d", nt, tw, tm, pre);
+  return -1;
+}
+
+// pointwise streaming kernel (conv_pw.h): nt = 16-column tiles of the resident weight tile
+int vinet_launch_conv_pw_bf16(int nt, const ConvArgs& a, hipStream_t s) {
+  const bool pre = a.in_scale != nullptr;
+  if (nt == 2) return pre ? launch_conv_pw_cfg<2, true>(a, s) : launch_conv_pw_cfg<2, false>(a, s);
+  if (nt == 4) return pre ? launch_conv_pw_cfg<4, true>(a, s) : launch_conv_pw_cfg<4, false>(a, s);
+  if (nt == 6) return pre ? launch_conv_pw_cfg<6, true>(a, s) : launch_conv_pw_cfg<6, false>(a, s);
+  vinet_set_error("conv pw bf16: no kernel for nt=%d", nt);
   return -1;
 }

@@ -603,6 +603,7 @@ int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStr
 int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_pp_bf16(int bn, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_ht_bf16(int nt, int tw, int tm, int pre, const ConvArgs& a, hipStream_t s);
+int vinet_launch_conv_pw_bf16(int nt, const ConvArgs& a, hipStream_t s);
 
 template <typename T, int MT, int NT, int WM, int WN, int MODE>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {

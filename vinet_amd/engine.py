@@ -531,6 +531,8 @@ class ConvPlan:
         # 3 x 3 spatial footprint, unit spatial stride, "same" padding: fwd_taps (kt-major) and every stride phase of the data
         # gradient keep |dh|, |dw| <= 1 with equal-dt taps contiguous -- the promise behind VinetConvDesc::tline == 5
         self.spatial3 = (not stem) and self.k[1:] == (3, 3) and self.p[1:] == (1, 1) and self.s[1:] == (1, 1)
+        # 1x1x1, unit stride, no padding: forward and data gradient are one tap (0, 0, 0, slice 0) -- VinetConvDesc::tline == 6
+        self.pointwise = (not stem) and self.k == (1, 1, 1) and self.s == (1, 1, 1) and self.p == (0, 0, 0)
         if stem:
             assert self.k == (1, 7, 7) and self.Cin == 3 and self.p[2] == 3
         self._packs = {}
@@ -594,6 +596,9 @@ class ConvPlan:
                 assert all(abs(r_[1]) <= 1 and abs(r_[2]) <= 1 for r_ in rows) and dts == sorted(dts, key=dts.index)
                 assert all(dts[i] == dts[i - 1] or dts[i] not in dts[:i] for i in range(1, len(dts))), "equal-dt taps must be contiguous"
                 tl = 5
+            if self.pointwise:
+                assert rows == [(0, 0, 0, 0)]
+                tl = 6
             phases.append(dict(taps=self._dev_taps(key, rows, device), ntaps=len(rows), Q=(QT, QH, QW), r=(rT, rH, rW),
                                tline=tl, tpad=-offs[0] if tline else 0))
         covered = all(len(p_) == min(s, I) for p_, s, I in zip(per, self.s, in_dims))
@@ -687,6 +692,7 @@ class JointConvPlan(ConvPlan):
         self.k, self.s, self.p = (1, 1, 1), (1, 1, 1), (0, 0, 0)
         self.N, self.Cin, self.ntaps, self.stem = sum(m.N for m in members), m0.Cin, 1, False
         self.temporal = self.spatial3 = False
+        self.pointwise = True
         self._packs, self._taps, self._dw_ws = {}, {}, {}
 
     def grad_targets(self):
@@ -935,7 +941,9 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     d.pre = x.affine()
     d.accumulate = 0
     d.n_valid = plan.N if Ny != plan.N else 0
-    if not folded and not plan.stem and plan.temporal:
+    if plan.pointwise:
+        d.tline = 6                         # the single tap (0, 0, 0, slice 0)
+    elif not folded and not plan.stem and plan.temporal:
         d.tline, d.tpad = 1, plan.p[0]      # promise to the library (it cannot read the device-side tap table)
     elif folded:
         d.tline = 2                         # taps (0, kh, 0, kh): ConvPlan.folded_taps

@@ -184,17 +184,19 @@ class _Mixed(_Block):
         r1, r2, cat = big.region(0, b1r), big.region(b1r, R), big.region(R, R + b0 + b1 + b2 + b3)
         entry = big.sub_chan(0, R + b0)
         entry.ready_of = [r1, r2, cat]
+        o1, o2, o3 = b0, b0 + b1, b0 + b1 + b2
+        # the pool branch FIRST: backward then reaches the entry conv before the pool, so the entry conv's data gradient is the
+        # first writer of x.grad (a plain store: the pointwise streaming kernel, conv_pw.h) and the pool backward accumulates
+        pooled = E.maxpool_forward(ctx, x, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        self.branch3[1]._fwd(ctx, pooled, cat.sub_chan(o3, o3 + b3))
         mods, jp, jbn = self._entry()
         E.conv_forward(ctx, jp, x, bn=jbn, act=L.ACT_RELU, dst=entry)
         if ctx.training:
             for m in mods:
                 m.bn.note_training_step()
             self.__dict__["_vinet_joint_fold"].clear()
-        o1, o2, o3 = b0, b0 + b1, b0 + b1 + b2
         self.branch1[1]._fwd(ctx, r1, cat.sub_chan(o1, o2))
         self.branch2[1]._fwd(ctx, r2, cat.sub_chan(o2, o3))
-        pooled = E.maxpool_forward(ctx, x, (3, 3, 3), (1, 1, 1), (1, 1, 1))
-        self.branch3[1]._fwd(ctx, pooled, cat.sub_chan(o3, o3 + b3))
         return cat
 
     def _fwd(self, ctx, x, dst=None):
