@@ -317,6 +317,28 @@ def test_conv3d_pointwise_stream(case):
         lib.vinet_set_option(b"pw", 1)
 
 
+# conv epilogue option epi_rows = 1 (whole-row stores through a wave-private LDS image, conv_igemm.h): off by default (measured
+# neutral to slower), kept working: row tails, channel tails (N = 48, 208, 80), channel-sliced outputs, stride-phase placement
+# (non-linear row offsets), spatial and temporal halo tiles, statistics
+EPI_ROWS_CASES = [c for c in CONV_CASES if c[0] in ("pw_pre_stats", "tm_3x1", "concat_slice_out", "phase_store", "big_m", "xslice_pw")]
+EPI_ROWS_HT = [c for c in HT_CASES if c[0] in ("ht_64_192", "ht_cin160_n80", "ht_slices", "ht_phase_store", "htt_192", "htt_pre_cin160")]
+
+
+@pytest.mark.parametrize("case", EPI_ROWS_CASES + EPI_ROWS_HT, ids=[c[0] for c in EPI_ROWS_CASES + EPI_ROWS_HT])
+def test_conv3d_whole_row_epilogue(case):
+    lib = _lib()
+    ht = case in EPI_ROWS_HT
+    assert lib.vinet_set_option(b"epi_rows", 1) == 0 and lib.vinet_set_option(b"ht", 2 if ht else 0) == 0
+    try:
+        ex = dict(case[7])
+        if ht:
+            ex.setdefault("tline", 5)
+        _run_conv_case(case[:7] + (ex,), E.BF16, forced=True)
+    finally:
+        lib.vinet_set_option(b"epi_rows", 0)
+        lib.vinet_set_option(b"ht", 1)
+
+
 # split-K (grids too small for the chip): long-K decoder shape, placement through a concat slice, padded fp32
 # head, a T-sliced input, a pending affine, a chunk count that does not divide over the splits
 SPLITK_CASES = [
@@ -1527,6 +1549,8 @@ def _exact_targets():
             t.append(("halo16-" + c[0], test_conv3d_halo_tile, dict(case=c, mfma32=0)))
     for c in PW_CASES:
         t.append(("pw-" + c[0], test_conv3d_pointwise_stream, dict(case=c)))
+    for c in EPI_ROWS_CASES + EPI_ROWS_HT:
+        t.append(("epi-rows-" + c[0], test_conv3d_whole_row_epilogue, dict(case=c)))
     for ksp in [(7, 2, 3), (3, 2, 1), (5, 3, 2)]:
         for acc in (0, 1):
             t.append(("tsd-k%ds%dp%d-acc%d" % (ksp + (acc,)), test_conv3d_tstream_dgrad_fused, dict(ksp=ksp, acc=acc)))

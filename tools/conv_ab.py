@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--only", default="", help="substring filter on site names")
     ap.add_argument("--ht", action="store_true", help="A/B of the halo-tile kernel (conv_ht.h) against the default dispatch on the 3x3-spatial sites")
     ap.add_argument("--pw", action="store_true", help="A/B of the pointwise streaming kernel (conv_pw.h) against the default dispatch on the 1x1x1 sites")
+    ap.add_argument("--opt", action="append", default=[], help="name=v0,v1,...: A/B of one library option on the library's own dispatch (one variant per value)")
     ap.add_argument("--default", action="store_true", help="one variant per library: its own dispatch, no option overrides (A/B of two builds)")
     ap.add_argument("--acc", action="store_true", help="accumulate into y (the epilogue of a data gradient that joins an existing gradient)")
     args = ap.parse_args()
@@ -106,6 +107,13 @@ def main():
             variants.append((ln + ":wdma", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), False))
             variants.append((ln + ":wdma-noperm", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=0), False))
             variants.append((ln + ":wdma+pre", lib, dict(wgrad_dma=1, wgrad_tg=0, wgrad_pp=0, tperm=1), True))
+        libs = []
+    if args.opt:
+        for ln, lib in libs:
+            for o in args.opt:
+                name, vals = o.split("=")
+                for v in vals.split(","):
+                    variants.append((ln + ":%s=%s" % (name, v), lib, {name: int(v)}, False))
         libs = []
     if args.default:
         for ln, lib in libs:

@@ -6,6 +6,7 @@
 
 static thread_local char g_err[512] = "";
 extern int g_vinet_opt_tperm;
+extern int g_vinet_opt_epi_rows;
 extern int g_vinet_opt_n64_tile;
 extern int g_vinet_opt_n192_tile;
 extern int g_vinet_opt_n64_kmax;
@@ -111,6 +112,7 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
                 d->y.T == d->oT && d->y.H == d->oH && d->y.W == d->oW &&
                 d->y.sB == (int64_t)d->y.T * d->y.H * d->y.W * d->y.ld) ? 1 : 0;
   a.act = d->act; a.accumulate = d->accumulate; a.out_f32 = d->out_dtype == VINET_F32;
+  a.epi_rows = g_vinet_opt_epi_rows;
   const int oeb = a.out_f32 ? 4 : 2;
   a.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && (a.sBy % 4 == 0) && ((((uintptr_t)d->y.ptr) % (4 * oeb)) == 0);
   t = vinet_pick_conv_tile(d->dtype, d->mode, M, a.N, (long)d->ntaps * (d->Kp / 32));
@@ -177,6 +179,7 @@ extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
 }
 
 int g_vinet_opt_dma = 1;
+int g_vinet_opt_epi_rows = 0;   // conv epilogue (bf16 fast path): 1 = whole-row stores through a wave-private LDS image.  Measured (tools/conv_ab.py --opt epi_rows=0,1, profiles/r3_epi_rows_ab.txt): neutral on conv_dma, 1...7 % slower on the halo-tile kernels, whole step 306.5 -> 307.4 ms: off.  (The pointwise kernel, conv_pw.h, always stores whole rows: there it is worth 2x.)
 int g_vinet_opt_pw_maxtn = 4;   // pointwise kernel: at most this many column tiles (each re-reads x)
 int g_vinet_opt_pw = 1;        // pointwise streaming kernel (conv_pw.h) for 1x1x1 convs and their data gradients (2 = also on small grids: tests)
 extern int g_vinet_opt_splitk;
@@ -208,6 +211,7 @@ int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
   if (name && !strcmp(name, "pw")) { g_vinet_opt_pw = value; return 0; }
+  if (name && !strcmp(name, "epi_rows")) { g_vinet_opt_epi_rows = value; return 0; }
   if (name && !strcmp(name, "pw_maxtn")) { g_vinet_opt_pw_maxtn = value; return 0; }
   if (name && !strcmp(name, "pool_blk")) { g_vinet_opt_pool_blk = value; return 0; }
   if (name && !strcmp(name, "up_blk")) { g_vinet_opt_up_blk = value; return 0; }

@@ -35,6 +35,7 @@ struct ConvArgs {
   int omT, omH, omW, ooT, ooH, ooW;
   int ntaps, Kp, M, tilesM, tilesN, Nw;
   int in_relu, act, accumulate, out_f32, vec_ok;
+  int epi_rows;          // bf16 fast path of conv_epilogue: whole-row stores through a wave-private LDS image (0 = 16-byte stores per lane)
   int y_linear;          // output offset of voxel m is simply m*ldy (full-extent, possibly channel-sliced view)
   FastDiv dW, dH, dT;    // fast division by Wo, Ho, To
   // M-tile order (BM = 256 kernels, Ho*Wo % 256 == 0): logical tile i -> (b, spatial chunk c, t) with t
@@ -65,11 +66,20 @@ VN_DEV int conv_tile_perm(const ConvArgs& a, int i) {
 }
 
 // LDS the epilogue needs behind a K loop (every kernel sizes its dynamic LDS with max(K loop, this))
+// per wave: the general path's fp32 row group, or the bf16 fast path's output image (MT x 16 rows x WNC bf16, conv_epilogue)
+// with its row-offset table
+template <int MT, int NT>
+constexpr int conv_epi_wave_bytes() {
+  constexpr int WNC = NT * 16;
+  // (tiles of more than four row groups per wave -- conv_pp.h -- keep the 16-byte stores: their image would not fit)
+  constexpr int general = 16 * (WNC + 4) * 4, image = MT <= 4 ? MT * 16 * WNC * 2 + MT * 16 * 8 : 0;
+  return general > image ? general : image;
+}
 template <int MT, int NT, int WARPS_M, int WARPS_N>
 constexpr int conv_epi_bytes() {
   constexpr int W = WARPS_M * WARPS_N, WNC = NT * 16, BN = WNC * WARPS_N;
-  // general path: one wave-private fp32 row group (the bf16 fast path stages nothing) + statistics table: 4 partial rows per wave row
-  return W * 16 * (WNC + 4) * 4 + 4 * WARPS_M * BN * 2 * 4;
+  // per-wave staging + statistics table: 4 partial rows per wave row
+  return W * conv_epi_wave_bytes<MT, NT>() + 4 * WARPS_M * BN * 2 * 4;
 }
 
 template <typename T, int MT, int NT, int WARPS_M, int WARPS_N>
@@ -161,7 +171,7 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   constexpr int WNC = NT * 16, EROW = WNC + 4;
   const int p = lane & 15, q = lane >> 4;              // my voxel inside a row group, my channel quad inside a column tile
-  float* Ew = (float*)smem + wave * (16 * EROW);
+  float* Ew = (float*)(smem + wave * conv_epi_wave_bytes<MT, NT>());
   float* red = (float*)(smem + conv_epi_bytes<MT, NT, WARPS_M, WARPS_N>() - 4 * WARPS_M * BN * 2 * 4);
   const int m_wave = tile_m * BM + wm * MT * 16;
   const int n_wave = tile_n * BN + wn * WNC;
@@ -216,13 +226,33 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   if (fast8) {
     // after the swap my 16 bytes are channels n8 .. n8 + 7 of voxel p in row group 2k + (q & 1)
     constexpr int NP = MT / 2;
+    // Plain stores (no accumulate) leave as WHOLE ROWS: the 16-byte pieces go into a wave-private LDS image (MT x 16 rows x WNC
+    // bf16, piece index XOR img_swz(row): 16 rows x one piece and the pieces of a row are both conflict-free), then WNC / 8
+    // consecutive lanes write the WNC * 2 contiguous bytes of a voxel.  Stored directly, a lane's 16 bytes sit next to only one
+    // other lane's: 32-byte fragments, four instructions per 128-byte line -- the pointwise kernel ran at half the speed of its
+    // own loads + MFMAs that way (conv_pw.h, profiles/r3_pw_ab.txt).  Row offsets: one voxel decode per lane, through LDS.
+    const bool staged = MT <= 4 && a.epi_rows && !a.accumulate;
+    constexpr int PPR = WNC / 8, IMG_G = (PPR % 16 == 0) ? 16 : (PPR % 8 == 0) ? 8 : (PPR % 4 == 0) ? 4 : 2, IMG_P = 16 / IMG_G;
+    auto img_swz = [](int row) { return (row / IMG_P) & (IMG_G - 1); };
+    char* const img = (char*)Ew;
+    long* const rowoff = (long*)(img + MT * 16 * WNC * 2);
     long voff[NP];
     bool vok[NP];
+    if (staged) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const int ig = 2 * k + (q & 1);
-      vok[k] = p < group_rows(ig);
-      voff[k] = vok[k] ? voxel_off(group_m0(ig) + p) : 0;
+      for (int r0 = 0; r0 < MT * 16; r0 += 64) {
+        const int ig = (r0 >> 4) + q;           // row r0 + lane: group (r0 + lane) >> 4, voxel p
+        if (ig < MT) rowoff[r0 + lane] = p < group_rows(ig) ? voxel_off(group_m0(ig) + p) : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) { vok[k] = false; voff[k] = 0; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int ig = 2 * k + (q & 1);
+        vok[k] = p < group_rows(ig);
+        voff[k] = vok[k] ? voxel_off(group_m0(ig) + p) : 0;
+      }
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -271,7 +301,12 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
           if (relu) { x0 = pk_relu_bf16(x0); x1 = pk_relu_bf16(x1); y0 = pk_relu_bf16(y0); y1 = pk_relu_bf16(y1); }
           permlane16_swap(x0, y0);
           permlane16_swap(x1, y1);
-          if (vok[k] && nok8) *(uint4*)((bf16_t*)a.y + voff[k] + n8) = make_uint4(x0, x1, y0, y1);
+          if (staged) {
+            const int row = (2 * k + (q & 1)) * 16 + p;
+            *(uint4*)(img + row * (WNC * 2) + (((2 * j + (q >> 1)) ^ img_swz(row)) * 16)) = make_uint4(x0, x1, y0, y1);
+          } else if (vok[k] && nok8) {
+            *(uint4*)((bf16_t*)a.y + voff[k] + n8) = make_uint4(x0, x1, y0, y1);
+          }
         } else {
           // y += result: ONE rounding, of old + new in fp32
 #pragma unroll
@@ -290,6 +325,18 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
       }
       if (do_stats) put_stats(j, ss, qq);
       __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: hoisted accumulator reads of later tiles spill
+    }
+    if (staged) {
+      wave_lds_fence();
+#pragma unroll
+      for (int it = 0; it < (MT * 16 * PPR) / 64; ++it) {
+        const int e = lane + 64 * it;
+        const int row = e / PPR, piece = e - row * PPR;
+        const long off = rowoff[row];
+        const int n = n_wave + piece * 8;
+        const uint4 v = *(const uint4*)(img + row * (WNC * 2) + ((piece ^ img_swz(row)) * 16));
+        if (off >= 0 && n < a.N) *(uint4*)((bf16_t*)a.y + off + n) = v;
+      }
     }
   } else {
     // ---- general path: fp32 output, sigmoid, odd channel counts; one row group at a time through a wave-private LDS tile
