@@ -1117,6 +1117,18 @@ def test_maxpool_k3s1_twalk_backward(dt, form):
         lib.vinet_set_option(b"pool_lds", 1)
 
 
+@pytest.mark.parametrize("acc", [0, 1])
+@pytest.mark.parametrize("Cc,hw", [(136, (17, 8)), (64, (8, 24))])
+def test_maxpool_k3s1_backward_shapes(Cc, hw, acc):
+    """the bf16 T-walking 3x3x3/s1 backward on more shapes: several channel octets per voxel, store and accumulate"""
+    lib = _lib()
+    assert lib.vinet_set_option(b"pool_twalk", 2) == 0
+    try:
+        test_maxpool(E.BF16, ((3, 3, 3), (1, 1, 1), (1, 1, 1)), Cc=Cc, acc=acc, hw=hw)
+    finally:
+        lib.vinet_set_option(b"pool_twalk", 1)
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_maxpool_133s2_generic_backward(dt):
     """1x3x3/s(1,2,2) through the generic gather (the 2x2-block kernel is its default)"""
@@ -1154,11 +1166,11 @@ def test_maxpool_k3s1_lds_forward(dt):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("ksp", POOLS, ids=[str(p[0]) + str(p[1]) for p in POOLS])
-def test_maxpool(dt, ksp):
+def test_maxpool(dt, ksp, Cc=24, acc=1, hw=(9, 10)):
     k, s, p = ksp
-    B, T, H, W, Cc = 2, 8, 9, 10, 24
+    B, T, (H, W) = 2, 8, hw
     od = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
-    xp, xmk = view_pair(B, T, H, W, Cc, dt, "px", 1, ld=40, c_off=8)      # input / its gradient: slices of a wider buffer
+    xp, xmk = view_pair(B, T, H, W, Cc, dt, "px", 1, ld=Cc + 16, c_off=8)      # input / its gradient: slices of a wider buffer
     yp, ymk = view_pair(B, od[0], od[1], od[2], Cc, dt, "py", 2)
     am = Pair(torch.zeros(B * od[0] * od[1] * od[2] * Cc, dtype=torch.uint8))
     ps, ph = fvec("pps", Cc, 3, -1.5, 1.5), fvec("pph", Cc, 4)
@@ -1171,9 +1183,9 @@ def test_maxpool(dt, ksp):
     diff = am.get("gpu") != am.get("cpu")
     assert not bool((diff & (yp.get("cpu").float() != 0)).any())
     gp, gmk = view_pair(B, od[0], od[1], od[2], Cc, dt, "pg", 5)
-    dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "pdx", 6, ld=40, c_off=8)
+    dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "pdx", 6, ld=Cc + 16, c_off=8)
     amc = Pair(am.cpu.clone())
-    run_both("vinet_maxpool3d_bwd", lambda sd: [C.byref(pd()), C.byref(gmk(sd).ct()), amc.ptr(sd), C.byref(dxmk(sd).ct()), 1, _stream() if sd == "gpu" else 0])
+    run_both("vinet_maxpool3d_bwd", lambda sd: [C.byref(pd()), C.byref(gmk(sd).ct()), amc.ptr(sd), C.byref(dxmk(sd).ct()), acc, _stream() if sd == "gpu" else 0])
     _cmp(dxp.get("gpu"), dxp.get("cpu"), 1e-5 if dt == E.F32 else 2e-2, "maxpool bwd")
 
 
