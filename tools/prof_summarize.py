@@ -70,6 +70,9 @@ for r in rows:
          "conv_wgrad_rs_kernel<2>": "conv_wgrad_rs_kernel<W64>", "conv_wgrad_rs_kernel<1>": "conv_wgrad_rs_kernel<W32>"}.get(k, k)
     k = re.sub(r"^bn_bwd_reduce8_bf16_kernel<\d+>$", "vinet_bn_bwd_reduce", k)
     k = re.sub(r"^bn_bwd_apply8_bf16_kernel<\d+>$", "vinet_bn_bwd_apply", k)
+    m = re.match(r"conv_pw_kernel<(\d+),(\w+)>", k)       # the library names the pointwise kernel by its column-tile width
+    if m:
+        k = "conv_pw_kernel<%d,%s>" % (int(m[1]) * 16, m[2])
     m = re.match(r"conv_wgrad_dma_kernel<(\d+),(\d+),(\d+),(\d+),(\w+)>", k)
     if m:
         k = "conv_wgrad_dma_kernel<%s,%s,%s,%s>" % (m[1], m[2], m[3], m[5])
