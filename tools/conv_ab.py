@@ -68,6 +68,11 @@ SITES = [
     ("4b dg 304->480 pw", 8, 8, 14, 24, 304, 480, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("4c b3 512->64 pw", 8, 8, 14, 24, 512, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("4c b3 dg 64->512 pw", 8, 8, 14, 24, 64, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("4f entry 528->448 pw", 8, 8, 14, 24, 528, 448, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("4c entry 512->296 pw", 8, 8, 14, 24, 512, 296, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("5b entry 832->624 pw", 8, 4, 7, 12, 832, 624, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("5c entry 832->448 pw", 8, 4, 7, 12, 832, 448, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("5b b3 832->128 pw", 8, 4, 7, 12, 832, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
 ]
 
 

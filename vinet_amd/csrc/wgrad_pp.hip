@@ -416,8 +416,12 @@ bool vinet_wgrad_use_pp(const VinetWgradDesc* d) {
   const int tn = wpp_tn(N);
   const int npad = (N + tn - 1) / tn * tn, spad = (nseg + 3) / 4 * 4;
   const long max_blocks = (long)(npad / tn) * (spad / 4) * (M / 64 / 32);
-  const double need = d->pre.scale ? 0.7 : 0.6;   // the fragment-time affine costs the kernel ~25%
-  return dy_linear && M >= 32768 && max_blocks >= 256 && (double)N * nseg >= need * (double)npad * spad;
+  // (the fragment-time affine costs the kernel ~25%.  Pointwise layers: the alternative is the 64 x 64 DMA kernel at 180...270
+  //  TF/s, and the ping-pong kernel wins from 65 % tile use and 190 workgroups on -- 528 -> 448 at 14 x 24: 1.10 -> 0.56 ms,
+  //  832 -> 624 at 7 x 12: 0.25 -> 0.15, 832 -> 448: 0.18 -> 0.12; tools/conv_ab.py --wgrad --only pw, 192 clips)
+  const bool pw = d->ntaps == 1;
+  const double need = pw ? 0.6 : (d->pre.scale ? 0.7 : 0.6);
+  return dy_linear && M >= 32768 && max_blocks >= (pw ? 190 : 256) && (double)N * nseg >= need * (double)npad * spad;
 }
 
 int vinet_launch_wgrad_pp(const VinetWgradDesc* d, hipStream_t s) {
