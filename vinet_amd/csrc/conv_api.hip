@@ -180,6 +180,7 @@ extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
 
 int g_vinet_opt_dma = 1;
 int g_vinet_opt_epi_rows = 0;   // conv epilogue (bf16 fast path): 1 = whole-row stores through a wave-private LDS image.  Measured (tools/conv_ab.py --opt epi_rows=0,1, profiles/r3_epi_rows_ab.txt): neutral on conv_dma, 1...7 % slower on the halo-tile kernels, whole step 306.5 -> 307.4 ms: off.  (The pointwise kernel, conv_pw.h, always stores whole rows: there it is worth 2x.)
+int g_vinet_opt_pp_pw_kt = 5;    // ping-pong kernel on pointwise layers from this many K tiles of 64 (16 = as for every other layer)
 int g_vinet_opt_pw_maxtn = 4;   // pointwise kernel: at most this many column tiles (each re-reads x)
 int g_vinet_opt_pw = 1;        // pointwise streaming kernel (conv_pw.h) for 1x1x1 convs and their data gradients (2 = also on small grids: tests)
 extern int g_vinet_opt_splitk;
@@ -213,6 +214,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "pw")) { g_vinet_opt_pw = value; return 0; }
   if (name && !strcmp(name, "epi_rows")) { g_vinet_opt_epi_rows = value; return 0; }
   if (name && !strcmp(name, "pw_maxtn")) { g_vinet_opt_pw_maxtn = value; return 0; }
+  if (name && !strcmp(name, "pp_pw_kt")) { g_vinet_opt_pp_pw_kt = value; return 0; }
   if (name && !strcmp(name, "pool_blk")) { g_vinet_opt_pool_blk = value; return 0; }
   if (name && !strcmp(name, "up_blk")) { g_vinet_opt_up_blk = value; return 0; }
   if (name && !strcmp(name, "n128_tile")) { g_vinet_opt_n128_tile = value; return 0; }
@@ -327,7 +329,10 @@ static bool use_pp(const VinetConvDesc* d) {
   const int bn = pp_bn(N);
   const long tiles = ((M + 255) / 256) * ((N + bn - 1) / bn);
   if (g_vinet_opt_pp >= 2) return true;   // tuning: force
-  return N >= 160 && nkt >= 16 && tiles >= 128;
+  // pointwise layers the streaming kernel does not take (Cin = 304...832 at 14 x 24 / 7 x 12): the alternative is conv_dma at
+  // 2.6 k cycles per K step of 32, and the ping-pong kernel wins from 5 K tiles on -- 480 -> 304: 0.42 -> 0.33 ms, 512 -> 296:
+  // 0.38 -> 0.32, 832 -> 624: 0.155 -> 0.106, 304 -> 480: 0.41 -> 0.37 (tools/conv_ab.py, 192 clips)
+  return N >= 160 && nkt >= (d->ntaps == 1 ? g_vinet_opt_pp_pw_kt : 16) && tiles >= 128;
 }
 
 // conv_ht.h: the caller promises (tline == 5) that every tap is (dt, dh, dw, slice) with |dh|, |dw| <= 1 and that taps
