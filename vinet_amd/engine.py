@@ -42,7 +42,7 @@ STEM_FOLD = os.environ.get("VINET_STEM_FOLD", "1") != "0"   # padded/folded stem
 WGRAD_SIDE_STREAM = True
 # CUs the persistent weight-gradient kernels may occupy while they run beside the main stream (conv_api.hip: wgrad_cus);
 # without a second stream they are alone on the GPU and get all of it
-WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "160"))
+WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "208"))
 _WGRAD_CUS_SET = {}
 # every packed weight gradient of a backward pass unpacked by ONE launch at its end (0 = one vinet_unpack_wgrad per conv).  Not
 # used while a parameter-gradient hook is installed (the bucketed all-reduce wants each gradient as soon as it is final).
