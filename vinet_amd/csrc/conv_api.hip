@@ -180,7 +180,7 @@ extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
 
 int g_vinet_opt_dma = 1;
 int g_vinet_opt_epi_rows = 0;   // conv epilogue (bf16 fast path): 1 = whole-row stores through a wave-private LDS image.  Measured (tools/conv_ab.py --opt epi_rows=0,1, profiles/r3_epi_rows_ab.txt): neutral on conv_dma, 1...7 % slower on the halo-tile kernels, whole step 306.5 -> 307.4 ms: off.  (The pointwise kernel, conv_pw.h, always stores whole rows: there it is worth 2x.)
-int g_vinet_opt_pp_pw_kt = 5;    // ping-pong kernel on pointwise layers from this many K tiles of 64 (16 = as for every other layer)
+int g_vinet_opt_pp_pw_kt = 8;    // ping-pong kernel on pointwise layers from this many K tiles of 64 (16 = as for every other layer; 5 wins alone from Cin = 304 on, but costs the training step 0.3 % beside the weight-gradient stream: 8 = Cin >= 480)
 int g_vinet_opt_pw_maxtn = 4;   // pointwise kernel: at most this many column tiles (each re-reads x)
 int g_vinet_opt_pw = 1;        // pointwise streaming kernel (conv_pw.h) for 1x1x1 convs and their data gradients (2 = also on small grids: tests)
 extern int g_vinet_opt_splitk;
