@@ -108,7 +108,7 @@ def _tile_m(dtype, mode, M, N, kchunks=0):
         nt = 8
     if nt == 6 and N % 192 == 0 and ((M + 127) // 128) * (N // 192) >= 512:
         return 128
-    if nt == 8 and 0 < kchunks <= 20 and ((M + 127) // 128) * ((N + 127) // 128) >= 1024:
+    if nt == 8 and 0 < kchunks <= 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 1024:
         return 128
     bm = 256
     if nt in (8, 4):
@@ -164,7 +164,7 @@ class AbiEmulator:
             nkt = d.ntaps * ((d.Kp + 63) // 64)
             bn = 192 if ((N + 191) // 192 * 192) * 20 <= ((N + 255) // 256 * 256) * 17 else 256
             tiles = ((M + 255) // 256) * ((N + bn - 1) // bn)
-            if N >= 160 and nkt >= 16 and tiles >= 128:
+            if N >= 160 and nkt >= (8 if d.ntaps == 1 else 16) and tiles >= 128:
                 return 256
         return _tile_m(d.dtype, d.mode, M, N, d.ntaps * (d.Kp // 32))
 

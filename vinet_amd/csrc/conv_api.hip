@@ -188,7 +188,7 @@ int g_vinet_opt_n64_tile = 0;   // tuning: 64-wide layers on 128x64 (1) or 64x64
 int g_vinet_opt_pool_blk = 1;   // 1x3x3/s(1,2,2) max-pool backward per 2x2 input block
 int g_vinet_opt_up_blk = 1;     // 8-channel upsample kernels (forward per 2x2 output block)
 int g_vinet_opt_n128_tile = 0;   // tuning: 128-wide layers on 128x128 (1) or 64x128 (2) tiles instead of 256x128
-int g_vinet_opt_n128_kmax = 20;  // 128-wide outputs: 128-row tiles up to this many K steps of 32 (0 = never)
+int g_vinet_opt_n128_kmax = 64;  // 128-wide outputs: 128-row tiles up to this many K steps of 32 (0 = never).  Whole step (alternating runs, end of round 3): 0: 304.3 ms, 20: 301.1...301.5, 40: 299.1...300.1, 64: 299.2...299.8, 100: 299.1
 // Workgroups (one 512-thread workgroup per CU, 62-124 KB of LDS each) that the persistent row- / frame-streaming weight-gradient
 // kernels may occupy.  They run on a second stream beside the BN-backward / data-gradient chain, which is the critical path: on
 // every CU they sit on, a conv_dma / conv_pp workgroup of the main stream finds LDS for one resident workgroup instead of
