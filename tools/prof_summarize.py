@@ -68,8 +68,8 @@ for r in rows:
     k = {"conv_wgrad_rsm_kernel<3,48>": "conv_wgrad_rs_kernel<W48>", "conv_wgrad_rsm_kernel<3,24>": "conv_wgrad_rs_kernel<W24>",
          "conv_wgrad_rs_kernel<3>": "conv_wgrad_rs_kernel<W96>", "conv_wgrad_rs_kernel<6>": "conv_wgrad_rs_kernel<W192>",
          "conv_wgrad_rs_kernel<2>": "conv_wgrad_rs_kernel<W64>", "conv_wgrad_rs_kernel<1>": "conv_wgrad_rs_kernel<W32>"}.get(k, k)
-    k = re.sub(r"^bn_bwd_reduce8_bf16_kernel<\d+>$", "vinet_bn_bwd_reduce", k)
-    k = re.sub(r"^bn_bwd_apply8_bf16_kernel<\d+>$", "vinet_bn_bwd_apply", k)
+    k = re.sub(r"^bn_bwd_reduce8_bf16_kernel<\d+(,\d+)?>$", "vinet_bn_bwd_reduce", k)
+    k = re.sub(r"^bn_bwd_apply8_bf16_kernel<\d+(,\d+)?>$", "vinet_bn_bwd_apply", k)
     m = re.match(r"conv_pw_kernel<(\d+),(\w+)>", k)       # the library names the pointwise kernel by its column-tile width
     if m:
         k = "conv_pw_kernel<%d,%s>" % (int(m[1]) * 16, m[2])
