@@ -1117,6 +1117,14 @@ def test_maxpool_k3s1_twalk_backward(dt, form):
         lib.vinet_set_option(b"pool_lds", 1)
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("acc", [0, 1])
+@pytest.mark.parametrize("Cc,hw", [(136, (17, 8)), (64, (8, 24))])
+def test_maxpool_k3s2_block_backward_shapes(Cc, hw, acc, dt):
+    """the 2x2x2-block 3x3x3/s2 backward on more shapes: odd and even extents, several channel octets, store and accumulate"""
+    test_maxpool(dt, POOLS[1], Cc=Cc, acc=acc, hw=hw)
+
+
 @pytest.mark.parametrize("acc", [0, 1])
 @pytest.mark.parametrize("Cc,hw", [(136, (17, 8)), (64, (8, 24))])
 def test_maxpool_k3s1_backward_shapes(Cc, hw, acc):
@@ -1131,11 +1139,12 @@ def test_maxpool_k3s1_backward_shapes(Cc, hw, acc):
 
 @pytest.mark.parametrize("dt", DTS)
 def test_maxpool_133s2_generic_backward(dt):
-    """1x3x3/s(1,2,2) through the generic gather (the 2x2-block kernel is its default)"""
+    """1x3x3/s(1,2,2) and 3x3x3/s2 through the generic gather (the 2x2 / 2x2x2-block kernels are their defaults)"""
     lib = _lib()
     assert lib.vinet_set_option(b"pool_blk", 0) == 0
     try:
         test_maxpool(dt, POOLS[0])
+        test_maxpool(dt, POOLS[1])
     finally:
         lib.vinet_set_option(b"pool_blk", 1)
 

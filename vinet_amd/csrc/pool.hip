@@ -838,6 +838,67 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k133s2_kernel(TView dy, const
     }
 }
 
+// 3x3x3 / s2 / p1 backward (the pool between the 28 x 48 and 14 x 24 stages, model.py:705): one lane owns the 2 x 2 x 2 input block
+// {2a, 2a+1} x {2b, 2b+1} x {2c, 2c+1} x 8 channels.  Per dimension block voxel i (0 / 1) is tap i + 1 of window a and, for i = 1,
+// tap 0 of window a + 1: eight windows reach the block through 27 (window, voxel) pairs, each with ONE fixed tap code -- so a pair
+// costs a byte compare and a predicated add per channel, with no code decode and no division (the generic gather walks up to 8
+// windows per voxel with their index arithmetic: 1.4 TB/s of tensors on the 480-channel pool).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(TView dy, const uint8_t* __restrict__ argmax, TView dx, int accumulate,
+                                                               int TB, int HB, int WB, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int G = dx.C >> 3;
+  long r = i / G;
+  const int g = (int)(i - r * G);
+  const int wb = (int)(r % WB); r /= WB;
+  const int hb = (int)(r % HB); r /= HB;
+  const int tb = (int)(r % TB);
+  const int b = (int)(r / TB);
+  // windows w = (dt * 2 + dh) * 2 + dw at (tb + dt, hb + dh, wb + dw)
+  unsigned long long am[8];
+  float dv[8][8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const int to = tb + (w >> 2), ho = hb + ((w >> 1) & 1), wo = wb + (w & 1);
+    const bool ok = to < dy.T && ho < dy.H && wo < dy.W;
+    am[w] = ~0ull;
+    if (ok) {
+      const long ovox = (((long)b * dy.T + to) * dy.H + ho) * dy.W + wo;
+      am[w] = *(const unsigned long long*)(argmax + ovox * dy.C + g * 8);
+      ld8<T>((const T*)dy.p + vox_off(dy, b, to, ho, wo) + g * 8, dv[w]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv[w][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const int it = v >> 2, ih = (v >> 1) & 1, iw = v & 1;
+    const int t = 2 * tb + it, h = 2 * hb + ih, w_ = 2 * wb + iw;
+    if (t >= dx.T || h >= dx.H || w_ >= dx.W) continue;
+    float gr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const int dt = w >> 2, dh = (w >> 1) & 1, dw = w & 1;
+      if (dt > it || dh > ih || dw > iw) continue;            // (compile time: the window does not reach this voxel)
+      const int kt = dt ? 0 : it + 1, kh = dh ? 0 : ih + 1, kw = dw ? 0 : iw + 1;
+      const unsigned long long x = am[w] ^ ((unsigned long long)((kt * 3 + kh) * 3 + kw) * 0x0101010101010101ull);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (((x >> (8 * e)) & 0xffull) == 0) gr[e] += dv[w][e];
+    }
+    T* dst = (T*)dx.p + vox_off(dx, b, t, h, w_) + g * 8;
+    if (accumulate) {
+      float o[8];
+      ld8<T>(dst, o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gr[e] += o[e];
+    }
+    st8<T>(dst, gr);
+  }
+}
+
 // 3x3x3 / s1 / p1 backward, T-walking form: one lane owns an input column (b, h, w, 8 channels) and walks the
 // output planes; the argmax word of each of the 9 in-plane neighbour windows is read ONCE per plane and tested
 // against the three temporal taps it could route to, accumulating into three named accumulators (inputs
@@ -1021,6 +1082,14 @@ extern "C" int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy
       DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_k133s2_kernel<T>, dim3(ew_grid(nthr)), dim3(256), 0, (hipStream_t)stream,
                                                  make_view(*dy), argmax, make_view(*dx), accumulate, HB, WB, nthr);)
       return vn_launch_status("maxpool3d_bwd(k133s2)");
+    }
+    if (g_vinet_opt_pool_blk && d->kT == 3 && d->kH == 3 && d->kW == 3 && d->sT == 2 && d->sH == 2 && d->sW == 2 && d->pT == 1 && d->pH == 1 &&
+        d->pW == 1 && dy->T == (dx->T - 1) / 2 + 1 && dy->H == (dx->H - 1) / 2 + 1 && dy->W == (dx->W - 1) / 2 + 1) {
+      const int TB = (dx->T + 1) / 2, HB = (dx->H + 1) / 2, WB = (dx->W + 1) / 2;
+      const long nthr = (long)dx->B * TB * HB * WB * (dx->C / 8);
+      DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<T>, dim3(ew_grid(nthr)), dim3(256), 0, (hipStream_t)stream,
+                                                 make_view(*dy), argmax, make_view(*dx), accumulate, TB, HB, WB, nthr);)
+      return vn_launch_status("maxpool3d_bwd(k3s2)");
     }
     DISPATCH_T(d->dtype, T, hipLaunchKernelGGL(maxpool_bwd8_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
                                                p, make_view(*dy), argmax, make_view(*dx), accumulate, total8);)
