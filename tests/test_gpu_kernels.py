@@ -1173,11 +1173,20 @@ def test_maxpool_k3s1_lds_forward(dt):
         lib.vinet_set_option(b"pool_lds", 1)
 
 
+@pytest.mark.parametrize("T", [7, 1])
+@pytest.mark.parametrize("Cc,hw", [(24, (9, 10)), (136, (17, 8)), (64, (34, 32))])
+@pytest.mark.parametrize("ksp", POOLS[:2], ids=["k133s2", "k333s2"])
+def test_maxpool_strided_odd_extents(ksp, Cc, hw, T):
+    """the strided 3 x 3 spatial pools (forward, and the 2x2 / 2x2x2-block backward kernels) on odd / unit clip lengths, odd and
+    even H / W, several channel octets"""
+    test_maxpool(E.BF16, ksp, Cc=Cc, hw=hw, T=T)
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("ksp", POOLS, ids=[str(p[0]) + str(p[1]) for p in POOLS])
-def test_maxpool(dt, ksp, Cc=24, acc=1, hw=(9, 10)):
+def test_maxpool(dt, ksp, Cc=24, acc=1, hw=(9, 10), T=8):
     k, s, p = ksp
-    B, T, (H, W) = 2, 8, hw
+    B, (H, W) = 2, hw
     od = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
     xp, xmk = view_pair(B, T, H, W, Cc, dt, "px", 1, ld=Cc + 16, c_off=8)      # input / its gradient: slices of a wider buffer
     yp, ymk = view_pair(B, od[0], od[1], od[2], Cc, dt, "py", 2)
