@@ -168,7 +168,7 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
 extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
   if (!d) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
-  if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_pw(d)) return pw_shape(d).gm;   // one row per persistent workgroup
+  if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_pw(d)) return pw_shape(d).gm;   // one row per workgroup (4 waves x up to 16 tiles of 64 rows)
   if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_ht(d)) {
     const HtShape h = ht_shape(d);
     if (h.tm) return (int)((long)d->x.B * vn_div_up(d->oT, 4) * vn_div_up((long)d->oH * d->oW, 64));

@@ -5,7 +5,7 @@
 // Why a fifth conv generation: these layers are memory-bound GEMMs with a tiny K loop (Cin = 64...288: 2...9 steps of 32) at
 // millions of rows.  conv_dma.h spends 2300...2800 cycles per K step of 32 (barrier + DMA issue + wait) and 12...17 k cycles
 // in the epilogue of a 256 x 96 tile whose K loop is 8 steps: 1.8...2.2 TB/s of tensor traffic at 250...350 TF/s, under half of
-// either roofline (profiles/r3_pw_phases.txt).  There is nothing to share between the rows of such a GEMM except the weights:
+// either roofline (profiles/r3_pw_ab.txt).  There is nothing to share between the rows of such a GEMM except the weights:
 //
 //   * the WEIGHT tile (BN = 32 / 64 / 96 output channels x all of K) is staged in LDS once per workgroup and stays there; the
 //     workgroup walks a block of rows (4 waves x up to 16 tiles of 64).  Row stride K * 2 + 16 bytes: a ds_read_b128 fragment read (16 rows x 16 B per
