@@ -1103,11 +1103,12 @@ POOLS = [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), (
          ((8, 1, 1), (8, 1, 1), (0, 0, 0))]
 
 
-@pytest.mark.parametrize("form", [2, 3])
+@pytest.mark.parametrize("form", [2, 3, 4])
 @pytest.mark.parametrize("dt", DTS)
 def test_maxpool_k3s1_twalk_backward(dt, form):
     """the T-walking 3x3x3/s1 backward (chosen for large tensors only) forced on the small test shape
-    (2: bf16 takes the all-loads-up-front form; 3: the conditional-load form for every dtype)"""
+    (2: bf16 takes the all-loads-up-front form with EXEC-mask routing; 3: the conditional-load form for every dtype;
+    4: bf16 all-loads-up-front with compare / select / add routing)"""
     lib = _lib()
     assert lib.vinet_set_option(b"pool_twalk", form) == 0 and lib.vinet_set_option(b"pool_lds", 0) == 0
     try:

@@ -200,7 +200,7 @@ int g_vinet_opt_n192_tile = 1;   // 128 x 192 tiles (waves 2 x 2) for N % 192 ==
 int g_vinet_opt_reduce_il = 1;  // channel reductions: blocks interleave rounds over one window (0 = one contiguous range per block)
 int g_vinet_opt_pool_pk = 1;    // bf16: packed 32-bit-key form of the LDS halo-tile pool (0 = the fp32-compare kernel)
 int g_vinet_opt_pool_lds = 1;   // LDS halo-tile 3x3x3/s1 max-pool forward (C % 64 == 0)
-int g_vinet_opt_pool_twalk = 1; // T-walking 3x3x3/s1 max-pool backward
+int g_vinet_opt_pool_twalk = 1; // T-walking 3x3x3/s1 max-pool backward (2 = force on small grids, 3 = conditional-load form, 4 = bf16 without the EXEC-mask routing)
 int g_vinet_opt_tperm = 0;      // t-fastest M-tile order (L2 reuse across temporal taps): measured neutral on the whole step, off
 int g_vinet_opt_wgrad_tr = 1;
 int g_vinet_opt_wgrad_dma = 1;
