@@ -608,6 +608,23 @@ extern "C" int vinet_maxpool3d(const VinetPoolDesc* d, const VinetTensor* x, Vin
   return vn_launch_status("maxpool3d");
 }
 
+// g += v in the lanes whose code byte (byte BYTE of `word`) equals `code`: v_cmpx (SDWA byte select) -> add under EXEC -> EXEC restored
+#define POOL_ADD_IF_X(g, word, BYTE, code, v, exec0)                                                                                  \
+  asm volatile("v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #BYTE " src1_sel:DWORD\n\tv_add_f32_e32 %0, %0, %3\n\ts_mov_b64 exec, %4" \
+               : "+v"(g) : "v"(word), "s"(code), "v"(v), "s"(exec0) : "vcc")
+#define POOL_ADD_IF(g, word, BYTE, code, v) POOL_ADD_IF_X(g, word, BYTE, code, v, exec0)
+// byte e (0..7) of a 64-bit code word
+#define POOL_ADD_IF8(g, lo, hi, e, code, v, ex)                                           \
+  do {                                                                                      \
+    const uint32_t w_ = (e) < 4 ? (lo) : (hi);                                              \
+    switch ((e) & 3) {                                                                      \
+      case 0: POOL_ADD_IF_X(g, w_, 0, code, v, ex); break;                                  \
+      case 1: POOL_ADD_IF_X(g, w_, 1, code, v, ex); break;                                  \
+      case 2: POOL_ADD_IF_X(g, w_, 2, code, v, ex); break;                                  \
+      default: POOL_ADD_IF_X(g, w_, 3, code, v, ex); break;                                 \
+    }                                                                                       \
+  } while (0)
+
 // backward as a gather over the (at most ceil(k/s)^3) windows covering each input voxel
 template <typename T>
 __global__ void maxpool_bwd_kernel(PoolP p, TView dy, const uint8_t* __restrict__ argmax, TView dx, int accumulate,
@@ -816,16 +833,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k133s2_kernel(TView dy, const
       const int h = h0 + ih, w = w0 + iw;
       if (h >= dx.H || w >= dx.W) continue;
       float gr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned long long ex;                                  // (the lanes that are inside the image: POOL_ADD_IF restores this mask)
+      asm volatile("s_mov_b64 %0, exec" : "=s"(ex));
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int dh = q >> 1, dw = q & 1;
         // input (h, w) as tap (kh, kw) of window (hb + dh, wb + dw): kh = h + 1 - 2*(hb + dh) = ih + 1 - 2*dh
         const int kh = ih + 1 - 2 * dh, kw = iw + 1 - 2 * dw;
         if (kh < 0 || kw < 0) continue;                       // (compile-time: the window does not reach this input)
-        const unsigned long long x = am[q] ^ ((unsigned long long)(kh * 3 + kw) * 0x0101010101010101ull);
+        const uint32_t alo = (uint32_t)am[q], ahi = (uint32_t)(am[q] >> 32);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (((x >> (8 * e)) & 0xffull) == 0) gr[e] += dv[q][e];
+        for (int e = 0; e < 8; ++e) POOL_ADD_IF8(gr[e], alo, ahi, e, (uint32_t)(kh * 3 + kw), dv[q][e], ex);
       }
       T* dst = (T*)dx.p + vox_off(dx, b, t, h, w) + g * 8;
       if (accumulate) {
@@ -878,15 +896,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(TView dy, const u
     const int t = 2 * tb + it, h = 2 * hb + ih, w_ = 2 * wb + iw;
     if (t >= dx.T || h >= dx.H || w_ >= dx.W) continue;
     float gr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ex;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(ex));
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
       const int dt = w >> 2, dh = (w >> 1) & 1, dw = w & 1;
       if (dt > it || dh > ih || dw > iw) continue;            // (compile time: the window does not reach this voxel)
       const int kt = dt ? 0 : it + 1, kh = dh ? 0 : ih + 1, kw = dw ? 0 : iw + 1;
-      const unsigned long long x = am[w] ^ ((unsigned long long)((kt * 3 + kh) * 3 + kw) * 0x0101010101010101ull);
+      const uint32_t alo = (uint32_t)am[w], ahi = (uint32_t)(am[w] >> 32);
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (((x >> (8 * e)) & 0xffull) == 0) gr[e] += dv[w][e];
+      for (int e = 0; e < 8; ++e) POOL_ADD_IF8(gr[e], alo, ahi, e, (uint32_t)((kt * 3 + kh) * 3 + kw), dv[w][e], ex);
     }
     T* dst = (T*)dx.p + vox_off(dx, b, t, h, w_) + g * 8;
     if (accumulate) {
@@ -1047,10 +1066,6 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s1_tw2_kernel(TView dy, con
   }
 }
 
-// g += v in the lanes whose code byte (byte BYTE of `word`) equals `code`: v_cmpx (SDWA byte select) -> add under EXEC -> EXEC restored
-#define POOL_ADD_IF(g, word, BYTE, code, v)                                                                                  \
-  asm volatile("v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #BYTE " src1_sel:DWORD\n\tv_add_f32_e32 %0, %0, %3\n\ts_mov_b64 exec, %4" \
-               : "+v"(g) : "v"(word), "s"(code), "v"(v), "s"(exec0) : "vcc")
 // the same walk with the routing done on the EXEC mask: 1127 -> 836 VALU instructions per plane and lane, 3.01 -> 2.37 ms on the
 // 256-channel pool at 28 x 48 (the default; pool_twalk = 4 selects the form above)
 __global__ __launch_bounds__(256) void maxpool_bwd_k3s1_tw3_kernel(TView dy, const uint8_t* __restrict__ argmax, TView dx,
