@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, NT >=
           const int row = e / PPR, piece = e - row * PPR;
           const int m = m0 + 32 * k + row, n = n_wave + piece * 8;
           const uint4 v = *(const uint4*)(stg + row * (BN * 2) + ((piece ^ swz(row)) * 16));
-#ifndef PW_NO_STORE
+#ifndef PW_NO_STORE      // (tuning build -DPW_NO_STORE: the kernel without its stores -- results are garbage, the time is the point)
           if (m < a.M && n < a.N) *(uint4*)((bf16_t*)a.y + voxel_off(m) + n) = v;
 #else
           if (v.x == 0x12345678u && n < a.N) *(uint4*)((bf16_t*)a.y + voxel_off(m < a.M ? m : 0) + n) = v;
@@ -276,19 +276,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, NT >=
   issue(ring[1]);
   issue(ring[2]);
   {
-#ifndef PW_NO_WAIT4
-#define PW_TILE_END_WAIT pw_wait<4>(); confirmed = 2;
-#else
-#define PW_TILE_END_WAIT
-#endif
     int confirmed = 0;                // ring steps ahead of the current one whose loads are known to have landed
 #define PW_STEP(NEXT, CUR)                                                                              \
     issue(ring[NEXT]);                                                                                  \
     if (confirmed > 0) --confirmed; else pw_wait<12>();                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     if (compute(ring[CUR])) {                                                                           \
-      PW_TILE_END_WAIT                                                                                  \
-                                                                                  \
+      pw_wait<4>();                /* everything but the newest ring step: the next two steps are confirmed */ \
+      confirmed = 2;                                                                                    \
       epilogue(c_wt);                                                                                   \
       zero_acc();                                                                                       \
       c_s = 0;                                                                                          \
