@@ -45,6 +45,8 @@ WGRAD_SIDE_STREAM = True
 WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "208"))
 _WGRAD_CUS_SET = {}
 TAIL_WGRAD_FULL = os.environ.get("VINET_TAIL_WGRAD_FULL", "1") != "0"
+# cap of the decoder's (BatchNorm-less, deferred) weight gradients, which run beside the backward of the low-resolution encoder stages
+WGRAD_CUS_DEC = int(os.environ.get("VINET_WGRAD_CUS_DEC", str(WGRAD_CUS)))
 # every packed weight gradient of a backward pass unpacked by ONE launch at its end (0 = one vinet_unpack_wgrad per conv).  Not
 # used while a parameter-gradient hook is installed (the bucketed all-reduce wants each gradient as soon as it is final).
 MULTI_UNPACK = int(os.environ.get("VINET_MULTI_UNPACK", "1"))
@@ -1139,17 +1141,15 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                     es = ESIZE[ctx.dt]
                     # the conv whose input needs no gradient (the RGB stem) is the LAST node of the tape: nothing of the main stream
                     # is left beside its weight gradient, which may take the whole chip
-                    tail = TAIL_WGRAD_FULL and side is not None and not x.needs_grad and WGRAD_CUS < 256
-                    if tail:
-                        ctx.lib.vinet_set_option(b"wgrad_cus", 256)
-                    try:
-                        ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
-                                 tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
-                                 work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
-                                           bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
-                    finally:
-                        if tail:
-                            ctx.lib.vinet_set_option(b"wgrad_cus", WGRAD_CUS)
+                    tail = TAIL_WGRAD_FULL and side is not None and not x.needs_grad
+                    cap = 256 if (tail or side is None) else (WGRAD_CUS_DEC if bn is None else WGRAD_CUS)
+                    if _WGRAD_CUS_SET.get("v") != cap:
+                        ctx.lib.vinet_set_option(b"wgrad_cus", cap)
+                        _WGRAD_CUS_SET["v"] = cap
+                    ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
+                             tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
+                             work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
+                                       bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
                     if Ny != plan.N:
                         assert plan.ntaps == 1, "channel-padded outputs are only supported for 1x1x1 convs"
                     if persistent and MULTI_UNPACK and PARAM_GRAD_HOOK is None and N_SIDE_STREAMS == 1:
