@@ -254,7 +254,7 @@ def extras(args, dev):
                         "model call + resize to 360x640 + 11x11 blur + uint8, maps copied to the host as bytes"}
 
     def train_cfg(**kw):
-        r = measure(_quiet(args, mode="train", steps=2, warmup=1, **kw), 0, 1, dev)
+        r = measure(_quiet(args, mode="train", steps=kw.pop("steps", 5), warmup=1, **kw), 0, 1, dev)
         return {"value": r["value"], "unit": "clips/s", "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
                 "whole_step": r["whole_step"], "peak_hbm_gb": r["config"]["peak_hbm_gb"]}
 
@@ -287,6 +287,7 @@ def measure(args, rank, world, dev):
     from vinet_amd import engine, loss, model, optim, parallel, synth
     engine.set_default_dtype(args.dtype)
     engine.WGRAD_SIDE_STREAM = not args.no_side_stream
+    torch.cuda.reset_peak_memory_stats(dev)      # `peak_hbm_gb` is this leg's own peak, not the largest leg of the process so far
 
     if args.batch <= 0:
         args.batch = 64 if (args.clip, args.height, args.width) == (64, 256, 448) else 192

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 9
+#define VINET_ABI_VERSION 10
 
 enum { VINET_F32 = 0, VINET_BF16 = 1 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
@@ -195,6 +195,11 @@ typedef struct VinetWgradDesc {
   const float* bnb_invstd;
   const float* bnb_c1;
   const float* bnb_c2;
+  /* Compute units the PERSISTENT weight-gradient kernels (one 512-thread workgroup per CU: the row- and frame-streaming
+   * forms) may occupy for this launch: a caller that runs its weight gradients on a second stream beside the data-gradient
+   * chain leaves the rest of the chip to that chain.  0 = the whole chip (256).  Per launch and per descriptor, so that
+   * concurrent callers (one host thread per device, autograd worker threads) never share mutable state. */
+  int32_t max_cus;
 } VinetWgradDesc;
 
 int vinet_conv3d_wgrad(const VinetWgradDesc* desc, void* stream);
@@ -412,6 +417,9 @@ int vinet_gt_preprocess(const uint8_t* src, int32_t N, int32_t H, int32_t W, flo
  * None of them changes results beyond floating-point accumulation order. */
 int vinet_set_option(const char* name, int32_t value);
 int vinet_fill_f32(float* p, int64_t n, float value, void* stream);
+/* Test / tuning aid, no reference counterpart: one wave that idles for ~`cycles` shader clocks on `stream` (delays whatever is
+ * enqueued behind it; touches no memory).  Used to perturb the two-stream backward schedule in eager mode. */
+int vinet_debug_spin(int64_t cycles, void* stream);
 int vinet_abi_version(void);
 const char* vinet_last_error(void);
 

@@ -136,6 +136,9 @@ class AbiEmulator:
     def vinet_set_option(self, name, value):
         return 0
 
+    def vinet_debug_spin(self, cycles, stream):
+        return 0
+
     def vinet_fill_f32(self, p, n, value, stream):
         _f32(p, n)[:] = value
         return 0

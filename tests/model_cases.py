@@ -263,3 +263,51 @@ def train_step_case(dev, make_optimizer=None):
         # sign-descent step: only the large-M stem statistics are tight
         close(sd[k[6:]], z[k], 5e-5 if "base1" in k else 2e-3, k)
     return worst
+
+
+def weight_shared_case(dev, dt, tol):
+    """A block whose forward calls ONE BasicConv3d twice (a module used twice in a forward, which parallel.expect_reports
+    supports): both tape nodes share the plan's persistent weight-gradient workspace, so the multi-job unpack must run one job
+    per workspace (the workspace already holds the sum).  Truth: the same graph on torch autograd (oracle blocks, fp32 CPU)."""
+    from vinet_amd import model_utils as MU
+
+    class Twice(MU._Block):
+        def __init__(self):
+            super().__init__()
+            self.c = MU.BasicConv3d(16, 16, (1, 3, 3), 1, (0, 1, 1))
+
+        def _fwd(self, ctx, x, dst=None):
+            return self.c._fwd(ctx, self.c._fwd(ctx, x))
+
+    class TwiceRef(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = O.BasicConv3d(16, 16, (1, 3, 3), 1, (0, 1, 1))
+
+        def forward(self, x):
+            return self.c(self.c(x))
+
+    m, r = Twice(), TwiceRef()
+    sd = synth.synth_state_dict(r.state_dict(), 5)
+    r.load_state_dict(sd)
+    m.load_state_dict(sd)
+    m.compute_dtype = dt
+    m = m.to(dev).train()
+    r.train()
+    x = synth.normal("x_twice", (2, 16, 3, 12, 16), 5)
+    xr = x.clone().requires_grad_(True)
+    xg = x.to(dev).requires_grad_(True)
+    proj = synth.normal("proj_twice", (2, 16, 3, 12, 16), 5)
+    errs = []
+    for _ in range(3):      # (the second and third passes find the persistent workspace handed back zeroed -- or not)
+        for p in m.parameters():
+            p.grad = None
+        xg.grad = None
+        (m(xg) * proj.to(dev)).sum().backward()
+    (r(xr) * proj).sum().backward()
+    errs.append(("gx", relerr(xg.grad, xr.grad)))
+    for (k, p), (_, q) in zip(m.named_parameters(), r.named_parameters()):
+        errs.append((k, relerr(p.grad, q.grad)))
+    for k, e in errs:
+        assert e <= tol, "weight-shared conv: %s rel err %g > %g" % (k, e, tol)
+    return dict(errs)

@@ -271,6 +271,8 @@ def test_conv3d_halo_tile(case, mfma32):
     """both matrix-instruction forms of the halo-tile kernel: conv_ht32.h (v_mfma_f32_32x32x16_bf16, option ht32) and
     conv_ht.h (16x16x32, the default)"""
     lib = _lib()
+    if mfma32 and lib.vinet_set_option(b"ht32", 1) == -2:
+        pytest.skip("conv_ht32.h is compiled into -DVINET_EXPERIMENTS side builds only (measured slower: profiles/r3_ht32_ab.txt)")
     assert lib.vinet_set_option(b"ht", 2) == 0 and lib.vinet_set_option(b"ht32", mfma32) == 0
     try:
         ex = dict(case[7])
@@ -328,6 +330,8 @@ EPI_ROWS_HT = [c for c in HT_CASES if c[0] in ("ht_64_192", "ht_cin160_n80", "ht
 def test_conv3d_whole_row_epilogue(case):
     lib = _lib()
     ht = case in EPI_ROWS_HT
+    if lib.vinet_set_option(b"epi_rows", 1) == -2:
+        pytest.skip("the whole-row epilogue is compiled into -DVINET_EXPERIMENTS side builds only (profiles/r3_epi_rows_ab.txt)")
     assert lib.vinet_set_option(b"epi_rows", 1) == 0 and lib.vinet_set_option(b"ht", 2 if ht else 0) == 0
     try:
         ex = dict(case[7])

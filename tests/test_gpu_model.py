@@ -57,6 +57,14 @@ def test_blocks_bf16(name, mode):
         dict(rel_y=errs["y"], rel_gx=errs["gx"], worst_param=max(v for k, v in errs.items() if k.startswith("g:")))))
 
 
+@pytest.mark.parametrize("dt", [E.F32, E.BF16], ids=["fp32", "bf16"])
+def test_weight_shared_conv_gradients(dt):
+    """a module called twice in one forward: both tape nodes share the plan's weight-gradient workspace, the multi-job unpack
+    runs ONE job for it (two would race on `grad += dw; dw = 0`); three backward passes in a row must agree with torch autograd"""
+    errs = MC.weight_shared_case(DEV, dt, 2e-4 if dt == E.F32 else 0.12)
+    _note("weight_shared_conv_%s" % ("fp32" if dt == E.F32 else "bf16"), errs)
+
+
 def test_losses():
     MC.losses_case(DEV)
 

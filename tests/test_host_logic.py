@@ -35,6 +35,11 @@ def test_blocks(name, mode):
     MC.block_case(name, mode, CPU)
 
 
+def test_weight_shared_conv_gradients():
+    """one ConvPlan run twice in a backward: one unpack job per weight-gradient workspace (engine.Ctx.flush_unpack)"""
+    MC.weight_shared_case(torch.device("cpu"), E.F32, 2e-4)
+
+
 def test_dgrad_phase_decomposition_matches_conv_transpose():
     """every (k, s, p) the nets use, plus a few odd ones, as 1-D identities"""
     for I, k, s, p in [(32, 7, 2, 3), (12, 3, 3, 0), (20, 5, 5, 0), (9, 3, 1, 1), (70560, 64, 2, 32), (11, 4, 2, 2), (7, 2, 3, 0)]:

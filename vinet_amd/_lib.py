@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class CTensor(C.Structure):
@@ -44,7 +44,8 @@ class CWgradDesc(C.Structure):
                 ("ntaps", C.c_int32), ("taps", C.c_void_p), ("dw", C.c_void_p), ("Kp", C.c_int32), ("pre", CAffine),
                 ("tline", C.c_int32), ("tpad", C.c_int32),
                 ("bnb_z", C.c_void_p), ("bnb_ld", C.c_int32), ("bnb_sB", C.c_int64), ("bnb_fwd", CAffine),
-                ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p), ("bnb_c1", C.c_void_p), ("bnb_c2", C.c_void_p)]
+                ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p), ("bnb_c1", C.c_void_p), ("bnb_c2", C.c_void_p),
+                ("max_cus", C.c_int32)]
 
 
 class CPoolDesc(C.Structure):
@@ -104,6 +105,7 @@ SIGNATURES = {
     "vinet_pack_weights_multi": [_vp, _i32, _i64, _i32, _vp],
     "vinet_unpack_wgrad_multi": [_vp, _i32, _i64, _i32, _vp],
     "vinet_fill_f32": [_vp, _i64, _f32, _vp],
+    "vinet_debug_spin": [_i64, _vp],
     "vinet_abi_version": [],
     "vinet_last_error": [],
 }

@@ -25,6 +25,39 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.j
          "-Wno-unused-result", "-ffp-contract=off"]
 
 
+# Kernels whose hand-counted `s_waitcnt` / EXEC-mask inline asm assumes that the compiler neither spills nor copies the registers
+# the asm owns (conv_pw.h: the global-load ring with counted vmcnt; pool.hip: routing on the EXEC mask).  A vector-register spill
+# in one of them would read in-flight data: the build FAILS on it instead of shipping silently wrong kernels.  Checked from
+# hipcc's own -Rpass-analysis=kernel-resource-usage remarks of the same compilation (pinned toolchain: ROCm 7.2 / clang 22).
+GUARDED = {"conv_bf16.hip": ("conv_pw_kernel",), "pool.hip": ("maxpool_bwd",)}
+RESOURCES = os.path.join(CSRC, "obj", "kernel_resources.json")
+
+
+def _parse_resources(text):
+    """hipcc remarks -> {mangled kernel name: {vgpr, agpr, sgpr, scratch, vgpr_spill, sgpr_spill, occupancy}}"""
+    import re
+    out, cur = {}, None
+    keys = {"VGPRs": "vgpr", "AGPRs": "agpr", "TotalSGPRs": "sgpr", "ScratchSize [bytes/lane]": "scratch", "VGPRs Spill": "vgpr_spill",
+            "SGPRs Spill": "sgpr_spill", "Occupancy [waves/SIMD]": "occupancy"}
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def check_guarded(src, text):
+    res = _parse_resources(text)
+    bad = [(k, v) for k, v in res.items() if any(g in k for g in GUARDED.get(src, ())) and v.get("vgpr_spill", 0) > 0]
+    if bad:
+        raise RuntimeError("vector-register spills in kernels whose inline asm owns in-flight registers (%s): %s" % (src, bad))
+    return res
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -63,9 +96,26 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        guarded = os.path.basename(s) in GUARDED
+        cmd = [hipcc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if guarded else []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
-        return s, r.returncode, r.stdout + r.stderr
+        out = r.stdout + r.stderr
+        if guarded and r.returncode == 0:
+            import json
+            try:
+                res = check_guarded(os.path.basename(s), out)
+            except RuntimeError:
+                os.remove(o)
+                raise
+            try:
+                allres = json.load(open(RESOURCES)) if os.path.exists(RESOURCES) else {}
+            except ValueError:
+                allres = {}
+            allres[os.path.basename(s)] = res
+            with open(RESOURCES, "w") as f:
+                json.dump(allres, f, indent=1, sort_keys=True)
+            out = "\n".join(l for l in out.splitlines() if "kernel-resource-usage" not in l and not l.startswith("   ") )
+        return s, r.returncode, out
 
     if jobs:
         if verbose:

@@ -358,10 +358,12 @@ static int launch_channel_reduce(const VinetTensor* x, const VinetTensor* dz, in
   const long vb = (nvox + rows - 1) / rows;
   const TView xv = make_view(*x), dv = dz ? make_view(*dz) : xv;
   if (MODE == 1 && g_vinet_opt_bn_lean && dtype == VINET_BF16 && dz && oct_ok(*x) && oct_ok(*dz)) {
+#ifdef VINET_EXPERIMENTS
     if (g_vinet_opt_bn_lean == 2)
       hipLaunchKernelGGL((bn_bwd_reduce8_bf16_kernel<2, 6>), dim3(rows), dim3(256), 0, (hipStream_t)stream, xv, dv, make_affine(fwd), mean,
                          invstd, nvox, g_vinet_opt_reduce_il ? 0 : vb, partials);
     else
+#endif
       hipLaunchKernelGGL((bn_bwd_reduce8_bf16_kernel<4, 4>), dim3(rows), dim3(256), 0, (hipStream_t)stream, xv, dv, make_affine(fwd), mean,
                          invstd, nvox, g_vinet_opt_reduce_il ? 0 : vb, partials);
     return vn_launch_status("bn_bwd_reduce8_bf16");
@@ -569,10 +571,12 @@ extern "C" int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_ra
     long vb = R * 16;                                  // 4 rounds of 4 voxels per lane
     while ((nvox + vb - 1) / vb > 16384) vb *= 2;
     if (g_vinet_opt_bn_lean && dtype == VINET_BF16) {
+#ifdef VINET_EXPERIMENTS
       if (g_vinet_opt_bn_lean == 2)
         hipLaunchKernelGGL((bn_bwd_apply8_bf16_kernel<2, 6>), dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, (hipStream_t)stream,
                            make_view(*dz), make_view(*x_raw), make_affine(fwd), mean, invstd, c1, c2, make_view(*dx), nvox, vb);
       else
+#endif
         hipLaunchKernelGGL((bn_bwd_apply8_bf16_kernel<4, 4>), dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, (hipStream_t)stream,
                            make_view(*dz), make_view(*x_raw), make_affine(fwd), mean, invstd, c1, c2, make_view(*dx), nvox, vb);
       return vn_launch_status("bn_bwd_apply8_bf16");

@@ -225,6 +225,10 @@ static inline int vn_launch_status(const char* what) {
   }
   return 0;
 }
+// CUs a persistent weight-gradient launch may occupy (VinetWgradDesc::max_cus; 0 = all 256)
+static inline int vn_wgrad_cus(const VinetWgradDesc* d) {
+  return d->max_cus <= 0 ? 256 : (d->max_cus < 8 ? 8 : (d->max_cus > 256 ? 256 : d->max_cus));
+}
 static inline int vn_div_up(long a, long b) { return (int)((a + b - 1) / b); }
 // `overlap`: a read-only conv input may be an OVERLAPPED view (ld < C): consecutive W positions share
 // channels.  The folded RGB stem uses it (position = 2 pixels, "channels" = 8 pixels x 4).

@@ -189,12 +189,6 @@ int g_vinet_opt_pool_blk = 1;   // 1x3x3/s(1,2,2) max-pool backward per 2x2 inpu
 int g_vinet_opt_up_blk = 1;     // 8-channel upsample kernels (forward per 2x2 output block)
 int g_vinet_opt_n128_tile = 0;   // tuning: 128-wide layers on 128x128 (1) or 64x128 (2) tiles instead of 256x128
 int g_vinet_opt_n128_kmax = 64;  // 128-wide outputs: 128-row tiles up to this many K steps of 32 (0 = never).  Whole step (alternating runs, end of round 3): 0: 304.3 ms, 20: 301.1...301.5, 40: 299.1...300.1, 64: 299.2...299.8, 100: 299.1
-// Workgroups (one 512-thread workgroup per CU, 62-124 KB of LDS each) that the persistent row- / frame-streaming weight-gradient
-// kernels may occupy.  They run on a second stream beside the BN-backward / data-gradient chain, which is the critical path: on
-// every CU they sit on, a conv_dma / conv_pp workgroup of the main stream finds LDS for one resident workgroup instead of
-// two.  Whole step at 192 clips, alternating runs on one box: 256 -> 543.4 clips/s, 128 -> 546.0, 96 -> 547.7, 64 -> 550.9,
-// 48 -> 522 (the weight-gradient stream becomes the critical path), 32 -> 422.  96 keeps a 2x margin to that cliff.
-int g_vinet_opt_wgrad_cus = 96;
 int g_vinet_opt_n64_kmax = 64;   // 64-wide outputs: 128-row tiles up to this many K steps of 32
 int g_vinet_opt_n192_tile = 1;   // 128 x 192 tiles (waves 2 x 2) for N % 192 == 0 instead of 256 x 96 (0 = off, 2 = also on small grids: tests)
 int g_vinet_opt_reduce_il = 1;  // channel reductions: blocks interleave rounds over one window (0 = one contiguous range per block)
@@ -212,6 +206,13 @@ int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
   if (name && !strcmp(name, "pw")) { g_vinet_opt_pw = value; return 0; }
+#ifndef VINET_EXPERIMENTS
+  // measured-slower variants live in side builds only (python -c "from vinet_amd import build; build.build_variant('exp', ['-DVINET_EXPERIMENTS'])")
+  if (name && value && (!strcmp(name, "epi_rows") || !strcmp(name, "ht32") || (!strcmp(name, "bn_lean") && value == 2))) {
+    vinet_set_error("set_option: %s=%d needs a -DVINET_EXPERIMENTS build of the library", name, value);
+    return -2;
+  }
+#endif
   if (name && !strcmp(name, "epi_rows")) { g_vinet_opt_epi_rows = value; return 0; }
   if (name && !strcmp(name, "pw_maxtn")) { g_vinet_opt_pw_maxtn = value; return 0; }
   if (name && !strcmp(name, "pp_pw_kt")) { g_vinet_opt_pp_pw_kt = value; return 0; }
@@ -219,7 +220,6 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "up_blk")) { g_vinet_opt_up_blk = value; return 0; }
   if (name && !strcmp(name, "n128_tile")) { g_vinet_opt_n128_tile = value; return 0; }
   if (name && !strcmp(name, "n128_kmax")) { g_vinet_opt_n128_kmax = value; return 0; }
-  if (name && !strcmp(name, "wgrad_cus")) { g_vinet_opt_wgrad_cus = value < 8 ? 8 : (value > 256 ? 256 : value); return 0; }
   if (name && !strcmp(name, "n64_kmax")) { g_vinet_opt_n64_kmax = value; return 0; }
   if (name && !strcmp(name, "n192_tile")) { g_vinet_opt_n192_tile = value; return 0; }
   if (name && !strcmp(name, "reduce_il")) { g_vinet_opt_reduce_il = value; return 0; }

@@ -231,7 +231,11 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     // consecutive lanes write the WNC * 2 contiguous bytes of a voxel.  Stored directly, a lane's 16 bytes sit next to only one
     // other lane's: 32-byte fragments, four instructions per 128-byte line -- the pointwise kernel ran at half the speed of its
     // own loads + MFMAs that way (conv_pw.h, profiles/r3_pw_ab.txt).  Row offsets: one voxel decode per lane, through LDS.
+#ifdef VINET_EXPERIMENTS
     const bool staged = MT <= 4 && a.epi_rows && !a.accumulate;
+#else
+    constexpr bool staged = false;      // (option epi_rows: measured neutral to slower, profiles/r3_epi_rows_ab.txt -- side builds only)
+#endif
     constexpr int PPR = WNC / 8, IMG_G = (PPR % 16 == 0) ? 16 : (PPR % 8 == 0) ? 8 : (PPR % 4 == 0) ? 4 : 2, IMG_P = 16 / IMG_G;
     auto img_swz = [](int row) { return (row / IMG_P) & (IMG_G - 1); };
     char* const img = (char*)Ew;

@@ -457,3 +457,16 @@ extern "C" int vinet_fill_f32(float* p, int64_t n, float value, void* stream) {
   hipLaunchKernelGGL(fill_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, (long)n, value);
   return vn_launch_status("fill_f32");
 }
+
+// Schedule-stress tool (tests / tools only): ONE wave that idles on its stream for ~`cycles` shader clocks.  Put in front of a
+// kernel it delays everything behind it on that stream without touching memory: the way to move a cross-stream schedule around
+// in EAGER mode and see whether results depend on it (tools/dbg_defer.py; the weight-gradient stream's ordering tests).
+__global__ void debug_spin_kernel(long cycles) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while ((long)(__builtin_amdgcn_s_memtime() - t0) < cycles) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int vinet_debug_spin(int64_t cycles, void* stream) {
+  VN_CHECK_ARG(cycles >= 0 && cycles <= (1L << 33), "debug_spin: cycles out of range (at most ~3.5 s)");
+  hipLaunchKernelGGL(debug_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long)cycles);
+  return vn_launch_status("debug_spin");
+}

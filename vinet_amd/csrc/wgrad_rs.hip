@@ -20,7 +20,6 @@
 //   * the grid is (kT x Cin/64) groups x workers; a worker keeps its accumulators over all its items and flushes
 //     once with fp32 atomics (dw is zero on entry).
 #include "common.h"
-extern int g_vinet_opt_wgrad_cus;
 
 struct WgradRsArgs {
   const char* x;
@@ -382,7 +381,7 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   a.items = d->dy.B * a.To;
   a.dTo = make_fastdiv((uint32_t)a.To);
   const int groups = a.kT * a.cchunks * a.nchunks;
-  int workers = g_vinet_opt_wgrad_cus / groups;       // one 512-thread workgroup per CU, never a second round; the cap leaves CUs to the main stream (conv_api.hip: wgrad_cus)
+  int workers = vn_wgrad_cus(d) / groups;       // one 512-thread workgroup per CU, never a second round; the caller's cap (VinetWgradDesc::max_cus) leaves CUs to its other stream
   if (workers < 1) workers = 1;
   if (workers > a.items) workers = a.items;
   a.workers = workers;

@@ -16,7 +16,6 @@
 //   * loads of frame t+1 are issued before the MFMAs of frame t (named registers, masked selects: wgrad_rs.hip);
 //   * grid = (channel chunks x output chunks) x workers, never more than one workgroup per CU; one atomic flush.
 #include "common.h"
-extern int g_vinet_opt_wgrad_cus;
 
 struct WgradTfArgs {
   const char* x;
@@ -230,7 +229,7 @@ int vinet_launch_wgrad_tf(const VinetWgradDesc* d, hipStream_t s) {
   a.items = d->dy.B * a.strips;
   a.dStrips = make_fastdiv((uint32_t)a.strips);
   const int groups = a.cchunks * a.nchunks;
-  int workers = g_vinet_opt_wgrad_cus / groups;
+  int workers = vn_wgrad_cus(d) / groups;       // one 512-thread workgroup per CU, never a second round; the caller's cap (VinetWgradDesc::max_cus) leaves CUs to its other stream
   if (workers < 1) workers = 1;
   if (workers > a.items) workers = a.items;
   a.workers = workers;

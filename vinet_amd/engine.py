@@ -40,10 +40,9 @@ _WEIGHTS_EPOCH = 0
 ROW_ALIGN = int(os.environ.get("VINET_ROW_ALIGN", "0"))      # bytes; 0 = dense rows.  128 measured neutral on the whole step
 STEM_FOLD = os.environ.get("VINET_STEM_FOLD", "1") != "0"   # padded/folded stem input (A/B switch)
 WGRAD_SIDE_STREAM = True
-# CUs the persistent weight-gradient kernels may occupy while they run beside the main stream (conv_api.hip: wgrad_cus);
+# CUs the persistent weight-gradient kernels may occupy while they run beside the main stream (VinetWgradDesc::max_cus, per launch);
 # without a second stream they are alone on the GPU and get all of it
 WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "208"))
-_WGRAD_CUS_SET = {}
 TAIL_WGRAD_FULL = os.environ.get("VINET_TAIL_WGRAD_FULL", "1") != "0"
 # cap of the decoder's (BatchNorm-less, deferred) weight gradients, which run beside the backward of the low-resolution encoder stages
 WGRAD_CUS_DEC = int(os.environ.get("VINET_WGRAD_CUS_DEC", str(WGRAD_CUS)))
@@ -110,6 +109,12 @@ SHARE_SKIP_GRAD = os.environ.get("VINET_SHARE_SKIP_GRAD", "1") != "0"
 DEFER_DECODER_WGRAD = int(os.environ.get("VINET_DEFER_DECODER_WGRAD", "1"))
 # packed weight-gradient workspaces owned by the conv plans and re-zeroed by vinet_unpack_wgrad (0 = a torch.zeros per conv and step)
 PERSISTENT_DW = int(os.environ.get("VINET_PERSISTENT_DW", "1"))
+# Schedule stress (tests / tools/dbg_defer.py): shader clocks a spin kernel idles on the weight-gradient stream in front of every
+# weight-gradient launch (DBG_SPIN_SIDE) / on the main stream in front of every data gradient (DBG_SPIN_MAIN).  The two streams
+# then drift apart by milliseconds in either direction; a result that depends on their relative timing shows up as a
+# gradient mismatch against the one-stream schedule.
+DBG_SPIN_SIDE = int(os.environ.get("VINET_DBG_SPIN_SIDE", "0"))
+DBG_SPIN_MAIN = int(os.environ.get("VINET_DBG_SPIN_MAIN", "0"))
 
 
 # VINET_ABLATE="vinet_conv3d_wgrad,vinet_bn_bwd_reduce,tag:dgrad": entry points (or call-site tags) whose launches are skipped -- how much
@@ -343,16 +348,25 @@ class Ctx:
         jobs, self._unpack_jobs = getattr(self, "_unpack_jobs", []), []
         if not jobs:
             return
-        key = tuple((j[0], j[1]) for j in jobs)
+        # A plan that ran twice in this backward (a module called twice in one forward) queued its job twice, but its
+        # persistent workspace already holds the SUM of both weight gradients: one job per workspace, or two thread
+        # groups of the launch would race on `grad += dw; dw = 0` over the same rows.
+        seen, uniq = set(), []
+        for j in jobs:
+            if j[0] not in seen:
+                seen.add(j[0])
+                uniq.append(j)
+        jobs = uniq
+        key = tuple(jobs)
         ent = _UNPACK_TABLES.get(key)
         if ent is None:
+            # (never evicted: a captured step has the table's address baked into its launch, and a table is a few KB)
+            assert not self.capturing, "weight-gradient unpack table built inside a stream capture (warm the step up first)"
             rows, off = [], 0
             for dw, gw, N, Cin, ntaps, stem, numel in jobs:
                 rows.append([dw, gw, N, Cin, ntaps, stem, off, 0])
                 off += numel
             rows.append([0, 0, 0, 0, 0, 0, off, 0])
-            if len(_UNPACK_TABLES) > 16:
-                _UNPACK_TABLES.clear()
             ent = _UNPACK_TABLES[key] = (torch.tensor(rows, dtype=torch.int64).to(self.device), off)
         table, total = ent
         side = self.side_stream()
@@ -369,14 +383,12 @@ class Ctx:
         self.side_used = False
         self._side_keep = []
         self._deferred = []
-        cus = WGRAD_CUS if self.side_stream() is not None else 256
-        if _WGRAD_CUS_SET.get("v") != cus:
-            self.lib.vinet_set_option(b"wgrad_cus", cus)
-            _WGRAD_CUS_SET["v"] = cus
         self._unpack_jobs = []
         self.capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        self._tape_left = len(self.tape)         # nodes still to run, the current one included
         for fn in reversed(self.tape):
             fn()
+            self._tape_left -= 1
         self.flush_deferred()
         self.flush_unpack()
         if getattr(self, "side_used", False):
@@ -1139,13 +1151,13 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                         wd.bnb_z, wd.bnb_ld, wd.bnb_sB, wd.bnb_fwd = zv.ptr(), zv.ld, zv.sB, zf
                         wd.bnb_mean, wd.bnb_invstd, wd.bnb_c1, wd.bnb_c2 = zm.data_ptr(), zi.data_ptr(), z1.data_ptr(), z2.data_ptr()
                     es = ESIZE[ctx.dt]
-                    # the conv whose input needs no gradient (the RGB stem) is the LAST node of the tape: nothing of the main stream
-                    # is left beside its weight gradient, which may take the whole chip
-                    tail = TAIL_WGRAD_FULL and side is not None and not x.needs_grad
-                    cap = 256 if (tail or side is None) else (WGRAD_CUS_DEC if bn is None else WGRAD_CUS)
-                    if _WGRAD_CUS_SET.get("v") != cap:
-                        ctx.lib.vinet_set_option(b"wgrad_cus", cap)
-                        _WGRAD_CUS_SET["v"] = cap
+                    # the LAST node of the tape (the RGB stem: its input needs no gradient, so nothing of the main stream is
+                    # left beside its weight gradient) may take the whole chip; any other conv without a data gradient (the first
+                    # SoundNet layer) still has main-stream work beside it and keeps the cap
+                    tail = TAIL_WGRAD_FULL and side is not None and not x.needs_grad and getattr(ctx, "_tape_left", 0) <= 1
+                    wd.max_cus = 256 if (tail or side is None) else (WGRAD_CUS_DEC if bn is None else WGRAD_CUS)
+                    if DBG_SPIN_SIDE and side is not None:
+                        ctx.lib.vinet_debug_spin(DBG_SPIN_SIDE, ctx.stream)
                     ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
                              tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
                              work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
@@ -1180,6 +1192,8 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
     # ---- data gradient -------------------------------------------------------------
     if x.needs_grad:
         xv = x.v
+        if DBG_SPIN_MAIN and ctx.device.type == "cuda":
+            ctx.lib.vinet_debug_spin(DBG_SPIN_MAIN, ctx.stream)
         phases, full = plan.dgrad_phases((xv.T, xv.H, xv.W), (out.T, out.H, out.W), ctx.device)
         ready = x.is_grad_ready()
         dx = x.grad_view(zero=(not ready and not full))

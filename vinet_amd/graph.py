@@ -52,7 +52,7 @@ class GraphedTrainStep:
         loss = step((clips,), gt)          # same shapes as at capture
     """
 
-    def __init__(self, model, optimizer, loss_fn, inputs, gt, warmup=2):
+    def __init__(self, model, optimizer, loss_fn, inputs, gt, warmup=2, debug_dot=None):
         assert all(t.is_cuda for t in inputs) and gt.is_cuda, "graph capture needs GPU tensors"
         self.model, self.opt, self.loss_fn = model.train(), optimizer, loss_fn
         self.static_in = [t.clone() for t in inputs]
@@ -98,6 +98,8 @@ class GraphedTrainStep:
             import copy
             opt.load_state_dict(copy.deepcopy(snap_sd))
         self.graph = torch.cuda.CUDAGraph()
+        if debug_dot:                          # hipGraphDebugDotPrint of the captured step (tools/dbg_defer.py)
+            self.graph.enable_debug_mode()
         # (a garbage collection inside the capture could drop plans from the pack registry, whose job table would then be
         # rebuilt -- a host-to-device copy -- in the captured region)
         was_enabled = gc.isenabled()
@@ -108,6 +110,8 @@ class GraphedTrainStep:
         finally:
             if was_enabled:
                 gc.enable()
+        if debug_dot:
+            self.graph.debug_dump(debug_dot)
         for bn, pend in snap_pend:           # (the captured call ran the Python forward once: its host-side step count does not count)
             bn.__dict__["_vinet_pending"] = pend
 
