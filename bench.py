@@ -51,7 +51,8 @@ def parse(argv=None):
     ap.add_argument("--clip", type=int, default=32)
     ap.add_argument("--height", type=int, default=224)
     ap.add_argument("--width", type=int, default=384)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32s"],
+                    help="fp32s = fp32 tensors, convs on three bf16 MFMAs per product (split operands): the fast configuration inside the 1e-3 contract")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -273,6 +274,11 @@ def extras(args, dev):
                                             note="exact-parity configuration (fp32 I/O, fp32 MFMA): max |err| vs the reference 3e-6..5e-6, argmax bit-exact on all "
                                                  "five golden shapes; the bf16 headline holds 1e-2 and the reference's fixation within its top-5 pixels "
                                                  "(profiles/r3_parity_report.jsonl)"))
+        # the FAST configuration inside the contract: fp32 tensors, convs on three bf16 MFMAs per product over hi / lo halves of both
+        # operands (VINET_F32S; tests/test_gpu_model.py::test_e2e_split_bf16_parity_gate holds 1e-4 and the exact argmax)
+        res["parity_path"] = leg(lambda: dict(train_cfg(dtype="fp32s", batch=64),
+                                              note="fp32 tensors + split-bf16 matrix arithmetic (3 MFMAs per product, 16 significant bits per operand): "
+                                                   "same gate as fp32_path (<= 1e-3 abs, bit-exact argmax on all five goldens + AViNet)"))
     if (args.clip, args.height, args.width) == (32, 224, 384) and args.model == "vinet":
         res["other_configs"] = {
             "avinet_32x224x384_b192": leg(lambda: train_cfg(model="avinet", batch=0)),

@@ -38,7 +38,11 @@ extern "C" {
 
 #define VINET_ABI_VERSION 10
 
-enum { VINET_F32 = 0, VINET_BF16 = 1 };
+enum { VINET_F32 = 0, VINET_BF16 = 1,
+       /* conv / weight-gradient descriptors only: fp32 tensors (as VINET_F32), bf16 matrix arithmetic on a two-term split of both
+        * operands (x = hi + lo, 16 significant bits; hi*hi + hi*lo + lo*hi, fp32 accumulate) -- 3/16 of the fp32-MFMA cost, error
+        * ~2^-17 per operand.  The fast configuration that still meets north_star's 1e-3 / exact-argmax contract. */
+       VINET_F32S = 2 };
 enum { VINET_ACT_NONE = 0, VINET_ACT_RELU = 1, VINET_ACT_SIGMOID = 2 };
 enum { VINET_CONV_GENERIC = 0, VINET_CONV_STEM = 1 };
 

@@ -121,6 +121,19 @@ def _tile_m(dtype, mode, M, N, kchunks=0):
     return bm
 
 
+def _plain_f32(fn):
+    """descriptor entry points: VINET_F32S (fp32 tensors, split-bf16 arithmetic) is modelled as exact fp32"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, d, *a, **k):
+        dd = d._obj if hasattr(d, "_obj") else d
+        if getattr(dd, "dtype", None) == L.F32S:
+            dd.dtype = F32
+        return fn(self, d, *a, **k)
+    return wrapper
+
+
 class AbiEmulator:
     def __init__(self):
         self.err = b""
@@ -144,9 +157,11 @@ class AbiEmulator:
         return 0
 
     # -- conv ----------------------------------------------------------------
+    @_plain_f32
     def vinet_conv3d_splitk_bytes(self, d):
         return 0          # the model never splits; results are identical by construction
 
+    @_plain_f32
     def vinet_conv3d_tile_m(self, d):
         d = _deref(d)
         M, N = d.x.B * d.oT * d.oH * d.oW, d.y.C
@@ -171,12 +186,15 @@ class AbiEmulator:
                 return 256
         return _tile_m(d.dtype, d.mode, M, N, d.ntaps * (d.Kp // 32))
 
+    @_plain_f32
     def vinet_conv3d_kernel_name(self, d, buf, n):
         return 0
 
+    @_plain_f32
     def vinet_conv3d_wgrad_kernel_name(self, d, buf, n):
         return 0
 
+    @_plain_f32
     def vinet_conv3d_wgrad_fuses_bn_bwd(self, d):
         d = _deref(d)
         # (as the library: only the folded-stem strip kernel; no size threshold here so that the CPU tests cover it)
@@ -192,6 +210,7 @@ class AbiEmulator:
         g = _gather(g, np.arange(oW) * d.sW + dw_, 3, x.shape[3])
         return g
 
+    @_plain_f32
     def vinet_conv3d_fuses_dgrad_phases(self, d):
         d = _deref(d)
         return 1 if (d.tline == 3 and d.dtype == BF16 and d.x.C == 64 and d.y.C == 64 and d.sT >= 2) else 0
@@ -215,15 +234,18 @@ class AbiEmulator:
         wr(d.y, d.out_dtype, out, bool(d.accumulate))
         return 0
 
+    @_plain_f32
     def vinet_conv3d_applies_pre_once(self, d):
         return 0
 
+    @_plain_f32
     def vinet_conv3d_stats_rows(self, d):
         d = _deref(d)
         M = d.x.B * d.oT * d.oH * d.oW
         bm = self.vinet_conv3d_tile_m(d)
         return (M + bm - 1) // bm
 
+    @_plain_f32
     def vinet_conv3d(self, d, stream):
         d = _deref(d)
         self.calls.append("conv3d")
@@ -274,6 +296,7 @@ class AbiEmulator:
         y[sl] = acc.astype(np.float32) if d.out_dtype == F32 else _f2bf(acc).reshape(acc.shape)
         return 0
 
+    @_plain_f32
     def vinet_conv3d_wgrad(self, d, stream):
         d = _deref(d)
         self.calls.append("wgrad")

@@ -202,7 +202,7 @@ def e2e_case(tag, dev, tol=1e-4, argmax=True):
     return d, meta
 
 
-def train_step_case(dev, make_optimizer=None):
+def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5):
     from vinet_amd import loss as VL
     from vinet_amd import model as VM
     from vinet_amd import optim as VO
@@ -219,8 +219,8 @@ def train_step_case(dev, make_optimizer=None):
     pred = m(xd)
     loss0 = VL.kldiv(pred, gd)
     loss0.backward()
-    close(pred, z["pred"], 2e-5, "train pred")
-    close(loss0, z["loss0"], 1e-5, "train loss0")
+    close(pred, z["pred"], pred_tol, "train pred")
+    close(loss0, z["loss0"], loss_tol, "train loss0")
     # Gradients: with B=2 the deepest BatchNorms see 12 samples per channel and the
     # reference's own fp32 gradients sit ~1.5e-2 (relative) from the fp64 truth there.
     # Criterion: we must be as close to the fp64 oracle as the fp32 reference is.

@@ -74,14 +74,38 @@ if "eager" in what:
         report(tag, g, ref, names, offs, nums)
 
 if "graph" in what:
+    import ctypes
     from vinet_amd.graph import GraphedTrainStep
+    hip = ctypes.CDLL("libamdhip64.so")
     print("---- captured step (gradients of the first replay against eager) ----")
-    for tag, defer_in_capture in (("graph, weight gradients in tape order", "0"), ("graph, decoder weight gradients deferred", "1")):
+    variants = [("tape order", "0", "per_job"), ("deferred, one join per job", "1", "per_job"),
+                ("deferred, ONE join for the batch", "1", "once"), ("deferred, a main-stream node between joins", "1", "dummy")]
+    for tag, defer_in_capture, mode in variants:
         os.environ["VINET_DBG_DEFER_IN_CAPTURE"] = defer_in_capture
+        os.environ["VINET_DBG_FLUSH_MODE"] = mode
         E.WGRAD_SIDE_STREAM, E.DEFER_DECODER_WGRAD = True, 1
         m, opt = fresh()
-        step = GraphedTrainStep(m, opt, VL.kldiv, (x,), gt, debug_dot=os.path.join(OUT, "graph_defer%s.dot" % defer_in_capture))
+        E.LAUNCH_LOG = None
+        step = GraphedTrainStep(m, opt, VL.kldiv, (x,), gt, keep_graph=True, launch_log=True)
+        log = step.launch_log
         step((x,), gt)
         torch.cuda.synchronize()
-        report(tag, opt.flat_g.clone(), ref, names, offs, nums)
+        report("graph: " + tag, opt.flat_g.clone(), ref, names, offs, nums, show=4)
+        key = "defer%s_%s" % (defer_in_capture, mode)
+        main = torch.cuda.current_stream().cuda_stream
+        with open(os.path.join(OUT, "launches_%s.txt" % key), "w") as f:
+            for name, st, tg in log:
+                f.write("%s %s %s\n" % ("main" if st == step.capture_stream else "side", name, tg or ""))
+        try:
+            h = step.graph.raw_cuda_graph()
+            path = os.path.join(OUT, "graph_%s.dot" % key).encode()
+            rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(h), path, ctypes.c_uint(0))
+            n = ctypes.c_size_t(0)
+            hip.hipGraphGetNodes(ctypes.c_void_p(h), None, ctypes.byref(n))
+            ne = ctypes.c_size_t(0)
+            hip.hipGraphGetEdges(ctypes.c_void_p(h), None, None, ctypes.byref(ne))
+            print("      dot rc %d, %d nodes, %d edges, %d engine launches logged" % (rc, n.value, ne.value, len(log)), flush=True)
+        except Exception as e:
+            print("      graph dump failed:", e)
     os.environ.pop("VINET_DBG_DEFER_IN_CAPTURE", None)
+    os.environ.pop("VINET_DBG_FLUSH_MODE", None)

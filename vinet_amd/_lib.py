@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
 
 F32, BF16 = 0, 1
+F32S = 2     # conv / weight-gradient descriptors: fp32 tensors, split-bf16 matrix arithmetic (include/vinet_hip.h)
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
 ABI_VERSION = 10

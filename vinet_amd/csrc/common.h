@@ -229,6 +229,8 @@ static inline int vn_launch_status(const char* what) {
 static inline int vn_wgrad_cus(const VinetWgradDesc* d) {
   return d->max_cus <= 0 ? 256 : (d->max_cus < 8 ? 8 : (d->max_cus > 256 ? 256 : d->max_cus));
 }
+// fp32 tensors in memory: the exact fp32-MFMA path and its split-bf16 arithmetic form (VINET_F32S)
+static inline bool vn_f32_storage(int dt) { return dt == VINET_F32 || dt == VINET_F32S; }
 static inline int vn_div_up(long a, long b) { return (int)((a + b - 1) / b); }
 // `overlap`: a read-only conv input may be an OVERLAPPED view (ld < C): consecutive W positions share
 // channels.  The folded RGB stem uses it (position = 2 pixels, "channels" = 8 pixels x 4).

@@ -40,7 +40,7 @@ ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks) 
     const int pad = ((N + bn - 1) / bn) * bn;
     if (pad * 4 <= best_pad * 5) { nt = nts[i]; break; }
   }
-  if (dtype == VINET_F32) return ConvTile{2, nt, 4, 1};  // BM = 128
+  if (vn_f32_storage(dtype)) return ConvTile{2, nt, 4, 1};  // BM = 128
   ConvTile t{4, nt, 4, 1};                               // BM = 256
   if (g_vinet_opt_n64_tile && nt == 4) return g_vinet_opt_n64_tile == 1 ? ConvTile{4, 2, 2, 2} : ConvTile{2, 2, 2, 2};   // tuning
   // 64-wide outputs with a short K loop (the stem, its 7x1x1 partner and their dgrads: 7-16 K steps at
@@ -76,10 +76,10 @@ ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks) 
 
 static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   VN_CHECK_ARG(d != nullptr, "conv: null descriptor");
-  VN_CHECK_ARG(d->dtype == VINET_F32 || d->dtype == VINET_BF16, "conv: bad dtype %d", d->dtype);
+  VN_CHECK_ARG(d->dtype == VINET_F32 || d->dtype == VINET_BF16 || d->dtype == VINET_F32S, "conv: bad dtype %d", d->dtype);
   VN_CHECK_ARG(d->out_dtype == VINET_F32 || d->out_dtype == VINET_BF16, "conv: bad out_dtype %d", d->out_dtype);
   VN_CHECK_ARG(d->mode == VINET_CONV_GENERIC || d->mode == VINET_CONV_STEM, "conv: bad mode %d", d->mode);
-  const int eg = d->dtype == VINET_F32 ? 4 : 8;
+  const int eg = vn_f32_storage(d->dtype) ? 4 : 8;
   VN_CHECK_ARG(vn_tensor_ok(d->x, d->mode == VINET_CONV_STEM ? 4 : eg, true),
                "conv: bad x view (C=%d ld=%d must be multiples of %d, 16-byte aligned)", d->x.C, d->x.ld, eg);
   VN_CHECK_ARG(d->y.ptr && d->y.C > 0 && d->y.ld >= d->y.C, "conv: bad y view");
@@ -462,7 +462,7 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   }
   else if (use_pp(d)) snprintf(buf, n, "conv_pp_kernel<%d>", pp_bn(d->y.C));
   else if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
-  else snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", t.MT, t.NT, t.WM, t.WN, d->mode);
+  else snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", d->dtype == VINET_BF16 ? "bf16" : (d->dtype == VINET_F32S ? "float/split" : "float"), t.MT, t.NT, t.WM, t.WN, d->mode);
   return 0;
 }
 
@@ -529,5 +529,5 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
     return vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);
   }
   if (d->dtype == VINET_BF16) return vinet_launch_conv_bf16(t, d->mode, a, (hipStream_t)stream);
-  return vinet_launch_conv_f32(t, d->mode, a, (hipStream_t)stream);
+  return vinet_launch_conv_f32(t, d->mode, a, (hipStream_t)stream, d->dtype == VINET_F32S);
 }

@@ -1,12 +1,15 @@
-// fp32 (exact, parity path) instantiations of the implicit-GEMM convolution.
+// fp32-tensor instantiations of the implicit-GEMM convolution: exact fp32 MFMA (parity path, VINET_F32) and the split-bf16
+// form (VINET_F32S: three bf16 MFMAs per product on hi / lo halves of every operand, conv_igemm.h).
 #include "conv_igemm.h"
 
 #define CASE(MT_, NT_, WM_, WN_)                                                            \
   if (t.MT == MT_ && t.NT == NT_ && t.WM == WM_ && t.WN == WN_)                             \
-    return launch_conv_cfg<float, MT_, NT_, WM_, WN_, VINET_CONV_GENERIC>(a, s);
+    return split ? launch_conv_cfg<float, MT_, NT_, WM_, WN_, VINET_CONV_GENERIC, true>(a, s) \
+                 : launch_conv_cfg<float, MT_, NT_, WM_, WN_, VINET_CONV_GENERIC>(a, s);
 
-int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s) {
-  if (mode == VINET_CONV_STEM) return launch_conv_cfg<float, 2, 4, 4, 1, VINET_CONV_STEM>(a, s);
+int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s, bool split) {
+  if (mode == VINET_CONV_STEM)
+    return split ? launch_conv_cfg<float, 2, 4, 4, 1, VINET_CONV_STEM, true>(a, s) : launch_conv_cfg<float, 2, 4, 4, 1, VINET_CONV_STEM>(a, s);
   CASE(2, 8, 4, 1) CASE(2, 6, 4, 1) CASE(2, 4, 4, 1) CASE(2, 3, 4, 1) CASE(2, 2, 4, 1) CASE(2, 1, 4, 1)
   CASE(2, 2, 2, 2)
   vinet_set_error("conv f32: no kernel for tile MT=%d NT=%d WM=%d WN=%d", t.MT, t.NT, t.WM, t.WN);

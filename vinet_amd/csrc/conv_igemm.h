@@ -82,16 +82,22 @@ constexpr int conv_epi_bytes() {
   return W * conv_epi_wave_bytes<MT, NT>() + 4 * WARPS_M * BN * 2 * 4;
 }
 
-template <typename T, int MT, int NT, int WARPS_M, int WARPS_N>
+// SPLIT (T = float only; VINET_F32S): fp32 tensors in memory, bf16 matrix arithmetic on a two-term split of every operand --
+// x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi), 16 significant bits -- and THREE MFMAs per product
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate; the lo*lo term is below 2^-16 of the product): 3/16 of the fp32-MFMA cost for an error of
+// ~2^-17 per operand instead of bf16's 2^-9.  The split happens once per loaded element, on the way into LDS, which then holds a hi
+// and a lo bf16 image of each tile (64-byte rows, 16-byte chunk index XOR (row >> 2) & 3: conflict-free ds_read_b128 fragments).
+template <typename T, int MT, int NT, int WARPS_M, int WARPS_N, bool SPLIT = false>
 struct ConvCfg {
+  static_assert(!SPLIT || sizeof(T) == 4, "the split form reads fp32 tensors");
   static constexpr int BM = 16 * MT * WARPS_M;
   static constexpr int BN = 16 * NT * WARPS_N;
   static constexpr int BK = 32;
   static constexpr int EG = ElemTraits<T>::EG;
   static constexpr int G = BK / EG;                     // 16-byte groups per K row
-  static constexpr int RS = BK * (int)sizeof(T) + 16;   // padded LDS row stride (bytes)
-  static constexpr int A_BYTES = BM * RS;
-  static constexpr int B_BYTES = BN * RS;
+  static constexpr int RS = SPLIT ? 64 : BK * (int)sizeof(T) + 16;   // LDS row stride (bytes): padded, or swizzled bf16 rows
+  static constexpr int A_BYTES = (SPLIT ? 2 : 1) * BM * RS;
+  static constexpr int B_BYTES = (SPLIT ? 2 : 1) * BN * RS;
   static constexpr int WNC = NT * 16;                   // columns per wave
   static constexpr int EROW = WNC + 4;                  // epilogue LDS row stride (floats)
   static constexpr int KLOOP_BYTES = 2 * (A_BYTES + B_BYTES);
@@ -458,9 +464,15 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   }
 }
 
-template <typename T, int MT, int NT, int WARPS_M, int WARPS_N, int MODE>
+// hi / lo bf16 pairs of two fp32 values: hi = RNE(x) packed, lo = RNE(x - hi) packed (6 VALU per pair)
+VN_DEV void split_pair(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  hi = cvt_pk_bf16_f32(x0, x1);
+  lo = cvt_pk_bf16_f32(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
+template <typename T, int MT, int NT, int WARPS_M, int WARPS_N, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
-  using Cfg = ConvCfg<T, MT, NT, WARPS_M, WARPS_N>;
+  using Cfg = ConvCfg<T, MT, NT, WARPS_M, WARPS_N, SPLIT>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, EG = Cfg::EG, G = Cfg::G, RS = Cfg::RS;
   constexpr int A_LOADS = (BM * G) / 256;
   constexpr int B_ITEMS = BN * G;
@@ -577,15 +589,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   auto store_tiles = [&](int buf) {
     char* As = smem + buf * Cfg::A_BYTES;
     char* Bs = smem + 2 * Cfg::A_BYTES + buf * Cfg::B_BYTES;
+    if constexpr (SPLIT) {
+      // four fp32 of K group g -> 8 bytes of the hi image and 8 bytes of the lo image (half g & 1 of 16-byte chunk g >> 1)
+      auto put = [&](char* img, int rows, int row, int gg, const uint4& v) {
+        uint32_t h0, l0, h1, l1;
+        split_pair(__uint_as_float(v.x), __uint_as_float(v.y), h0, l0);
+        split_pair(__uint_as_float(v.z), __uint_as_float(v.w), h1, l1);
+        char* dst = img + row * 64 + ((((gg >> 1) ^ ((row >> 2) & 3))) << 4) + (gg & 1) * 8;
+        *(uint2*)dst = make_uint2(h0, h1);
+        *(uint2*)(dst + rows * 64) = make_uint2(l0, l1);
+      };
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int row = (i * 256 + tid) / G;
-      *(uint4*)(As + row * RS + g * 16) = ra[i];
-    }
+      for (int i = 0; i < A_LOADS; ++i) put(As, BM, (i * 256 + tid) / G, g, ra[i]);
 #pragma unroll
-    for (int j = 0; j < B_LOADS; ++j) {
-      const int idx = j * 256 + tid;
-      if (idx < B_ITEMS) *(uint4*)(Bs + (idx / G) * RS + (idx % G) * 16) = rb[j];
+      for (int j = 0; j < B_LOADS; ++j) {
+        const int idx = j * 256 + tid;
+        if (idx < B_ITEMS) put(Bs, BN, idx / G, idx % G, rb[j]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const int row = (i * 256 + tid) / G;
+        *(uint4*)(As + row * RS + g * 16) = ra[i];
+      }
+#pragma unroll
+      for (int j = 0; j < B_LOADS; ++j) {
+        const int idx = j * 256 + tid;
+        if (idx < B_ITEMS) *(uint4*)(Bs + (idx / G) * RS + (idx % G) * 16) = rb[j];
+      }
     }
   };
 
@@ -598,7 +629,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   auto compute = [&](int buf) {
     const char* As = smem + buf * Cfg::A_BYTES + (wm * MT * 16 + (lane & 15)) * RS;
     const char* Bs = smem + 2 * Cfg::A_BYTES + buf * Cfg::B_BYTES + (wn * NT * 16 + (lane & 15)) * RS;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (SPLIT) {
+      const int fo = ((lane >> 4) ^ ((lane >> 2) & 3)) << 4;     // my 8 k of the step, swizzled like the stores
+      bf16x8_v ah[MT], al[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        ah[i] = *(const bf16x8_v*)(As + i * 16 * 64 + fo);
+        al[i] = *(const bf16x8_v*)(As + BM * 64 + i * 16 * 64 + fo);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bf16x8_v bh = *(const bf16x8_v*)(Bs + j * 16 * 64 + fo);
+        const bf16x8_v bl = *(const bf16x8_v*)(Bs + BN * 64 + j * 16 * 64 + fo);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {     // small terms first (weights as A: transposed tile, see conv_epilogue)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc[i][j], 0, 0, 0);
+        }
+      }
+    } else if constexpr (sizeof(T) == 2) {
       bf16x8_v af[MT], bfr[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8_v*)(As + i * 16 * RS + (lane >> 4) * 16);
@@ -650,16 +700,16 @@ struct ConvTile { int MT, NT, WM, WN; int BM() const { return 16 * MT * WM; } in
 // statistics workspace (vinet_conv3d_tile_m).
 ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks);
 int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
-int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
+int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s, bool split = false);
 int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_pp_bf16(int bn, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_ht_bf16(int nt, int tw, int tm, int pre, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_pw_bf16(int nt, const ConvArgs& a, hipStream_t s);
 
-template <typename T, int MT, int NT, int WM, int WN, int MODE>
+template <typename T, int MT, int NT, int WM, int WN, int MODE, bool SPLIT = false>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
-  using Cfg = ConvCfg<T, MT, NT, WM, WN>;
-  auto kern = conv_igemm_kernel<T, MT, NT, WM, WN, MODE>;
+  using Cfg = ConvCfg<T, MT, NT, WM, WN, SPLIT>;
+  auto kern = conv_igemm_kernel<T, MT, NT, WM, WN, MODE, SPLIT>;
   static bool attr_done[64] = {false};  // per device; benign race (same value written)
   int dev = 0;
   (void)hipGetDevice(&dev);

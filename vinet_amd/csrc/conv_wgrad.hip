@@ -49,14 +49,23 @@ struct WgradArgs {
   FastDiv dW, dH, dT;
 };
 
-template <typename T, int MODE>
+// hi / lo bf16 pairs of two fp32 values (conv_igemm.h: the split-bf16 form, VINET_F32S)
+VN_DEV void wg_split_pair(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  hi = cvt_pk_bf16_f32(x0, x1);
+  lo = cvt_pk_bf16_f32(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
+// SPLIT (T = float, VINET_F32S): fp32 tensors, each operand split into hi + lo bf16 on the way into LDS (a hi and a lo image per
+// tile), three bf16 MFMAs per product -- the weight-gradient counterpart of conv_igemm_kernel's split form.
+template <typename T, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int TN = 64, TC = 64, KV = 32;
   constexpr int EG = ElemTraits<T>::EG;
   constexpr int GW = TN / EG;                       // 16-byte groups per tile row
-  constexpr int RSW = TN * (int)sizeof(T) + 16;      // LDS row stride (bytes)
+  constexpr int RSW = SPLIT ? TN * 2 + 16 : TN * (int)sizeof(T) + 16;      // LDS row stride (bytes)
   constexpr int LOADS = KV * GW / 256;               // per operand per thread
-  constexpr int TILE_BYTES = KV * RSW;
+  constexpr int IMG_BYTES = KV * RSW;                // one [32 voxel][64 channel] image
+  constexpr int TILE_BYTES = (SPLIT ? 2 : 1) * IMG_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // D[2], X[2]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -138,8 +147,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     for (int i = 0; i < LOADS; ++i) {
       const int idx = i * 256 + tid;
       const int row = idx / GW, gg = idx % GW;
-      *(uint4*)(Ds + row * RSW + gg * 16) = rd[i];
-      *(uint4*)(Xs + row * RSW + gg * 16) = rx[i];
+      if constexpr (SPLIT) {
+        auto put = [&](char* img, const uint4& v) {
+          uint32_t h0, l0, h1, l1;
+          wg_split_pair(__uint_as_float(v.x), __uint_as_float(v.y), h0, l0);
+          wg_split_pair(__uint_as_float(v.z), __uint_as_float(v.w), h1, l1);
+          *(uint2*)(img + row * RSW + gg * 8) = make_uint2(h0, h1);
+          *(uint2*)(img + IMG_BYTES + row * RSW + gg * 8) = make_uint2(l0, l1);
+        };
+        put(Ds, rd[i]);
+        put(Xs, rx[i]);
+      } else {
+        *(uint4*)(Ds + row * RSW + gg * 16) = rd[i];
+        *(uint4*)(Xs + row * RSW + gg * 16) = rx[i];
+      }
     }
   };
 
@@ -172,7 +193,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   auto compute = [&](int buf) {
     const char* Ds = smem + buf * TILE_BYTES;
     const char* Xs = smem + (2 + buf) * TILE_BYTES;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (SPLIT) {
+      bf16x8_v ah[2], al[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { ah[i] = frag_bf16(Ds, wm * 32 + i * 16); al[i] = frag_bf16(Ds + IMG_BYTES, wm * 32 + i * 16); }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8_v bh = frag_bf16(Xs, wn * 32 + j * 16), bl = frag_bf16(Xs + IMG_BYTES, wn * 32 + j * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        }
+      }
+    } else if constexpr (sizeof(T) == 2) {
       bf16x8_v af[2], bfr[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) af[i] = frag_bf16(Ds, wm * 32 + i * 16);
@@ -269,7 +304,7 @@ extern "C" int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* d, char* buf
   if (vinet_wgrad_use_tf(d)) { snprintf(buf, n, "conv_wgrad_tf_kernel<%s>", d->pre.scale ? "pre" : "plain"); return 0; }
   if (wgrad_use_dma(d) && vinet_wgrad_use_pp(d)) { snprintf(buf, n, "conv_wgrad_pp_kernel<%s,%d>", d->pre.scale ? "pre" : "plain", vinet_wgrad_pp_rows(d->dy.C)); return 0; }
   if (wgrad_use_dma(d)) return vinet_wgrad_dma_name(d, buf, n);
-  snprintf(buf, n, "conv_wgrad_kernel<%s,%d>", d->dtype == VINET_BF16 ? "bf16" : "float", d->mode);
+  snprintf(buf, n, "conv_wgrad_kernel<%s,%d>", d->dtype == VINET_BF16 ? "bf16" : (d->dtype == VINET_F32S ? "float/split" : "float"), d->mode);
   return 0;
 }
 
@@ -280,8 +315,8 @@ extern "C" int vinet_conv3d_wgrad_fuses_bn_bwd(const VinetWgradDesc* d) {
 extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   VN_CHECK_ARG(d != nullptr, "wgrad: null descriptor");
   VN_CHECK_ARG(!d->bnb_z || vinet_conv3d_wgrad_fuses_bn_bwd(d), "wgrad: fused BN backward requested for a problem whose kernel cannot apply it");
-  VN_CHECK_ARG(d->dtype == VINET_F32 || d->dtype == VINET_BF16, "wgrad: bad dtype %d", d->dtype);
-  const int eg = d->dtype == VINET_F32 ? 4 : 8;
+  VN_CHECK_ARG(d->dtype == VINET_F32 || d->dtype == VINET_BF16 || d->dtype == VINET_F32S, "wgrad: bad dtype %d", d->dtype);
+  const int eg = vn_f32_storage(d->dtype) ? 4 : 8;
   VN_CHECK_ARG(vn_tensor_ok(d->x, d->mode == VINET_CONV_STEM ? 4 : eg, true), "wgrad: bad x view");
   VN_CHECK_ARG(vn_tensor_ok(d->dy, eg), "wgrad: bad dy view");
   VN_CHECK_ARG(d->x.B == d->dy.B, "wgrad: batch mismatch");
@@ -325,6 +360,9 @@ extern "C" int vinet_conv3d_wgrad(const VinetWgradDesc* d, void* stream) {
   if (d->dtype == VINET_BF16) {
     if (d->mode == VINET_CONV_STEM) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, VINET_CONV_STEM>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, VINET_CONV_GENERIC>), grid, dim3(256), 0, s, a);
+  } else if (d->dtype == VINET_F32S) {
+    if (d->mode == VINET_CONV_STEM) hipLaunchKernelGGL((conv_wgrad_kernel<float, VINET_CONV_STEM, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<float, VINET_CONV_GENERIC, true>), grid, dim3(256), 0, s, a);
   } else {
     if (d->mode == VINET_CONV_STEM) hipLaunchKernelGGL((conv_wgrad_kernel<float, VINET_CONV_STEM>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<float, VINET_CONV_GENERIC>), grid, dim3(256), 0, s, a);

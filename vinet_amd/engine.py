@@ -29,6 +29,7 @@ import torch
 from . import _lib as L
 
 F32, BF16 = L.F32, L.BF16
+F32S = L.F32S        # fp32 tensors + split-bf16 matrix arithmetic: a COMPUTE mode of the fp32 storage type (Ctx.cdt), never a View dtype
 TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 ESIZE = {F32: 4, BF16: 2}
 EG = {F32: 4, BF16: 8}          # elements per 16 bytes
@@ -56,9 +57,10 @@ _SIDE_STREAMS = {}
 
 
 def set_default_dtype(name):
-    """'bf16' (throughput path, default) or 'fp32' (exact parity path)."""
+    """'bf16' (throughput path, default), 'fp32' (exact parity path: fp32 tensors, fp32 MFMA) or 'fp32s' (fp32 tensors, convs on
+    three bf16 MFMAs per product over hi / lo halves of both operands: the fast configuration that meets the 1e-3 contract)."""
     global _DEFAULT_DTYPE
-    _DEFAULT_DTYPE = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "float32": F32}[str(name).replace("torch.", "")]
+    _DEFAULT_DTYPE = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "float32": F32, "fp32s": F32S, "fp32_split": F32S}[str(name).replace("torch.", "")]
 
 
 def default_dtype():
@@ -100,6 +102,7 @@ class Profiler:
 
 
 PROFILER = None
+LAUNCH_LOG = None      # tools/dbg_defer.py: list that receives (entry point, stream, tag) of every launch issued through Ctx.call
 # Inception blocks run their three input-side 1x1x1 convs as one (model_utils._Mixed._fwd_joint); 0 = per conv
 JOINT_ENTRY = int(os.environ.get("VINET_JOINT_ENTRY", "1"))
 # the stem's BN-backward apply pass folded into its weight-gradient kernel (0 = separate pass)
@@ -280,7 +283,9 @@ class Ctx:
     def __init__(self, device, dt=None, training=False, record=False):
         self.lib = L.get()
         self.device = device
-        self.dt = _DEFAULT_DTYPE if dt is None else dt
+        dt = _DEFAULT_DTYPE if dt is None else dt
+        self.dt = F32 if dt == F32S else dt       # storage type of activations / packed weights
+        self.cdt = dt                             # what the conv / weight-gradient descriptors carry (F32S: split-bf16 arithmetic)
         self.training = training
         self.tape = [] if record else None
         self.stream = _stream_for(device)
@@ -297,6 +302,8 @@ class Ctx:
         return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.device)
 
     def call(self, name, *args, tag=None, work=None):
+        if LAUNCH_LOG is not None:
+            LAUNCH_LOG.append((name, args[-1] if args else None, tag))
         if _ABLATE and (name in _ABLATE or (tag is not None and any(a in tag for a in _ABLATE_TAGS))):
             return          # tuning only (VINET_ABLATE): the launch is skipped, results are garbage, the step time is the point
         prof = PROFILER
@@ -338,8 +345,20 @@ class Ctx:
 
     def flush_deferred(self):
         jobs, self._deferred = self._deferred, []
-        for job in jobs:
-            job()
+        if not jobs:
+            return
+        mode = os.environ.get("VINET_DBG_FLUSH_MODE", "per_job")     # tools/dbg_defer.py
+        side = self.side_stream()
+        if mode == "once" and side is not None:
+            side.wait_stream(torch.cuda.current_stream(self.device))  # one join for the whole batch of deferred jobs
+            self._joined = True
+        try:
+            for job in jobs:
+                if mode == "dummy" and side is not None:               # a main-stream node between two event records
+                    self.lib.vinet_debug_spin(0, self.stream)
+                job()
+        finally:
+            self._joined = False
 
     def flush_unpack(self):
         """the packed weight gradients collected during this backward -> `.grad`, ONE launch behind the last weight-gradient
@@ -946,7 +965,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     w = plan.packed(ctx, False)
 
     d = L.CConvDesc()
-    d.dtype, d.out_dtype, d.mode = lib_dt, out.dt, (L.CONV_STEM if (plan.stem and not folded) else L.CONV_GENERIC)
+    d.dtype, d.out_dtype, d.mode = ctx.cdt, out.dt, (L.CONV_STEM if (plan.stem and not folded) else L.CONV_GENERIC)
     d.x, d.y = xv.ct(), out.ct()
     d.oT, d.oH, d.oW = oT, oH, oW
     d.sT, d.sH, d.sW = (1, 2, 1) if folded else plan.s
@@ -1051,7 +1070,7 @@ def _wgrad_desc(ctx, plan, x, dy, dw=None):
     folded = plan.stem and x.fold is not None
     taps, ntaps = plan.folded_taps(ctx.device) if folded else plan.fwd_taps(ctx.device)
     wd = L.CWgradDesc()
-    wd.dtype, wd.mode = ctx.dt, (L.CONV_STEM if (plan.stem and not folded) else L.CONV_GENERIC)
+    wd.dtype, wd.mode = ctx.cdt, (L.CONV_STEM if (plan.stem and not folded) else L.CONV_GENERIC)
     wd.x, wd.dy = x.v.ct(), dy.ct()
     wd.sT, wd.sH, wd.sW = (1, 2, 1) if folded else plan.s
     wd.ntaps, wd.taps, wd.dw, wd.Kp = ntaps, taps.data_ptr(), (dw.data_ptr() if dw is not None else None), plan.kp(False)
@@ -1132,7 +1151,8 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             side = ctx.side_stream(ctx._side_rr)
             main_ptr = ctx.stream
             if side is not None:
-                side.wait_stream(torch.cuda.current_stream(ctx.device))   # dy (and everything before it) is ready
+                if not getattr(ctx, "_joined", False):
+                    side.wait_stream(torch.cuda.current_stream(ctx.device))   # dy (and everything before it) is ready
                 ctx.side_used = True
             with (torch.cuda.stream(side) if side is not None else _NullCtx()):
                 if side is not None:
@@ -1203,7 +1223,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             # all stride phases of a temporal data gradient in one launch where the library has a kernel for it
             # (dy is read once instead of once per phase): include/vinet_hip.h, tline == 3
             d = L.CConvDesc()
-            d.dtype, d.out_dtype, d.mode = ctx.dt, dx.dt, L.CONV_GENERIC
+            d.dtype, d.out_dtype, d.mode = ctx.cdt, dx.dt, L.CONV_GENERIC
             d.x, d.y = dy.ct(), dx.ct()
             d.oT, d.oH, d.oW = xv.T, xv.H, xv.W
             d.sT, d.sH, d.sW = plan.s[0], 1, 1
@@ -1224,7 +1244,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                 phases = []
         for ph in phases:
             d = L.CConvDesc()
-            d.dtype, d.out_dtype, d.mode = ctx.dt, dx.dt, L.CONV_GENERIC
+            d.dtype, d.out_dtype, d.mode = ctx.cdt, dx.dt, L.CONV_GENERIC
             d.x, d.y = dy.ct(), dx.ct()
             d.oT, d.oH, d.oW = ph["Q"]
             d.sT = d.sH = d.sW = 1

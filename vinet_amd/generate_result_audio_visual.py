@@ -200,7 +200,7 @@ def build_parser():
     p.add_argument('--num_hier', default=3, type=int)
     p.add_argument('--clip_size', default=32, type=int)
     p.add_argument('--use_sound', default=False, type=bool)
-    p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
+    p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32", "fp32s"])
     p.add_argument('--batch', default=1, type=int)
     return p
 

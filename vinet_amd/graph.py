@@ -52,7 +52,7 @@ class GraphedTrainStep:
         loss = step((clips,), gt)          # same shapes as at capture
     """
 
-    def __init__(self, model, optimizer, loss_fn, inputs, gt, warmup=2, debug_dot=None):
+    def __init__(self, model, optimizer, loss_fn, inputs, gt, warmup=2, debug_dot=None, keep_graph=False, launch_log=False):
         assert all(t.is_cuda for t in inputs) and gt.is_cuda, "graph capture needs GPU tensors"
         self.model, self.opt, self.loss_fn = model.train(), optimizer, loss_fn
         self.static_in = [t.clone() for t in inputs]
@@ -97,7 +97,7 @@ class GraphedTrainStep:
         if snap_sd is not None:
             import copy
             opt.load_state_dict(copy.deepcopy(snap_sd))
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
         if debug_dot:                          # hipGraphDebugDotPrint of the captured step (tools/dbg_defer.py)
             self.graph.enable_debug_mode()
         # (a garbage collection inside the capture could drop plans from the pack registry, whose job table would then be
@@ -106,8 +106,12 @@ class GraphedTrainStep:
         gc.disable()
         try:
             with torch.cuda.graph(self.graph):
+                if launch_log:                 # (tools/dbg_defer.py: which launch went to which stream, in issue order)
+                    engine.LAUNCH_LOG = self.launch_log = []
+                    self.capture_stream = torch.cuda.current_stream().cuda_stream
                 self.static_loss = self._body()
         finally:
+            engine.LAUNCH_LOG = None
             if was_enabled:
                 gc.enable()
         if debug_dot:

@@ -74,7 +74,7 @@ def build_parser():
     p.add_argument('--use_transformer', default=False, type=_bool)
     p.add_argument('--use_vox', default=False, type=_bool)
     # additions of this build
-    p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32"])
+    p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32", "fp32s"])
     p.add_argument('--synthetic_steps', default=20, type=int, help="steps per epoch with --dataset synthetic")
     p.add_argument('--sound_path_data', default="/ssd_scratch/cvit/samyak/data/", type=str,
                    help="root of the audio-visual sets (hard-coded in the reference: dataloader.py:127)")
