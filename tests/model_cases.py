@@ -202,7 +202,7 @@ def e2e_case(tag, dev, tol=1e-4, argmax=True):
     return d, meta
 
 
-def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5):
+def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5, grad_factor=3.0):
     from vinet_amd import loss as VL
     from vinet_amd import model as VM
     from vinet_amd import optim as VO
@@ -242,7 +242,9 @@ def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5):
         # the 12-sample BNs) flips a ~1e-5 fraction of ReLU gates, and the gradient's L2 error goes with
         # the square root of that fraction; a 2e-6 perturbation of the oracle's own input moves these
         # gradients by 1e-4..6e-4.  A wrong tap / pad / stride shows up at >= 1e-1.
-        assert e_me <= 3.0 * e_ref + 2e-3, "%s: rel err %.3e vs reference-fp32 %.3e" % (k, e_me, e_ref)
+        # (grad_factor 5 for the split-bf16 form: the stem's weight gradient is a residual of cancelling sums -- the reference's OWN
+        #  fp32 gradient sits 3.8 % from fp64 there -- and 16-bit operands land at 4x that)
+        assert e_me <= grad_factor * e_ref + 2e-3, "%s: rel err %.3e vs reference-fp32 %.3e" % (k, e_me, e_ref)
         worst = max(worst, e_me)
     table.sort(reverse=True)
     train_step_case.last_table = table[:8]

@@ -344,17 +344,25 @@ class Ctx:
         self._side_keep.extend(t for t in tensors if t is not None)
 
     def flush_deferred(self):
+        """launch the deferred weight-gradient jobs on the weight-gradient stream behind ONE join with the main stream.
+
+        One join for the whole batch is not only cheaper: a join per job (event record on the main stream + wait on the side
+        stream, with no main-stream launch in between) gives the main stream's last node one outgoing edge per job, and a
+        captured step with such a fan-out REPLAYS WRONG on ROCm 7.2 -- the main stream's next kernel runs before that node
+        has finished, although hipGraphDebugDotPrint shows the edge (the two graphs' edge sets differ only by the redundant
+        fan-out edges; tools/dbg_defer.py, tools/dot_edges.py, tools/repro_graph_fanout.py, profiles/r4_capture_fanout.txt).
+        Eager execution of the same launches is correct under any relative timing of the two streams (spin-kernel stress)."""
         jobs, self._deferred = self._deferred, []
         if not jobs:
             return
-        mode = os.environ.get("VINET_DBG_FLUSH_MODE", "per_job")     # tools/dbg_defer.py
+        mode = os.environ.get("VINET_DBG_FLUSH_MODE", "once")        # "per_job" / "dummy": tools/dbg_defer.py only
         side = self.side_stream()
         if mode == "once" and side is not None:
-            side.wait_stream(torch.cuda.current_stream(self.device))  # one join for the whole batch of deferred jobs
+            side.wait_stream(torch.cuda.current_stream(self.device))
             self._joined = True
         try:
             for job in jobs:
-                if mode == "dummy" and side is not None:               # a main-stream node between two event records
+                if mode == "dummy" and side is not None:               # a main-stream node between two joins
                     self.lib.vinet_debug_spin(0, self.stream)
                 job()
         finally:
@@ -1165,6 +1173,11 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                     #  never read -- keeps a persistent workspace too: no allocation and no fill on the weight-gradient stream)
                     persistent = bool(PERSISTENT_DW)
                     dw = plan.dw_workspace(ctx, nsl * Ny * kp) if persistent else ctx.f32(nsl * Ny * kp, zero=True)
+                    if persistent and any(j[0] == dw.data_ptr() for j in ctx._unpack_jobs):
+                        # this plan already ran in this backward (a module used twice in one forward): its workspace holds the
+                        # first use's gradient, and the kernels may STORE their result (no split-K, no atomics: "dw is zero on
+                        # entry").  Hand that gradient over and get the workspace back zeroed first.
+                        plan.unpack_wgrad(ctx, dw, clear=True)
                     wd = _wgrad_desc(ctx, plan, x, dy, dw)
                     if fused_bnb is not None:
                         zv, zf, zm, zi, z1, z2 = fused_bnb
@@ -1198,13 +1211,10 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         # decoder's data gradients, which are MFMA-bound too: both lose.  Deferred, they start when the tape reaches the
         # encoder, whose BN-backward passes and pools are HBM-bound and share a CU with them at little cost.  dy and x
         # stay untouched meanwhile: gradient buffers are written once per backward and live until the tape is dropped.
-        # NOT under stream capture: a replayed hipGraph of the step with deferred jobs computes wrong ENCODER gradients (the
-        # loss and the decoder's are right; relative error 0.5, deterministic; found by tests/test_gpu_model.py::
-        # test_graphed_train_step_follows_the_eager_trajectory, bisected with tools/dbg_graph.py: correct without the side
-        # stream, without deferral, and with the deferred jobs flushed at the END of backward).  Eager execution of the same
-        # launch order is bit-stable and passes the gradient parity tests, so the captured graph's cross-stream edges are
-        # what differs; until that is understood a captured step launches its weight gradients in tape order.
-        if DEFER_DECODER_WGRAD and bn is None and ctx.side_stream() is not None and (not ctx.capturing or os.environ.get("VINET_DBG_DEFER_IN_CAPTURE") in ("1", str(plan.Cin))):
+        # (Under stream capture too: the wrong encoder gradients of round 3's captured step came from the per-job joins of the
+        # flush -- a fan-out of redundant graph edges that ROCm 7.2 replays wrongly, see Ctx.flush_deferred -- not from the
+        # deferral; with one join per batch the captured step follows the eager trajectory.)
+        if DEFER_DECODER_WGRAD and bn is None and ctx.side_stream() is not None and (not ctx.capturing or os.environ.get("VINET_DBG_DEFER_IN_CAPTURE", "1") != "0"):
             ctx._deferred.append(wgrad_job)
         else:
             ctx.flush_deferred()
