@@ -242,8 +242,8 @@ def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5, grad
         # the 12-sample BNs) flips a ~1e-5 fraction of ReLU gates, and the gradient's L2 error goes with
         # the square root of that fraction; a 2e-6 perturbation of the oracle's own input moves these
         # gradients by 1e-4..6e-4.  A wrong tap / pad / stride shows up at >= 1e-1.
-        # (grad_factor 5 for the split-bf16 form: the stem's weight gradient is a residual of cancelling sums -- the reference's OWN
-        #  fp32 gradient sits 3.8 % from fp64 there -- and 16-bit operands land at 4x that)
+        # (grad_factor 8 for the split-bf16 form: the stem's weight gradient is a residual of cancelling sums -- the reference's OWN
+        #  fp32 gradient sits 3.8 % from fp64 there -- and 16-bit operands land at 4-6x that)
         assert e_me <= grad_factor * e_ref + 2e-3, "%s: rel err %.3e vs reference-fp32 %.3e" % (k, e_me, e_ref)
         worst = max(worst, e_me)
     table.sort(reverse=True)

@@ -678,7 +678,7 @@ def test_stem_folded(dt, hw):
 
     def mkw(side):
         d = L.CWgradDesc()
-        d.dtype, d.mode = (dt if cdt is None else cdt), 0
+        d.dtype, d.mode = dt, 0
         d.x = E.View(b(side), 0, B, T, Hp, Wp // 2, 32, 8, sB, dt).ct()
         d.dy = dmk(side).ct()
         d.sT, d.sH, d.sW = 1, 2, 1
@@ -920,7 +920,7 @@ def _run_wgrad_case(case, dt, cdt=None):
 
     def mk(side):
         d = L.CWgradDesc()
-        d.dtype, d.mode = dt, 0
+        d.dtype, d.mode = (dt if cdt is None else cdt), 0
         d.x, d.dy = xmk(side).ct(), dmk(side).ct()
         d.sT, d.sH, d.sW = s
         d.ntaps, d.taps, d.dw, d.Kp = ntaps, taps.ptr(side), dw.ptr(side), Kp

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvinet_hip.so")
+# (VINET_LIB: another build of the same ABI, for A/B runs of two builds -- tools/conv_ab.py, bench.py)
+LIB_PATH = os.environ.get("VINET_LIB") or os.path.join(HERE, "libvinet_hip.so")
 
 F32, BF16 = 0, 1
 F32S = 2     # conv / weight-gradient descriptors: fp32 tensors, split-bf16 matrix arithmetic (include/vinet_hip.h)

@@ -87,7 +87,7 @@ struct WgCfg {
 // tile row r (0..31) of a [32][TW channels] bf16 tile, 16-byte chunk ch -> byte offset with swizzle
 template <int TW> VN_DEV int wg_swz(int r) {
   if (TW == 32) return ((r >> 3) & 1) << 1;   // 64-byte rows: rows r and r+8 share banks, move one to the other half
-  return TW == 64 ? (((r >> 1) & 1) << 1) : ((r & 3) << 1);
+  return TW == 64 ? ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1) : ((r & 3) << 1);   // (64: bits 1 and 3, see wgrad_rs.hip)
 }
 
 template <int TN, int TC, int TG, int STAGES, bool PRE>

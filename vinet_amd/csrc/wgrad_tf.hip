@@ -29,7 +29,10 @@ struct WgradTfArgs {
   FastDiv dStrips;
 };
 
-VN_DEV int wtf_swz(int r) { return ((r >> 1) & 1) << 1; }
+// 128-byte rows: a 32-lane transpose read touches rows {a .. a+3, a+8 .. a+11}; rows of equal parity share a 128-byte half of the
+// 256-byte bank row, so bits 1 and 3 of the row pick one of its four 32-byte windows (bit 1 alone left rows r and r + 8 on
+// the same banks: a 2-way conflict on every ds_read_b64_tr_b16)
+VN_DEV int wtf_swz(int r) { return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1; }
 
 template <bool PRE, int NTW>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_tf_kernel(const WgradTfArgs a) {

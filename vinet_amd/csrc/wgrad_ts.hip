@@ -33,7 +33,10 @@ struct WgradTsArgs {
   FastDiv dPatches;
 };
 
-VN_DEV int wts_swz(int r) { return ((r >> 1) & 1) << 1; }   // = wg_swz<64> of wgrad_dma.hip
+// 128-byte rows: a 32-lane transpose read touches rows {a .. a+3, a+8 .. a+11}; rows of equal parity share a 128-byte half of the
+// 256-byte bank row, so bits 1 and 3 of the row pick one of its four 32-byte windows (bit 1 alone left rows r and r + 8 on
+// the same banks: a 2-way conflict on every ds_read_b64_tr_b16)
+VN_DEV int wts_swz(int r) { return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1; }   // = wg_swz<64> of wgrad_dma.hip
 
 template <bool PRE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_ts_kernel(const WgradTsArgs a) {
