@@ -151,6 +151,7 @@ int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s);
 extern int g_vinet_opt_conv_ts;
 extern int g_vinet_opt_wgrad_hs;
 extern int g_vinet_opt_wgrad_rs;
+extern int g_vinet_opt_wgrad_rs4;
 extern int g_vinet_opt_wgrad_tf;
 extern int g_vinet_opt_wgrad_skinny;
 extern int g_vinet_opt_bn_lean;
@@ -243,6 +244,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "conv_hs")) { g_vinet_opt_conv_hs = value; return 0; }
   if (name && !strcmp(name, "conv_ts")) { g_vinet_opt_conv_ts = value; return 0; }
   if (name && !strcmp(name, "wgrad_rs")) { g_vinet_opt_wgrad_rs = value; return 0; }
+  if (name && !strcmp(name, "wgrad_rs4")) { g_vinet_opt_wgrad_rs4 = value; return 0; }
   if (name && !strcmp(name, "wgrad_skinny")) { g_vinet_opt_wgrad_skinny = value; return 0; }
   if (name && !strcmp(name, "wgrad_tf")) { g_vinet_opt_wgrad_tf = value; return 0; }
   if (name && !strcmp(name, "wgrad_hs")) { g_vinet_opt_wgrad_hs = value; return 0; }

@@ -30,11 +30,18 @@ struct WgradRsArgs {
   int kT, cchunks, nchunks, Kp, N, Cin;
   int items, workers;          // items = B * To, workers per group
   FastDiv dTo;
+  float* dbg;
 };
 
 // 128-byte rows: a 32-lane transpose read touches rows {a .. a+3, a+8 .. a+11}; rows of equal parity share a 128-byte half of the
 // 256-byte bank row, so bits 1 and 3 of the row pick one of its four 32-byte windows (bit 1 alone left rows r and r + 8 on
 // the same banks: a 2-way conflict on every ds_read_b64_tr_b16)
+#ifdef VINET_CONV_TIMING
+// tuning build: per-workgroup cycle stamps of conv_wgrad_rsm_kernel (tools/wrs_phases.py): [grid][8] floats
+// {total, prologues, MFMA phases, barrier 1, write phases, barrier 2, steps, items}
+static float* g_wrs_dbg = nullptr;
+extern "C" void vinet_debug_wrs_ptr(float* p) { g_wrs_dbg = p; }
+#endif
 VN_DEV int wrs_swz(int r) { return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1; }
 
 template <int KS>              // W / 32: K steps per image row (1, 2 or 3)
@@ -262,12 +269,24 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rsm_kernel(const WgradRsArg
     const uint32_t m = on ? 0xffffffffu : 0u;
     return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
   };
+#ifdef VINET_CONV_TIMING
+  unsigned long long tm_pro = 0, tm_mma = 0, tm_b1 = 0, tm_wr = 0, tm_b2 = 0, tm_steps = 0, tm_items = 0;
+  const unsigned long long tm_start = __builtin_amdgcn_s_memtime();
+#define WRS_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define WRS_T(var)
+#endif
+#ifdef VINET_WRS_PRIO
+  // the second-dispatched half of the workgroup loses every arbitration (age) to the first: static priority for it
+  if (wave >= 4) __builtin_amdgcn_s_setprio(VINET_WRS_PRIO);
+#endif
   const int nsteps = (H + R - 1) / R;
 
   for (int item = worker; item < a.items; item += a.workers) {
     const int b = (int)fdiv((uint32_t)item, a.dTo);
     const int to = item - b * a.To;
     const int t = to * a.kT + kt;
+    WRS_T(t_item0);
     const char* xb = a.x + ((long)b * a.sBx + (long)t * H * WW * a.ldx + cx_off) * 2;      // + (y*W + w) * ldx * 2
     const char* db = a.dy + ((long)b * a.sBy + (long)to * H * WW * a.ldy + dn_off) * 2;
 
@@ -290,8 +309,12 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rsm_kernel(const WgradRsArg
       }
     __syncthreads();
 
+#ifdef VINET_CONV_TIMING
+    tm_pro += __builtin_amdgcn_s_memtime() - t_item0; ++tm_items;
+#endif
     int s_base = 0;                                          // slot of image row h0 - 1
     for (int st = 0; st < nsteps; ++st) {
+      WRS_T(t_s0);
       const int h0 = st * R;
       // ---- loads for the next step: x rows h0+R+1 .. h0+2R, dy rows h0+R .. h0+2R-1 ---------------------------------
       const bool more = st + 1 < nsteps;
@@ -304,6 +327,44 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rsm_kernel(const WgradRsArg
 
       // ---- MFMAs ------------------------------------------------------------------------------------------------------
       const char* dt = dyb + (st & 1) * DROW;
+#ifdef VINET_WRS_AHEAD     // experiment: reads of a K step before its MFMAs, reads of the next step before those (two register sets)
+      bf16x8_v fa[2][2], fb[2][9];
+      auto read_step = [&](int buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[buf][i] = frag_dy(dt, ks, (nh * 2 + i) * 16);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            union { bf16x8_v v; s16x4_v h[2]; } u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              int slot = s_base + f_r[ks][h] + kh;
+              slot -= slot >= RING ? RING : 0;
+              const int xp = f_w[ks][h] + kw;
+              const int col = ct * 16 + (lane & 3) * 4;
+              const int ch = (col >> 3) ^ wrs_swz(xp);
+              u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) s16x4_v*)(ring + slot * XROW + xp * 128 + ch * 16 + (col & 7) * 2));
+            }
+            fb[buf][kh * 3 + kw] = u.v;
+          }
+      };
+      read_step(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+          read_step((ks + 1) & 1, ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) mfma_bf16_acc(acc[t][i], fa[ks & 1][i], fb[ks & 1][t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         bf16x8_v af[2];
@@ -321,14 +382,26 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rsm_kernel(const WgradRsArg
               const int xp = f_w[ks][h] + kw;                // ring position of image column f_w + kw - 1
               const int col = ct * 16 + (lane & 3) * 4;
               const int ch = (col >> 3) ^ wrs_swz(xp);
+#ifdef VINET_WRS_NO_LDS      // ablation (tools/wrs_phases.py): MFMAs on whatever the registers hold, no fragment reads
+              (void)slot; (void)ch;
+              asm volatile("" : "=v"(u.h[h]));
+#else
               u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                   (__attribute__((address_space(3))) s16x4_v*)(ring + slot * XROW + xp * 128 + ch * 16 + (col & 7) * 2));
+#endif
             }
+#ifdef VINET_WRS_NO_MMA      // ablation: fragment reads only
+            asm volatile("" :: "v"(u.v), "v"(af[0]), "v"(af[1]));
+#else
 #pragma unroll
             for (int i = 0; i < 2; ++i) mfma_bf16_acc(acc[kh * 3 + kw][i], af[i], u.v);
+#endif
           }
       }
+#endif
+      WRS_T(t_s1);
       __syncthreads();
+      WRS_T(t_s2);
       if (more) {
         char* dn = dyb + ((st + 1) & 1) * DROW;
         if (p_ok[0]) {
@@ -343,9 +416,21 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rsm_kernel(const WgradRsArg
         }
       }
       s_base += R; s_base -= s_base >= RING ? RING : 0;
+      WRS_T(t_s3);
       __syncthreads();
+#ifdef VINET_CONV_TIMING
+      { const unsigned long long t_s4 = __builtin_amdgcn_s_memtime();
+        tm_mma += t_s1 - t_s0; tm_b1 += t_s2 - t_s1; tm_wr += t_s3 - t_s2; tm_b2 += t_s4 - t_s3; ++tm_steps; }
+#endif
     }
   }
+#ifdef VINET_CONV_TIMING
+  if (a.dbg && (tid & 63) == 0) {     // one row per wave
+    float* o = a.dbg + ((long)blockIdx.x * 8 + wave) * 8;
+    o[0] = (float)(__builtin_amdgcn_s_memtime() - tm_start); o[1] = (float)tm_pro; o[2] = (float)tm_mma; o[3] = (float)tm_b1;
+    o[4] = (float)tm_wr; o[5] = (float)tm_b2; o[6] = (float)tm_steps; o[7] = (float)tm_items;
+  }
+#endif
   mfma_drain();
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -358,6 +443,239 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rsm_kernel(const WgradRsArg
       }
 }
 
+
+// ---- round 4: the same row-streaming weight gradient with FOUR waves per workgroup -------------------------------------------
+// tools/wrs_phases.py (s_memtime stamps, ablation builds) on the 8-wave kernels above: a step's 54 MFMAs per wave (864 cycles of
+// matrix pipe, 1728 per SIMD with its two waves) take 3600 cycles; without the MFMAs 2400, without the fragment reads 1900 --
+// the two waves of a SIMD are bound by INSTRUCTION ISSUE: 66 transpose reads + ~190 address / wait instructions beside 54
+// MFMAs, 5.4 per MFMA where ~2 fit into an MFMA's shadow (reads issued ahead of their MFMAs: older waves 2140 cycles, younger
+// 3190; static priority only swaps the two).  Here a wave owns 16 input channels x ALL 64 output channels x 9 taps (36
+// accumulator tiles, 144 registers): an x fragment feeds four MFMAs instead of two (0.72 transpose reads per MFMA instead of
+// 1.22), fragment addresses are two precomputed tables (row-in-ring offset, position offset) and one add per read, and a
+// 256-thread workgroup leaves room for a second one on the CU (two independent (tap, channel chunk) groups, or a main-stream
+// kernel beside the weight-gradient stream).  P = 32 KS positions per step = R image rows of WW (R = 1: W = 32, 64, 96;
+// R = 2, 4: W = 48, 24).
+template <int KS, int WW>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_rs4_kernel(const WgradRsArgs a) {
+  constexpr int P = KS * 32, R = P / WW, RING = R + 2;
+  static_assert(R * WW == P && R >= 1, "whole rows per step");
+  constexpr int XROW = (WW + 2) * 128, DROW = P * 128;
+  constexpr int PPT = KS;                           // 16-byte pieces of a step's x rows (and of its dy tile) per thread: P * 8 / 256
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;                                // RING x rows
+  char* dyb = smem + RING * XROW;                   // 2 dy tiles
+  const int tid = threadIdx.x, lane = tid & 63, ct = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int groups = a.kT * a.cchunks * a.nchunks;
+  const int grp = blockIdx.x % groups, worker = blockIdx.x / groups;
+  const int n0 = (grp % a.nchunks) * 64;
+  const int gc = grp / a.nchunks;
+  const int kt = gc / a.cchunks, c0 = (gc - kt * a.cchunks) * 64;
+  const int l_chunk = tid & 7;
+  const int H = a.H;
+  const bool cx_ok = c0 + l_chunk * 8 < a.Cin, dn_ok = n0 + l_chunk * 8 < a.N;
+  const int cx_off = cx_ok ? c0 + l_chunk * 8 : 0, dn_off = dn_ok ? n0 + l_chunk * 8 : 0;
+
+  // piece roles: piece q = tid + 256 j -> tile position q >> 3 = (row pr, column pw), chunk q & 7 (= tid & 7)
+  int x_in[PPT], d_off[PPT], g_pos[PPT], p_r[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int pos = (tid + 256 * j) >> 3;
+    const int pr = pos / WW, pw = pos - pr * WW;
+    g_pos[j] = pos; p_r[j] = pr;
+    x_in[j] = (pw + 1) * 128 + ((l_chunk ^ wrs_swz(pw + 1)) * 16);
+    d_off[j] = pos * 128 + ((l_chunk ^ wrs_swz(pos)) * 16);
+  }
+  for (int i = tid; i < RING * 2 * 8; i += 256) {            // zero pad positions of every ring row, once
+    const int row = i / 16, side = (i >> 3) & 1, ch = i & 7;
+    *(uint4*)(ring + row * XROW + (side ? (WW + 1) * 128 : 0) + ch * 16) = make_uint4(0, 0, 0, 0);
+  }
+  // fragment tables of this lane.  K-major fragments: 8 positions x 1 channel per lane, two transpose reads (h) of 4 positions.
+  //   x : address = ring + slot(row f_r + kh) * XROW + xa[ks][h][kw]     (position f_w + kw of the ring row, swizzled chunk)
+  //   dy: address = tile + da[ks][h] + (((2 i + db) ^ ds[ks][h]) << 4)   (column tile i of the 64 output channels)
+  const int p = lane & 15, q = lane >> 4;
+  int f_r[KS][2], xa[KS][2][3], da[KS][2], ds[KS][2];
+  const int db = (p & 3) >> 1;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pos = ks * 32 + q * 8 + h * 4 + (p >> 2);
+      const int fr = pos / WW, fw = pos - fr * WW;
+      f_r[ks][h] = fr;
+      const int col = ct * 16 + (p & 3) * 4;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) xa[ks][h][kw] = (fw + kw) * 128 + (((col >> 3) ^ wrs_swz(fw + kw)) * 16) + (col & 7) * 2;
+      da[ks][h] = pos * 128 + ((p & 3) & 1) * 8;
+      ds[ks][h] = wrs_swz(pos);
+    }
+
+  f32x4_v acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+
+  auto keep = [](uint4 v, bool on) -> uint4 {
+    const uint32_t m = on ? 0xffffffffu : 0u;
+    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+  };
+  auto tr_read = [](const char* ptr) -> s16x4_v {
+#ifdef VINET_WRS_NO_LDS      // ablation (tools/wrs_phases.py): MFMAs on whatever the registers hold
+    s16x4_v r;
+    asm volatile("" : "=v"(r) : "v"(ptr));
+    return r;
+#else
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)ptr);
+#endif
+  };
+#ifdef VINET_CONV_TIMING
+  unsigned long long tm_pro = 0, tm_mma = 0, tm_b1 = 0, tm_wr = 0, tm_b2 = 0, tm_steps = 0, tm_items = 0;
+  const unsigned long long tm_start = __builtin_amdgcn_s_memtime();
+#endif
+  const int nsteps = (H + R - 1) / R;
+
+  for (int item = worker; item < a.items; item += a.workers) {
+    const int b = (int)fdiv((uint32_t)item, a.dTo);
+    const int to = item - b * a.To;
+    const int t = to * a.kT + kt;
+    WRS_T(t_item0);
+    const char* xb = a.x + ((long)b * a.sBx + (long)t * H * WW * a.ldx + cx_off) * 2;      // + (y*W + w) * ldx * 2
+    const char* db_ = a.dy + ((long)b * a.sBy + (long)to * H * WW * a.ldy + dn_off) * 2;
+
+    // ---- prologue: image rows -1 (zero) and 0..R into slots 0..R+1 (slot of row y = (y + 1) % RING), dy rows 0..R-1
+    for (int e = tid; e < (R + 1) * WW * 8; e += 256) {
+      const int pos = e >> 3, ch = e & 7;                     // (e & 7 == l_chunk)
+      const int y = pos / WW, w = pos - y * WW;
+      uint4 v = *(const uint4*)(xb + (long)(y < H ? pos : 0) * a.ldx * 2);
+      v = keep(v, y < H && cx_ok);
+      *(uint4*)(ring + (y + 1) * XROW + (w + 1) * 128 + ((ch ^ wrs_swz(w + 1)) * 16)) = v;
+    }
+    for (int e = tid; e < WW * 8; e += 256)
+      *(uint4*)(ring + ((e >> 3) + 1) * 128 + (((e & 7) ^ wrs_swz((e >> 3) + 1)) * 16)) = make_uint4(0, 0, 0, 0);     // row -1
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const bool in = p_r[j] < H && dn_ok;
+      const uint4 v = *(const uint4*)(db_ + (long)(in ? g_pos[j] : 0) * a.ldy * 2);
+      *(uint4*)(dyb + d_off[j]) = keep(v, in);
+    }
+    __syncthreads();
+
+#ifdef VINET_CONV_TIMING
+    tm_pro += __builtin_amdgcn_s_memtime() - t_item0; ++tm_items;
+#endif
+    int s_base = 0;                                          // slot of image row h0 - 1
+    for (int st = 0; st < nsteps; ++st) {
+      WRS_T(t_s0);
+      const int h0 = st * R;
+      // ---- loads for the next step: x rows h0+R+1 .. h0+2R, dy rows h0+R .. h0+2R-1 ---------------------------------
+      const bool more = st + 1 < nsteps;
+      uint4 nx[PPT], nd[PPT];
+      bool xi[PPT], di[PPT];
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        xi[j] = more && cx_ok && h0 + R + 1 + p_r[j] < H;
+        di[j] = more && dn_ok && h0 + R + p_r[j] < H;
+        nx[j] = *(const uint4*)(xb + (long)(xi[j] ? (h0 + R + 1) * WW + g_pos[j] : 0) * a.ldx * 2);
+        nd[j] = *(const uint4*)(db_ + (long)(di[j] ? (h0 + R) * WW + g_pos[j] : 0) * a.ldy * 2);
+      }
+      // ---- MFMAs: per K step the four dy fragments, then per kernel row kh three x fragments and their twelve MFMAs; the
+      // reads of a batch are issued before the MFMAs of the batch in front of it ------------------------------------------
+      const char* dt = dyb + (st & 1) * DROW;
+      int srow[2][3];                                        // ring row offsets of the K step being read: image row h0 + f_r + kh - 1
+      auto rows_of = [&](int ks) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            int slot = s_base + f_r[ks][h] + kh;
+            slot -= slot >= RING ? RING : 0;
+            srow[h][kh] = slot * XROW;
+          }
+      };
+      union Frag { bf16x8_v v; s16x4_v h[2]; };
+      Frag fa[4], fb[2][3];
+      auto read_dy = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) fa[i].h[h] = tr_read(dt + da[ks][h] + (((2 * i + db) ^ ds[ks][h]) << 4));
+      };
+      auto read_x = [&](int buf, int ks, int kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) fb[buf][kw].h[h] = tr_read(ring + srow[h][kh] + xa[ks][h][kw]);
+      };
+      rows_of(0);
+      read_dy(0);
+      read_x(0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b3 = 0; b3 < KS * 3; ++b3) {                  // batch = (ks, kh)
+        const int ks = b3 / 3, kh = b3 % 3;
+        if (b3 + 1 < KS * 3) {
+          if (kh == 2) rows_of(ks + 1);
+          read_x((b3 + 1) & 1, (b3 + 1) / 3, (b3 + 1) % 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#ifdef VINET_WRS_NO_MMA      // ablation: fragment reads only
+            asm volatile("" :: "v"(fa[i].v), "v"(fb[b3 & 1][kw].v));
+#else
+            mfma_bf16_acc(acc[kh * 3 + kw][i], fa[i].v, fb[b3 & 1][kw].v);
+#endif
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kh == 2 && ks + 1 < KS) {                        // (behind the K step's last MFMAs: they have read fa long before LDS answers)
+          read_dy(ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      WRS_T(t_s1);
+      __syncthreads();
+      WRS_T(t_s2);
+      if (more) {
+        char* dn = dyb + ((st + 1) & 1) * DROW;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          int sl = s_base + p_r[j]; sl -= sl >= RING ? RING : 0;       // new row h0+R+1+pr replaces row h0-1+pr
+          *(uint4*)(ring + sl * XROW + x_in[j]) = keep(nx[j], xi[j]);
+          *(uint4*)(dn + d_off[j]) = keep(nd[j], di[j]);
+        }
+      }
+      s_base += R; s_base -= s_base >= RING ? RING : 0;
+      WRS_T(t_s3);
+      __syncthreads();
+#ifdef VINET_CONV_TIMING
+      { const unsigned long long t_s4 = __builtin_amdgcn_s_memtime();
+        tm_mma += t_s1 - t_s0; tm_b1 += t_s2 - t_s1; tm_wr += t_s3 - t_s2; tm_b2 += t_s4 - t_s3; ++tm_steps; }
+#endif
+    }
+  }
+#ifdef VINET_CONV_TIMING
+  if (a.dbg && (tid & 63) == 0) {     // one row per wave
+    float* o = a.dbg + ((long)blockIdx.x * 4 + ct) * 8;
+    o[0] = (float)(__builtin_amdgcn_s_memtime() - tm_start); o[1] = (float)tm_pro; o[2] = (float)tm_mma; o[3] = (float)tm_b1;
+    o[4] = (float)tm_wr; o[5] = (float)tm_b2; o[6] = (float)tm_steps; o[7] = (float)tm_items;
+  }
+#endif
+  mfma_drain();
+  // dw[kt*9 + tap][n0 + n][c0 + c]: n = i*16 + (lane>>4)*4 + r, c = ct*16 + (lane & 15)
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = i * 16 + (lane >> 4) * 4 + r, c = c0 + ct * 16 + (lane & 15);
+        if (n0 + n < a.N && c < a.Cin) atomicAdd(a.dw + ((long)(kt * 9 + t) * a.N + n0 + n) * (long)a.Kp + c, acc[t][i][r]);
+      }
+}
+
+int g_vinet_opt_wgrad_rs4 = 1;  // the four-wave form for W = 24, 48, 32, 64, 96 (0 = the eight-wave kernels above)
 int g_vinet_opt_wgrad_rs = 1;   // 0 = off, 2 = force on every eligible shape (tests)
 
 // VinetWgradDesc::tline == 4: the caller promises taps (kt, kh-1, kw-1, slice (kt*3 + kh)*3 + kw), kt < ntaps / 9
@@ -383,11 +701,41 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   a.kT = d->ntaps / 9; a.cchunks = (d->x.C + 63) / 64; a.nchunks = (d->dy.C + 63) / 64; a.Kp = d->Kp; a.N = d->dy.C; a.Cin = d->x.C;
   a.items = d->dy.B * a.To;
   a.dTo = make_fastdiv((uint32_t)a.To);
+  a.dbg = nullptr;
+#ifdef VINET_CONV_TIMING
+  a.dbg = g_wrs_dbg;
+#endif
   const int groups = a.kT * a.cchunks * a.nchunks;
   int workers = vn_wgrad_cus(d) / groups;       // one 512-thread workgroup per CU, never a second round; the caller's cap (VinetWgradDesc::max_cus) leaves CUs to its other stream
   if (workers < 1) workers = 1;
   if (workers > a.items) workers = a.items;
   a.workers = workers;
+  if (g_vinet_opt_wgrad_rs4 && (a.W == 24 || a.W == 48 || a.W == 32 || a.W == 64 || a.W == 96)) {
+    const int ks4 = (a.W == 24 || a.W == 48) ? 3 : a.W / 32;
+    const int rows = ks4 * 32 / a.W;
+    const int smem4 = (rows + 2) * (a.W + 2) * 128 + 2 * ks4 * 32 * 128;
+    int w4 = 2 * vn_wgrad_cus(d) / groups;       // two 256-thread workgroups per CU
+    if (w4 < 1) w4 = 1;
+    if (w4 > a.items) w4 = a.items;
+    a.workers = w4;
+    auto launch4 = [&](auto kern) -> int {
+      static bool attr_done[64] = {false};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (!attr_done[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(wgrad_rs4): %s", hipGetErrorString(e)); return (int)e; }
+        attr_done[dev & 63] = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(groups * w4), dim3(256), smem4, s, a);
+      return vn_launch_status("conv_wgrad_rs4");
+    };
+    if (a.W == 48) return launch4(conv_wgrad_rs4_kernel<3, 48>);
+    if (a.W == 24) return launch4(conv_wgrad_rs4_kernel<3, 24>);
+    if (a.W == 32) return launch4(conv_wgrad_rs4_kernel<1, 32>);
+    if (a.W == 64) return launch4(conv_wgrad_rs4_kernel<2, 64>);
+    return launch4(conv_wgrad_rs4_kernel<3, 96>);
+  }
   const bool multi = a.W == 48 || a.W == 24;
   const int ks = multi ? 3 : a.W / 32;
   const int ringrows = multi ? 96 / a.W + 2 : 3;
