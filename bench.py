@@ -33,6 +33,7 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
 TRAIN_WORK = {(32, 224, 384): (675.0, 3014.7), (64, 256, 448): (1800.0, 7994.0), (8, 128, 192): (48.1, 219.0), (8, 224, 384): (168.5, 767.0)}
 STEP_MB_PER_GPU = 1119.6
 SWEEP_BATCHES = (1, 2, 4, 8, 16, 32)
+GLOBAL_BATCH_SWEEP = (64, 256, 1536)      # N > 1: global batches of the data-parallel sweep (8 / 32 / 192 clips per GPU at N = 8)
 # forward work per clip (inference): (clip, height, width) -> (GFLOP, MB)
 INFER_WORK = {(32, 224, 384): (229.32, 1004.9), (64, 256, 448): (611.5, 2664.8), (8, 128, 192): (16.36, 73.0), (8, 224, 384): (57.25, 255.5)}
 
@@ -315,6 +316,7 @@ def measure(args, rank, world, dev):
         opt = optim.Adam(parallel.trainable_parameters(m), lr=1e-4)
         parallel.broadcast_parameters(opt)
         buckets = parallel.GradientBuckets(opt)      # N > 1: bucketed RCCL all-reduce issued from the tape, overlapped with backward
+        buckets.timing = True                        # (two HIP events per 25 MB bucket: issue / completion stamps in the result line)
 
         def train_step(ins, g_):
             opt.zero_grad()
@@ -402,6 +404,32 @@ def measure(args, rank, world, dev):
     if parallel.distributed():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)
+    # N > 1 (or VINET_FORCE_COLLECTIVES=1): the gradient exchange of the LAST timed step -- per 25 MB bucket when its all-reduce
+    # was issued and when it completed (ms from the start of the step), and how much of the exchange lay inside the backward pass
+    comm = buckets.timeline() if (args.mode == "train" and parallel.distributed()) else None
+    # ... and the same step at the global batches config 3 will really see (train.py:43 defaults to 8; a DHF1K epoch is 600 clips):
+    # 64, 256 and 1536 clips over all ranks, i.e. 8 / 32 / 192 per GPU at N = 8
+    gsweep = None
+    if args.mode == "train" and parallel.distributed() and not args.no_sweep:
+        gsweep = {}
+        for G in GLOBAL_BATCH_SWEEP:
+            b = G // world
+            if G % world or b < 1 or b >= B:
+                continue
+            xs = x[:b].contiguous()
+            ins = (xs, inputs[1][:b].contiguous()) if av else (xs,)
+            gs = gt[:b].contiguous()
+            train_step(ins, gs)
+            sync()
+            t0s = time.perf_counter()
+            for _ in range(args.sweep_steps):
+                train_step(ins, gs)
+            sync()
+            el = torch.tensor([time.perf_counter() - t0s], dtype=torch.float64, device=dev)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            tl = buckets.timeline()
+            gsweep[str(G)] = dict(clips_per_s=G * args.sweep_steps / float(el), local_batch=b, ms_per_step=1e3 * float(el) / args.sweep_steps,
+                                  allreduce_hidden_frac=None if tl is None else tl["hidden_frac"])
     if graphed:   # roofline of the dominant kernel from the eager profile call
         prof.records = [r for r in engine.Profiler().records]
         domtab = {k: v for k, v in table.items() if k in kernels[dom]["sites"]}
@@ -418,7 +446,7 @@ def measure(args, rank, world, dev):
     # ---- local-batch sweep of the same step ({1,2,4,8,16,32}), N = 1 training only
     # (each point eager -- one Python-issued launch per kernel -- and as a replayed hipGraph of the step, vinet_amd.graph)
     sweep, sweep_eager = None, None
-    if world == 1 and args.mode == "train" and not args.no_sweep:
+    if world == 1 and args.mode == "train" and not args.no_sweep and not parallel.distributed():
         from vinet_amd.graph import GraphedTrainStep
         sweep, sweep_eager = {}, {}
         import gc
@@ -524,6 +552,12 @@ def measure(args, rank, world, dev):
             "roofline": roof,
             "whole_step": None if whole is None else {"hbm_frac_of_8TBs": whole["frac"], "mfma_frac_of_2.5PF": whole["mfma_frac"]},
         }
+        if comm is not None:
+            out["allreduce"] = dict(comm, payload_mb=round(opt.flat_g.numel() * 4 / 1e6, 1), bucket_mb=25,
+                                    note="RCCL all-reduce (SUM) of the flat fp32 gradient buffer in reverse-order buckets, issued from inside "
+                                         "backward; hidden_frac = share of the summed all-reduce time that ended before backward did")
+        if gsweep:
+            out["global_batch_sweep"] = dict(unit="clips/s", steps_each=args.sweep_steps, global_batch=gsweep)
         if sweep is not None:
             sweep[str(B)] = value
             sweep_eager[str(B)] = value

@@ -758,16 +758,23 @@ def test_bench_self_spawn_path(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(VINET_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1", "--batch", "4",
-                          "--no-sweep", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1", "--batch", "72",
+                          "--sweep-steps", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1"
+    # the data-parallel extras of the line: per-bucket issue / completion stamps of the gradient exchange with the share hidden
+    # under backward, and the global-batch sweep (64 of {64, 256, 1536} fits under the 72 clips of this run)
+    ar = line["allreduce"]
+    assert len(ar["buckets"]) >= 4 and abs(sum(b["mb"] for b in ar["buckets"]) - ar["payload_mb"]) < 1.0
+    assert all(b["done_ms"] >= b["issue_ms"] >= 0 for b in ar["buckets"]) and 0.0 <= ar["hidden_frac"] <= 1.0
+    assert list(line["global_batch_sweep"]["global_batch"]) == ["64"] and line["global_batch_sweep"]["global_batch"]["64"]["clips_per_s"] > 0
     too_many = torch.cuda.device_count() + 1
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(too_many), "--steps", "1", "--warmup", "1"],
                          env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode == 2 and "GPU(s) visible" in bad.stderr, (bad.returncode, bad.stderr[-500:])
-    _note("bench_self_spawn", dict(clips_per_s=line["value"], refused_gpus=too_many))
+    _note("bench_self_spawn", dict(clips_per_s=line["value"], refused_gpus=too_many, allreduce_hidden_frac=ar["hidden_frac"],
+                                   backward_end_ms=ar["backward_end_ms"], buckets=ar["buckets"]))
 
 
 def test_weight_gradient_stream_does_not_change_the_gradients():

@@ -73,10 +73,41 @@ def _worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
+def _worker_graphed(rank, world, port, out):
+    """the captured-step wrapper under data parallelism: step = [zero_grad, forward, loss, backward] (a replayed hipGraph on a GPU,
+    the same calls eagerly on the ABI emulator) -> ONE all-reduce of the flat gradient buffer -> fused Adam with 1 / world"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from tests.abi_emulator import AbiEmulator
+    from vinet_amd import _lib as L
+    from vinet_amd import engine as E
+    from vinet_amd import loss as VL
+    from vinet_amd import optim as VO
+    from vinet_amd import parallel
+    from vinet_amd.graph import GraphedTrainStep
+    L._install_test_double(AbiEmulator())
+    E.set_default_dtype("fp32")
+    parallel.init_from_env(backend="gloo")
+    m = _build(seed=5 + rank)
+    ys, gt = _inputs(4)
+    lo, hi = parallel.shard_batch(4, rank, world)
+    opt = VO.Adam(m.parameters(), lr=1e-3)
+    parallel.broadcast_parameters(opt)
+    mine, gmine = tuple(y[lo:hi].contiguous() for y in ys), gt[lo:hi].contiguous()
+    step = GraphedTrainStep(m, opt, VL.kldiv, mine, gmine)
+    l = float(step(mine, gmine))
+    assert opt.grad_scale == 0.5
+    torch.save(dict(p=opt.flat_p.clone(), loss=l), os.path.join(out, "rank%d.pt" % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 @pytest.mark.slow
-def test_two_ranks_match_single_process(tmp_path):
+@pytest.mark.parametrize("worker", ["eager", "graphed_step"])
+def test_two_ranks_match_single_process(tmp_path, worker):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker if worker == "eager" else _worker_graphed, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
     assert torch.equal(r0["p"], r1["p"]), "replicas diverged"

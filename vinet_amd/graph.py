@@ -50,14 +50,25 @@ class GraphedTrainStep:
 
         step = GraphedTrainStep(model, optimizer, vinet_amd.loss.kldiv, (clips,), gt)
         loss = step((clips,), gt)          # same shapes as at capture
+
+    Data parallel (one process per GPU): the replayed graph leaves the local gradients in the optimizer's flat buffer; ONE
+    all-reduce of that buffer (parallel.allreduce_gradients: RCCL, 1 / world folded into Adam) runs between the replay and the
+    fused Adam launch.  At the batch sizes a captured step is for (1-8 clips per GPU, a ~20 ms step) the 124 MB exchange is
+    ~1.4 ms on a ring over xGMI: issued in one piece behind the graph it is not worth cutting the graph into segments for.
+    Without a GPU (host-logic tests on the ABI emulator) nothing is captured: the same call sequence runs eagerly.
     """
 
     def __init__(self, model, optimizer, loss_fn, inputs, gt, warmup=2, debug_dot=None, keep_graph=False, launch_log=False):
-        assert all(t.is_cuda for t in inputs) and gt.is_cuda, "graph capture needs GPU tensors"
+        self.capture = all(t.is_cuda for t in inputs) and gt.is_cuda
+        if not self.capture:
+            from . import _lib
+            assert _lib.is_test_double(), "graph capture needs GPU tensors"
         self.model, self.opt, self.loss_fn = model.train(), optimizer, loss_fn
         self.static_in = [t.clone() for t in inputs]
         self.static_gt = gt.clone()
         self._bns = [m for m in model.modules() if hasattr(m, "note_training_step")]
+        if not self.capture:
+            return
         # The warm-up steps are REAL steps (they have to be: they build weight packs, tap tables, persistent workspaces, LDS
         # attributes and autograd's own set-up), so everything they advance is snapshotted and put back: parameters, Adam
         # moments and step count, BatchNorm running statistics and the lazily counted num_batches_tracked.  A run that
@@ -126,13 +137,18 @@ class GraphedTrainStep:
         return loss.detach()
 
     def __call__(self, inputs, gt):
+        from . import parallel
         for dst, src in zip(self.static_in, inputs):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         if self.static_gt.data_ptr() != gt.data_ptr():
             self.static_gt.copy_(gt)
-        self.graph.replay()
-        for bn in self._bns:                 # (host-side bookkeeping the captured body did once: num_batches_tracked)
-            bn.note_training_step()
+        if self.capture:
+            self.graph.replay()
+            for bn in self._bns:             # (host-side bookkeeping the captured body did once: num_batches_tracked)
+                bn.note_training_step()
+        else:
+            self.static_loss = self._body()
+        parallel.allreduce_gradients(self.opt)     # N > 1: one RCCL all-reduce of the flat buffer (no-op on one rank)
         self.opt.step()
         return self.static_loss

@@ -143,6 +143,10 @@ class GradientBuckets:
         self._works, self._fired, self._members, self._launched = [], [], [], []
         self._seen, self._last_ctx = {}, None
         self._comm_streams = {}
+        # timing=True: per-bucket HIP events (issue / completion on the communication stream) and the backward pass's own
+        # extent on the main stream -> `timeline()` after finish(): how much of the exchange hid under backward
+        self.timing = False
+        self._ev = []
 
     def _add(self, lo, hi, members):
         for p in members:
@@ -167,6 +171,10 @@ class GradientBuckets:
         if self.active():
             engine.PARAM_GRAD_HOOK = self._on_param
         self.opt.grad_scale = 1.0 / dist.get_world_size() if self.active() else 1.0
+        self._ev, self._t0, self._t1 = [], None, None
+        if self.timing and self.active() and self.opt.flat_g.is_cuda:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record()
 
     def expect_reports(self, counts):
         """{id(param): number of tape nodes that write its gradient per backward} for models that use a parameter more than
@@ -205,7 +213,13 @@ class GradientBuckets:
             for side in (ctx.side_streams() if ctx is not None else []):
                 comm.wait_stream(side)                                    # the weight-gradient kernels launched so far
             with torch.cuda.stream(comm):
+                if self._t0 is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+                if self._t0 is not None:
+                    e1.record()
+                    self._ev.append((b, (hi - lo) * 4, e0, e1))
         else:
             self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
 
@@ -218,6 +232,9 @@ class GradientBuckets:
         engine.PARAM_GRAD_HOOK = None
         if not self.active():
             return
+        if getattr(self, "_t0", None) is not None:
+            self._t1 = torch.cuda.Event(enable_timing=True)       # end of the backward pass on the main stream
+            self._t1.record()
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b, self._last_ctx)
@@ -225,3 +242,20 @@ class GradientBuckets:
             w.wait()
         self._works = []
         self._last_ctx = None
+
+    def timeline(self):
+        """after finish() of a step taken with timing = True (and a device synchronisation): per bucket the issue and completion
+        time of its all-reduce in ms from begin_step(), the end of the backward pass, and the fraction of the summed all-reduce
+        time that lay inside the backward pass (hidden: the optimizer never waited for it)"""
+        if not self._ev or self._t0 is None or self._t1 is None:
+            return None
+        torch.cuda.synchronize()
+        bwd_end = self._t0.elapsed_time(self._t1)
+        rows, tot, hid = [], 0.0, 0.0
+        for b, nbytes, e0, e1 in self._ev:
+            t_is, t_done = self._t0.elapsed_time(e0), self._t0.elapsed_time(e1)
+            rows.append(dict(bucket=b, mb=round(nbytes / 1e6, 2), issue_ms=round(t_is, 3), done_ms=round(t_done, 3)))
+            tot += max(t_done - t_is, 0.0)
+            hid += max(min(t_done, bwd_end) - min(t_is, bwd_end), 0.0)
+        return dict(buckets=rows, backward_end_ms=round(bwd_end, 3), allreduce_ms=round(tot, 3),
+                    hidden_frac=(hid / tot if tot > 0 else None))
