@@ -30,6 +30,7 @@ def relerr(a, b):
 def blocks():
     from vinet_amd import model_utils as MU
     return {
+        "mixed_5b": lambda: MU.Mixed_5b(),
         "basic_16_32": lambda: MU.BasicConv3d(16, 32, 1, 1),
         "sep_16_32_k3": lambda: MU.SepConv3d(16, 32, 3, 1, 1),
         "sep_3_64_k7s2": lambda: MU.SepConv3d(3, 64, 7, 2, 3),
@@ -84,6 +85,36 @@ def block_case(name, mode, dev, ftol=2e-5, gtol=2e-4):
         for k, v in m.state_dict().items():
             if "running" in k:
                 close(v, z["train_stat:" + k], max(1e-5, ftol), name + " " + k)
+
+
+def block_case_compact(name, mode, dev, sample_tol, norm_tol):
+    """block goldens stored as strided samples + L2 norms (tests/golden/make_goldens.py::_compact: the M = 336-voxel Inception
+    blocks have 1.3 M weights).  Per tensor: the same strided sample of ours against the reference's, max abs error relative to
+    the sample's largest magnitude <= sample_tol, and the L2 norm within norm_tol (relative)."""
+    z, meta = G.load("block_" + name)
+    m = blocks()[name]()
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), meta["seed"]))
+    m = m.to(dev)
+    m.train(mode == "train")
+    x = synth.normal("x_" + name, tuple(meta["in_shape"]), meta["seed"]).to(dev).requires_grad_(True)
+    y = m(x)
+    proj = synth.normal("proj_" + name, tuple(y.shape), meta["seed"]).to(dev)
+    (y * proj).sum().backward()
+    got = {"y": y, "gx": x.grad}
+    got.update({"g:" + k: p.grad for k, p in m.named_parameters()})
+    errs = {}
+    for k, t in got.items():
+        key = mode + "_" + k
+        ref = torch.as_tensor(z[key])
+        stride = int(z[key + "#stride"])
+        mine = t.detach().reshape(-1)[::stride].float().cpu()
+        scale = max(1e-6, float(ref.abs().max()))
+        es = float((mine - ref).abs().max()) / scale
+        en = abs(float(t.detach().double().norm()) - float(z[key + "#norm"])) / max(1e-12, float(z[key + "#norm"]))
+        errs[k] = (es, en)
+        assert es <= sample_tol, "%s %s %s: sample error %g (relative to the largest sample) > %g" % (name, mode, k, es, sample_tol)
+        assert en <= norm_tol, "%s %s %s: L2 norm off by %g > %g" % (name, mode, k, en, norm_tol)
+    return errs
 
 
 def losses_case(dev, vtol=2e-6, gtol=1e-7):

@@ -57,6 +57,17 @@ def test_blocks_bf16(name, mode):
         dict(rel_y=errs["y"], rel_gx=errs["gx"], worst_param=max(v for k, v in errs.items() if k.startswith("g:")))))
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp32s", "bf16"])
+def test_mixed_5b_block_at_4x7x12(dtype, mode):
+    """a block-level golden at the M = 336-voxel stage (4 x 7 x 12 = base4 of a 32 x 224 x 384 clip; Mixed_5b, 832 -> 832
+    channels): outputs, input gradient and every parameter gradient against the reference's (strided samples + L2 norms)"""
+    E.set_default_dtype(dtype)
+    tol = dict(fp32=(2e-4, 2e-4), fp32s=(2e-3, 2e-3), bf16=(0.15, 0.08))[dtype]
+    errs = MC.block_case_compact("mixed_5b", mode, DEV, *tol)
+    _note("block_mixed_5b_%s_%s" % (dtype, mode), dict(worst_sample=max(v[0] for v in errs.values()), worst_norm=max(v[1] for v in errs.values())))
+
+
 @pytest.mark.parametrize("dt", [E.F32, E.BF16], ids=["fp32", "bf16"])
 def test_weight_shared_conv_gradients(dt):
     """a module called twice in one forward: both tape nodes share the plan's weight-gradient workspace, the multi-job unpack

@@ -35,6 +35,13 @@ def test_blocks(name, mode):
     MC.block_case(name, mode, CPU)
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_mixed_5b_block_at_4x7x12(mode):
+    """the M = 336-voxel stage (base4 of a 32 x 224 x 384 clip): outputs, input and parameter gradients of Mixed_5b against the
+    reference's (compact golden: strided samples + norms)"""
+    MC.block_case_compact("mixed_5b", mode, CPU, 2e-4, 2e-4)
+
+
 def test_weight_shared_conv_gradients():
     """one ConvPlan run twice in a backward: one unpack job per weight-gradient workspace (engine.Ctx.flush_unpack)"""
     MC.weight_shared_case(torch.device("cpu"), E.F32, 2e-4)
