@@ -326,6 +326,7 @@ class AbiEmulator:
         return 0
 
     def vinet_pack_weights(self, w, N, Cin, ntaps, transpose, stem, dtype, out, stream):
+        dtype = F32 if dtype == L.F32S else dtype      # (the emulator models the split-bf16 form as exact fp32, plain fp32 packs)
         W = _f32(w, N * Cin * ntaps).reshape(N, Cin, ntaps)
         if stem:
             o = np.zeros((7, N, 32), np.float32)
@@ -345,6 +346,7 @@ class AbiEmulator:
         return 0
 
     def vinet_pack_weights_multi(self, table, njobs, total, dtype, stream):
+        dtype = F32 if dtype == L.F32S else dtype
         tab = np.ctypeslib.as_array((C.c_int64 * (8 * (njobs + 1))).from_address(table)).reshape(njobs + 1, 8)
         assert int(tab[njobs, 6]) == total
         for j in range(njobs):

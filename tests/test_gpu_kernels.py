@@ -497,6 +497,10 @@ def _run_conv_case(case, dt, forced=False, want_y=False, cdt=None, tol=None):
     wpk = torch.zeros(ntaps, N, Kp)
     wpk[:, :, :Cin] = wmaster.permute(2, 0, 1)
     wp = Pair(wpk.to(E.TORCH_DT[dt]))
+    if cdt == L.F32S:      # the split form reads hi / lo bf16 planes (vinet_pack_weights with the arithmetic dtype): pack the GPU side
+        wsrc = wmaster.contiguous().cuda()
+        assert _lib().vinet_pack_weights(wsrc.data_ptr(), N, Cin, ntaps, 0, 0, L.F32S, wp.gpu.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
     taps = Pair(torch.tensor(_fwd_taps(k, p), dtype=torch.int32))
     pre_s, pre_h = fvec("ps" + name, Cin, 4, 0.5, 1.5), fvec("ph" + name, Cin, 5)
     os_, oh_ = fvec("os" + name, N, 6, 0.5, 1.5), fvec("oh" + name, N, 7)

@@ -135,6 +135,14 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
 
 static bool use_pp(const VinetConvDesc* d);
 static bool use_ht(const VinetConvDesc* d);
+int vinet_launch_conv_dma3(int nt, const ConvArgs& a, hipStream_t s);
+int g_vinet_opt_dma3 = 1;        // LDS-DMA kernel for the split-bf16 form (0 = the register-staged kernel everywhere)
+// conv_dma3.h: fp32 tensors + split-bf16 arithmetic; a pending affine only as BatchNorm + ReLU (NaN-page padding)
+static bool use_dma3(const VinetConvDesc* d) {
+  const bool pre_ok = !d->pre.scale || (d->pre.relu && d->pre.shift && d->Kp <= 1024);
+  return g_vinet_opt_dma3 && d->dtype == VINET_F32S && d->mode == VINET_CONV_GENERIC && pre_ok && !(d->pre.relu && !d->pre.scale);
+}
+static int dma3_nt(const VinetConvDesc* d) { return d->y.C <= 32 ? 2 : 4; }
 static bool use_pw(const VinetConvDesc* d);
 struct HtShape { int nt, tw, tm, pre; };
 struct PwShape { int nt, tilesN, gm, tpw; };
@@ -206,6 +214,7 @@ int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad
 
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
+  if (name && !strcmp(name, "dma3")) { g_vinet_opt_dma3 = value; return 0; }
   if (name && !strcmp(name, "pw")) { g_vinet_opt_pw = value; return 0; }
 #ifndef VINET_EXPERIMENTS
   // measured-slower variants live in side builds only (python -c "from vinet_amd import build; build.build_variant('exp', ['-DVINET_EXPERIMENTS'])")
@@ -464,6 +473,7 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   }
   else if (use_pp(d)) snprintf(buf, n, "conv_pp_kernel<%d>", pp_bn(d->y.C));
   else if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
+  else if (use_dma3(d)) snprintf(buf, n, "conv_dma3_kernel<%d,3,%s>", dma3_nt(d) * 16, d->pre.scale ? "pre" : "plain");
   else snprintf(buf, n, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d>", d->dtype == VINET_BF16 ? "bf16" : (d->dtype == VINET_F32S ? "float/split" : "float"), t.MT, t.NT, t.WM, t.WN, d->mode);
   return 0;
 }
@@ -529,6 +539,12 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
       return vn_launch_status("conv_splitk_finish");
     }
     return vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);
+  }
+  if (use_dma3(d)) {
+    const int nt = dma3_nt(d);
+    a.tilesM = vn_div_up(a.M, 128);
+    a.tilesN = vn_div_up(a.N, nt * 16);
+    return vinet_launch_conv_dma3(nt, a, (hipStream_t)stream);
   }
   if (d->dtype == VINET_BF16) return vinet_launch_conv_bf16(t, d->mode, a, (hipStream_t)stream);
   return vinet_launch_conv_f32(t, d->mode, a, (hipStream_t)stream, d->dtype == VINET_F32S);

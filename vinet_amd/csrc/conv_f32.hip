@@ -1,6 +1,6 @@
 // fp32-tensor instantiations of the implicit-GEMM convolution: exact fp32 MFMA (parity path, VINET_F32) and the split-bf16
 // form (VINET_F32S: three bf16 MFMAs per product on hi / lo halves of every operand, conv_igemm.h).
-#include "conv_igemm.h"
+#include "conv_dma3.h"
 
 #define CASE(MT_, NT_, WM_, WN_)                                                            \
   if (t.MT == MT_ && t.NT == NT_ && t.WM == WM_ && t.WN == WN_)                             \
@@ -14,4 +14,10 @@ int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStr
   CASE(2, 2, 2, 2)
   vinet_set_error("conv f32: no kernel for tile MT=%d NT=%d WM=%d WN=%d", t.MT, t.NT, t.WM, t.WN);
   return -1;
+}
+
+// LDS-DMA form of the split-bf16 arithmetic (conv_dma3.h): 128 x 64 tiles (128 x 32 for narrow outputs)
+int vinet_launch_conv_dma3(int nt, const ConvArgs& a, hipStream_t s) {
+  if (nt == 2) return a.in_scale ? launch_conv_dma3_cfg<2, true>(a, s) : launch_conv_dma3_cfg<2, false>(a, s);
+  return a.in_scale ? launch_conv_dma3_cfg<4, true>(a, s) : launch_conv_dma3_cfg<4, false>(a, s);
 }

@@ -590,21 +590,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     char* As = smem + buf * Cfg::A_BYTES;
     char* Bs = smem + 2 * Cfg::A_BYTES + buf * Cfg::B_BYTES;
     if constexpr (SPLIT) {
-      // four fp32 of K group g -> 8 bytes of the hi image and 8 bytes of the lo image (half g & 1 of 16-byte chunk g >> 1)
+      // activations: four fp32 of K group gg (channels 4gg .. 4gg+3 of the chunk) -> 8 bytes of the hi image and 8 of the lo
+      // image, at K positions 8 (gg & 3) + 4 (gg >> 2) + {0..3}: the channel permutation of the split weight packs
+      // (layout.hip: pack_store<VINET_F32S>), so that a lane group's 16 bytes hold the same eight channels on both sides
       auto put = [&](char* img, int rows, int row, int gg, const uint4& v) {
         uint32_t h0, l0, h1, l1;
         split_pair(__uint_as_float(v.x), __uint_as_float(v.y), h0, l0);
         split_pair(__uint_as_float(v.z), __uint_as_float(v.w), h1, l1);
-        char* dst = img + row * 64 + ((((gg >> 1) ^ ((row >> 2) & 3))) << 4) + (gg & 1) * 8;
+        char* dst = img + row * 64 + ((((gg & 3) ^ ((row >> 2) & 3))) << 4) + (gg >> 2) * 8;
         *(uint2*)dst = make_uint2(h0, h1);
         *(uint2*)(dst + rows * 64) = make_uint2(l0, l1);
       };
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i) put(As, BM, (i * 256 + tid) / G, g, ra[i]);
+      // weights arrive split and permuted: 16-byte piece gg of a row's 128-byte chunk is K positions 8 (gg & 3) .. +7 of the
+      // hi (gg < 4) or lo plane
 #pragma unroll
       for (int j = 0; j < B_LOADS; ++j) {
         const int idx = j * 256 + tid;
-        if (idx < B_ITEMS) put(Bs, BN, idx / G, idx % G, rb[j]);
+        if (idx < B_ITEMS) {
+          const int row = idx / G, gg = idx % G;
+          *(uint4*)(Bs + (gg >> 2) * BN * 64 + row * 64 + ((((gg & 3) ^ ((row >> 2) & 3))) << 4)) = rb[j];
+        }
       }
     } else {
 #pragma unroll

@@ -6,9 +6,32 @@
 // ============================================================================
 // weight packing
 // ============================================================================
-template <typename T>
+// Destination formats.  VINET_F32 / VINET_BF16: element L of the logical [slice][row][Kp] array at out[L].  VINET_F32S (fp32
+// tensors, split-bf16 arithmetic): every 32-wide K chunk of a row becomes 128 bytes = [32 bf16 hi | 32 bf16 lo] with hi = bf16(v),
+// lo = bf16(v - hi) -- the same bytes per row as fp32 -- and the chunk's channels PERMUTED so that MFMA lane group q (K
+// positions 8q .. 8q+7) holds channels {4q .. 4q+3, 16+4q .. 16+4q+3}: the activation side of the split kernels reads its fp32
+// rows in 16-byte pieces (4 channels), piece q and piece q + 4 per lane (conv_dma3.h, conv_igemm.h), and both sides must agree
+// on which channel sits in which K position.
+template <int DT> VN_DEV void pack_store(void* out, long L, float v) {
+  if constexpr (DT == VINET_F32) ((float*)out)[L] = v;
+  else if constexpr (DT == VINET_BF16) ((bf16_t*)out)[L] = f2bf(v);
+  else {
+    const int c = (int)(L & 31);
+    const int pos = c < 16 ? ((c >> 2) * 8 + (c & 3)) : (((c - 16) >> 2) * 8 + 4 + (c & 3));
+    bf16_t* o = (bf16_t*)out + (L >> 5) * 64 + pos;
+    const bf16_t hi = f2bf(v);
+    o[0] = hi;
+    o[32] = f2bf(v - bf2f(hi));
+  }
+}
+#define DISPATCH_PACK(dt, DT, ...)                                   \
+  if ((dt) == VINET_F32) { constexpr int DT = VINET_F32; __VA_ARGS__ }      \
+  else if ((dt) == VINET_F32S) { constexpr int DT = VINET_F32S; __VA_ARGS__ } \
+  else { constexpr int DT = VINET_BF16; __VA_ARGS__ }
+
+template <int DT>
 __global__ void pack_weights_kernel(const float* __restrict__ w, int N, int Cin, int ntaps, int transpose, int stem,
-                                    int rows, int Kp, int nslices, T* __restrict__ out) {
+                                    int rows, int Kp, int nslices, void* __restrict__ out) {
   const long total = (long)nslices * rows * Kp;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % Kp);
@@ -23,13 +46,14 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int N, int Cin,
     } else {  // out[t][c][n]
       if (k < N) v = w[((long)k * Cin + r) * ntaps + s];
     }
-    store1<T>(out + i, v);
+    pack_store<DT>(out, i, v);
   }
 }
 
 extern "C" int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_t ntaps, int32_t transpose,
                                   int32_t stem, int32_t dtype, void* out, void* stream) {
   VN_CHECK_ARG(w && out && N > 0 && Cin > 0 && ntaps > 0, "pack_weights: bad arguments");
+  VN_CHECK_ARG(dtype == VINET_F32 || dtype == VINET_BF16 || dtype == VINET_F32S, "pack_weights: bad dtype %d", dtype);
   int rows, Kp, nslices;
   if (stem) {
     VN_CHECK_ARG(ntaps == 49 && Cin <= 4 && !transpose, "pack_weights stem: need 1x7x7, Cin<=4");
@@ -38,8 +62,8 @@ extern "C" int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_
   else { rows = Cin; Kp = (N + 31) / 32 * 32; nslices = ntaps; }
   const long total = (long)nslices * rows * Kp;
   int grid = ew_grid(total); if (grid > 8192) grid = 8192;
-  DISPATCH_T(dtype, T, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, N,
-                                          Cin, ntaps, transpose, stem, rows, Kp, nslices, (T*)out);)
+  DISPATCH_PACK(dtype, DT, hipLaunchKernelGGL(pack_weights_kernel<DT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, N,
+                                             Cin, ntaps, transpose, stem, rows, Kp, nslices, out);)
   return vn_launch_status("pack_weights");
 }
 
@@ -49,7 +73,7 @@ extern "C" int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_
 // ld != 0 (transposed jobs only): rows of the destination are `ld` elements apart and this job owns columns
 // [col, col + N) of them -- several convs that share an input, packed side by side along K for ONE dgrad.
 // plus one trailing row whose prefix field is the total; one thread per output element, job by binary search.
-template <typename T>
+template <int DT>
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long* __restrict__ table, int njobs, long total) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int lo = 0, hi = njobs;               // last job with prefix <= i
@@ -59,7 +83,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long* __r
     }
     const long* J = table + lo * 8;
     const float* w = (const float*)J[0];
-    T* out = (T*)J[1];
+    void* out = (void*)J[1];
     const int N = (int)J[2], Cin = (int)J[3], ntaps = (int)J[4];
     const int transpose = (int)(J[5] & 1), stem = (int)((J[5] >> 1) & 1);
     const long e = i - J[6];
@@ -78,19 +102,19 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const long* __r
       if (k < N) v = w[((long)k * Cin + r) * ntaps + sl];
       const long ld = J[7] & 0xffffffffl;
       if (ld) {          // side-by-side destination: only the job's own columns are written
-        if (k < N) store1<T>(out + ((long)sl * rows + r) * ld + (J[7] >> 32) + k, v);
+        if (k < N) pack_store<DT>(out, ((long)sl * rows + r) * ld + (J[7] >> 32) + k, v);
         continue;
       }
     }
-    store1<T>(out + e, v);
+    pack_store<DT>(out, e, v);
   }
 }
 
 extern "C" int vinet_pack_weights_multi(const int64_t* table, int32_t njobs, int64_t total, int32_t dtype, void* stream) {
   VN_CHECK_ARG(table && njobs > 0 && total > 0, "pack_weights_multi: bad arguments");
   int grid = ew_grid(total); if (grid > 16384) grid = 16384;
-  DISPATCH_T(dtype, T, hipLaunchKernelGGL(pack_weights_multi_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                          (const long*)table, njobs, (long)total);)
+  DISPATCH_PACK(dtype, DT, hipLaunchKernelGGL(pack_weights_multi_kernel<DT>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                             (const long*)table, njobs, (long)total);)
   return vn_launch_status("pack_weights_multi");
 }
 

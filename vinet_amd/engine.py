@@ -648,7 +648,9 @@ class ConvPlan:
 
     # ---- packed weights -----------------------------------------------------
     def packed(self, ctx, transpose=False):
-        key = (ctx.dt, transpose, str(ctx.device))
+        # (keyed and packed by the ARITHMETIC dtype: the split-bf16 form reads hi / lo bf16 planes -- the same bytes per row as
+        #  the fp32 pack, a different content: include/vinet_hip.h, vinet_pack_weights)
+        key = (ctx.cdt, transpose, str(ctx.device))
         stamp = self._pack_stamp()
         ent = self._packs.get(key)
         if ent is not None and ent[0] == stamp:
@@ -659,7 +661,7 @@ class ConvPlan:
         assert w.dtype == torch.float32 and w.is_contiguous()
         buf = ent[1] if ent is not None else torch.empty(self.pack_numel(transpose), dtype=TORCH_DT[ctx.dt], device=ctx.device)
         ctx.call("vinet_pack_weights", w.data_ptr(), self.N, self.Cin, self.ntaps, 1 if transpose else 0,
-                 1 if (self.stem and not transpose) else 0, ctx.dt, buf.data_ptr(), ctx.stream)
+                 1 if (self.stem and not transpose) else 0, ctx.cdt, buf.data_ptr(), ctx.stream)
         self._packs[key] = (stamp, buf)
         _PACKS.register(self, key)
         return buf
@@ -749,7 +751,7 @@ class JointConvPlan(ConvPlan):
 
     def pack_jobs(self, key):
         dt, transpose = key[0], key[1]
-        base, es = self._packs[key][1].data_ptr(), ESIZE[dt]
+        base, es = self._packs[key][1].data_ptr(), (4 if dt == F32S else ESIZE[dt])
         jobs = []
         for m, off in zip(self.members, self.offs):
             w = m.weight.detach()
@@ -761,7 +763,7 @@ class JointConvPlan(ConvPlan):
         return jobs
 
     def packed(self, ctx, transpose=False):
-        key = (ctx.dt, transpose, str(ctx.device))
+        key = (ctx.cdt, transpose, str(ctx.device))
         stamp = self._pack_stamp()
         ent = self._packs.get(key)
         if ent is not None and ent[0] == stamp:
@@ -773,7 +775,7 @@ class JointConvPlan(ConvPlan):
             _PACKS.register(self, key)
         jobs = self.pack_jobs(key)
         table, total = pack_table(jobs, ctx.device)
-        ctx.call("vinet_pack_weights_multi", table.data_ptr(), len(jobs), total, ctx.dt, ctx.stream)
+        ctx.call("vinet_pack_weights_multi", table.data_ptr(), len(jobs), total, ctx.cdt, ctx.stream)
         self._packs[key] = (stamp, self._packs[key][1])
         self._keep_table = table       # the launch reads it asynchronously
         return self._packs[key][1]
