@@ -25,7 +25,9 @@
  *    slice of a wider concat buffer), H-stride `W*ld`, T-stride `H*W*ld`,
  *    batch stride `sB` (so a view may also be a T slice of a longer buffer).
  *  - dtype: VINET_F32 (parity path) or VINET_BF16 (throughput path); all
- *    accumulation, BN statistics and loss arithmetic are fp32/fp64.
+ *    accumulation, BN statistics and loss arithmetic are fp32/fp64.  Conv and
+ *    weight-gradient descriptors (and vinet_pack_weights) also take VINET_F32S:
+ *    fp32 tensors, bf16 matrix arithmetic on hi / lo halves of both operands.
  */
 #ifndef VINET_HIP_H
 #define VINET_HIP_H
@@ -215,6 +217,10 @@ int vinet_conv3d_wgrad_kernel_name(const VinetWgradDesc* desc, char* buf, int32_
  *  transpose == 0: out[t][n][c]       (Kp = pad32(Cin))   forward / wgrad layout
  *  transpose == 1: out[t][c][n]       (Kp = pad32(N))     dgrad layout
  *  stem      == 1: out[kh][n][kw*4+c] (Kp = 32; ntaps = 7*7, Cin = 3)
+ * dtype VINET_F32S (the packs VINET_F32S descriptors read): the same logical arrays, stored as hi / lo bf16 planes -- every
+ * 32-wide K chunk of a row becomes 128 bytes [32 bf16 hi | 32 bf16 lo], hi = bf16(w), lo = bf16(w - hi), K positions permuted so
+ * that positions 8q .. 8q+7 hold channels {4q .. 4q+3, 16+4q .. 16+4q+3} (the order in which the kernels' lane groups read fp32
+ * activations in 16-byte pieces).  Same byte count as the fp32 pack; callers size the buffer as for VINET_F32.
  * Replaces the implicit weight reads of every nn.Conv3d above. */
 int vinet_pack_weights(const float* w, int32_t N, int32_t Cin, int32_t ntaps, int32_t transpose, int32_t stem,
                        int32_t dtype, void* out, void* stream);
