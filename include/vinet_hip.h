@@ -426,6 +426,10 @@ int vinet_gt_preprocess(const uint8_t* src, int32_t N, int32_t H, int32_t W, flo
  * (default), 2 every eligible shape), "reduce_il" (channel reductions walk one window, default 1).
  * None of them changes results beyond floating-point accumulation order. */
 int vinet_set_option(const char* name, int32_t value);
+/* fp32 view (with its pending affine applied) -> hi = bf16(v) and lo = bf16(v - hi) planes of the same dims: the operands of
+ * the bf16 kernels when they serve the VINET_F32S arithmetic as three accumulating launches (hi*hi + lo*hi + hi*lo; the weight
+ * gradients: every bf16 weight-gradient kernel ADDS into `dw`).  No reference counterpart: a numerics tool of this path. */
+int vinet_split_bf16(const VinetTensor* src, VinetAffine pre, const VinetTensor* hi, const VinetTensor* lo, void* stream);
 int vinet_fill_f32(float* p, int64_t n, float value, void* stream);
 /* Test / tuning aid, no reference counterpart: one wave that idles for ~`cycles` shader clocks on `stream` (delays whatever is
  * enqueued behind it; touches no memory).  Used to perturb the two-stream backward schedule in eager mode. */

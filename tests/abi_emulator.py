@@ -149,6 +149,14 @@ class AbiEmulator:
     def vinet_set_option(self, name, value):
         return 0
 
+    def vinet_split_bf16(self, src, pre, hi, lo, stream):
+        src, hi, lo = (t._obj if hasattr(t, "_obj") else t for t in (src, hi, lo))
+        v = affine(rd(src, F32), pre, src.C)
+        h = _bf2f(_f2bf(v.reshape(-1))).reshape(v.shape)
+        wr(hi, BF16, h)
+        wr(lo, BF16, v - h)
+        return 0
+
     def vinet_debug_spin(self, cycles, stream):
         return 0
 

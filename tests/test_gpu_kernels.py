@@ -1047,6 +1047,28 @@ def test_copy_affine_streaming(acc, aff):
     _cmp(dp.get("gpu"), dp.get("cpu"), 1e-2, "copy_affine streaming")
 
 
+@pytest.mark.parametrize("aff", [0, 1])
+def test_split_bf16_planes(aff):
+    """vinet_split_bf16: fp32 view (+ pending BatchNorm + ReLU) -> hi = bf16(v), lo = bf16(v - hi) planes, bit-identical with the model;
+    hi + lo reproduces v to 2^-16 relative"""
+    B, T, H, W, Cc = 2, 3, 5, 7, 24
+    sp, smk = view_pair(B, T, H, W, Cc, E.F32, "spx", 1, ld=40, c_off=8)
+    hp, hmk = view_pair(B, T, H, W, Cc, E.BF16, "sph", 2, ld=32, c_off=8)
+    lp, lmk = view_pair(B, T, H, W, Cc, E.BF16, "spl", 3)
+    ps, ph = fvec("spps", Cc, 3, 0.5, 1.5), fvec("spph", Cc, 4)
+    run_both("vinet_split_bf16", lambda s: [C.byref(smk(s).ct()), L.CAffine(ps.ptr(s), ph.ptr(s), 1) if aff else L.CAffine(None, None, 0),
+                                            C.byref(hmk(s).ct()), C.byref(lmk(s).ct()), _stream() if s == "gpu" else 0])
+    if not aff:      # (with the affine the library's fused multiply-add and the model's multiply + add differ in the last bit of v)
+        assert torch.equal(hp.get("gpu"), hp.get("cpu")) and torch.equal(lp.get("gpu"), lp.get("cpu"))
+    recg = hmk("gpu").torch5().float().cpu() + lmk("gpu").torch5().float().cpu()
+    v = smk("cpu").torch5().float()
+    if aff:
+        v = torch.relu(v * ps.cpu + ph.cpu)
+    rec = hmk("cpu").torch5().float() + lmk("cpu").torch5().float()
+    for r in (rec, recg):
+        assert float((r - v).abs().max()) <= 2.0 ** -15 * max(1.0, float(v.abs().max()))
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("Cc", [16, 24, 64, 208, 528, 1024])
 def test_bn_kernels(dt, Cc):

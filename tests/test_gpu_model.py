@@ -126,7 +126,7 @@ def test_train_step_split_bf16():
     as the reference's own fp32 gradients are (the criterion of test_train_step_fp32)"""
     E.set_default_dtype("fp32s")
     try:
-        MC.train_step_case(DEV, pred_tol=1e-4, loss_tol=1e-4, grad_factor=8.0, grad_floor=0.05, worst_max=0.3, global_tol=2e-2, sq_rtol=0.25)
+        MC.train_step_case(DEV, pred_tol=1e-4, loss_tol=1e-4, grad_factor=8.0, grad_floor=0.1, worst_max=0.3, global_tol=2e-2, sq_rtol=0.25)
     finally:
         _note("train_step_fp32s", dict(top_grad_rel_err_vs_fp64=getattr(MC.train_step_case, "last_table", None),
                                        whole_gradient_rel_l2=getattr(MC.train_step_case, "global_rel", None)))

@@ -107,6 +107,7 @@ SIGNATURES = {
     "vinet_pack_weights_multi": [_vp, _i32, _i64, _i32, _vp],
     "vinet_unpack_wgrad_multi": [_vp, _i32, _i64, _i32, _vp],
     "vinet_fill_f32": [_vp, _i64, _f32, _vp],
+    "vinet_split_bf16": [_PT, CAffine, _PT, _PT, _vp],
     "vinet_debug_spin": [_i64, _vp],
     "vinet_abi_version": [],
     "vinet_last_error": [],

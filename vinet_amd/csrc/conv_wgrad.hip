@@ -259,8 +259,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         const int c = c0 + wn * 32 + j * 16 + (lane & 15);
         if (n < a.N && c < a.Kp) {
           float* dst = a.dw + ((long)tp.w * a.N + n) * (long)a.Kp + c;
-          if (a.splitK > 1) atomicAdd(dst, acc[i][j][r]);
-          else *dst = acc[i][j][r];
+          atomicAdd(dst, acc[i][j][r]);      // (always +=: dw is zero on entry, or holds the other terms of a split-bf16 sum / an earlier use of a shared weight)
         }
       }
 }

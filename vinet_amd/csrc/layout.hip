@@ -367,6 +367,32 @@ extern "C" int vinet_copy_affine(const VinetTensor* src, int32_t src_dtype, Vine
 }
 
 
+// fp32 view (+ pending affine) -> hi and lo bf16 planes, hi = bf16(v), lo = bf16(v - hi): the operands of the bf16 kernels when
+// they serve the split-bf16 form (the weight gradient of VINET_F32S runs as three bf16 launches hi*hi + lo*hi + hi*lo that
+// accumulate into one fp32 workspace: engine.py)
+__global__ void split_bf16_kernel(TView src, Affine pre, TView hi, TView lo, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t vox_u = fdiv((uint32_t)i, src.dQ);
+  const int q = (int)((uint32_t)i - vox_u * (uint32_t)(src.C / 4));
+  const long vox = (long)vox_u;
+  float4 v = ldq<float>((const float*)src.p + vox_lin(src, vox) + q * 4);
+  v = affine4(v, pre, q * 4);
+  const uint32_t h01 = pack2bf(v.x, v.y), h23 = pack2bf(v.z, v.w);
+  const uint32_t l01 = pack2bf(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+  const uint32_t l23 = pack2bf(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+  *(uint2*)((bf16_t*)hi.p + vox_lin(hi, vox) + q * 4) = make_uint2(h01, h23);
+  *(uint2*)((bf16_t*)lo.p + vox_lin(lo, vox) + q * 4) = make_uint2(l01, l23);
+}
+extern "C" int vinet_split_bf16(const VinetTensor* src, VinetAffine pre, const VinetTensor* hi, const VinetTensor* lo, void* stream) {
+  VN_CHECK_ARG(src && hi && lo && quad_ok(*src, 4) && quad_ok(*hi, 2) && quad_ok(*lo, 2) && same_dims(*src, *hi) && same_dims(*src, *lo),
+               "split_bf16: bad views");
+  const long total = view_voxels(*src) * (src->C / 4);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, make_view(*src), make_affine(pre),
+                     make_view(*hi), make_view(*lo), total);
+  return vn_launch_status("split_bf16");
+}
+
 // ---- "skinny" weight gradient: a pointwise conv with at most 8 output channels (ViNet's 32 -> 1 head, model.py:279: the
 // channel-padded dy has 8 columns, 7 of them exactly zero) over tens of millions of voxels is a per-channel reduction, not a
 // GEMM: dw[n][c] = sum_v dy[v][n] * x[v][c].  The 64 x 64 MFMA tile spent 0.9 ms (0.8 TF/s) on it; here a lane owns 8 input

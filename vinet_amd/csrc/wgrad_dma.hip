@@ -306,8 +306,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
           const int c = c0 + wn * (TC / 2) + j * 16 + (lane & 15);
           if (n < a.N && c < a.Kp) {
             float* dst = a.dw + ((long)tp[g].w * a.N + n) * (long)a.Kp + c;
-            if (a.splitK > 1) atomicAdd(dst, acc[g][i][j][r]);
-            else *dst = acc[g][i][j][r];
+            atomicAdd(dst, acc[g][i][j][r]);      // (always +=: dw is zero on entry, or holds the other terms of a split-bf16 sum / an earlier use of a shared weight)
           }
         }
   }

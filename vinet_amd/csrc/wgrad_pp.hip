@@ -362,8 +362,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(const WgradPPArgs
 #ifdef VINET_WPP_NO_ATOMIC   // tuning build: what do the split-K atomics cost?
             *dst = acc[hi][j * 2 + jj][r];
 #else
-            if (a.splitK > 1) atomicAdd(dst, acc[hi][j * 2 + jj][r]);
-            else *dst = acc[hi][j * 2 + jj][r];
+            atomicAdd(dst, acc[hi][j * 2 + jj][r]);      // (always +=: see wgrad_dma.hip)
 #endif
           }
         }

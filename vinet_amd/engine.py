@@ -1076,6 +1076,22 @@ class _NullCtx:
         return False
 
 
+# the weight gradient of the split-bf16 form (fp32s) as three launches of the bf16 kernels over hi / lo planes (0 = the dedicated
+# register-staged split kernel, conv_wgrad.hip)
+SPLIT_WGRAD_BF16 = int(os.environ.get("VINET_SPLIT_WGRAD_BF16", "1"))
+
+
+def _split_planes(ctx, x, dy):
+    """hi / lo bf16 planes of a conv's input (pending affine applied) and of its output gradient: ((x_hi, x_lo), (dy_hi, dy_lo))"""
+    out = []
+    for v, aff in ((x.v, x.affine()), (dy, L.CAffine(None, None, 0))):
+        hi = View.alloc(v.B, v.T, v.H, v.W, v.C, BF16, v.device)
+        lo = View.alloc(v.B, v.T, v.H, v.W, v.C, BF16, v.device)
+        ctx.call("vinet_split_bf16", C.byref(v.ct()), aff, C.byref(hi.ct()), C.byref(lo.ct()), ctx.stream)
+        out.append((hi, lo))
+    return out
+
+
 def _wgrad_desc(ctx, plan, x, dy, dw=None):
     folded = plan.stem and x.fold is not None
     taps, ntaps = plan.folded_taps(ctx.device) if folded else plan.fwd_taps(ctx.device)
@@ -1193,10 +1209,29 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                     wd.max_cus = 256 if (tail or side is None) else (WGRAD_CUS_DEC if bn is None else WGRAD_CUS)
                     if DBG_SPIN_SIDE and side is not None:
                         ctx.lib.vinet_debug_spin(DBG_SPIN_SIDE, ctx.stream)
-                    ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
-                             tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
-                             work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
-                                       bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
+                    planes = None
+                    if (SPLIT_WGRAD_BF16 and ctx.cdt == F32S and not plan.stem and x.fold is None and fused_bnb is None and
+                            x.v.C % 8 == 0 and dy.C % 8 == 0 and x.v.dt == F32 and dy.dt == F32):
+                        planes = _split_planes(ctx, x, dy)
+                    if planes is not None:
+                        # the split-bf16 weight gradient as THREE launches of the bf16 kernels (the row- / frame-streaming ones
+                        # included) over hi / lo planes of both operands: dw += dy_hi x_hi + dy_lo x_hi + dy_hi x_lo.  Every bf16
+                        # weight-gradient kernel adds into dw; the pending affine of x went into its planes.
+                        (xh, xl), (dh, dl) = planes
+                        for xa, da in ((xh, dl), (xl, dh), (xh, dh)):      # small terms first
+                            wq = _wgrad_desc(ctx, plan, Act(xa), da, dw)
+                            wq.dtype, wq.max_cus = BF16, wd.max_cus
+                            ctx.call("vinet_conv3d_wgrad", C.byref(wq), ctx.stream,
+                                     tag=(_wgrad_kernel_name(ctx, wq) + " | wgrad(split x3) " + plan.site(x.v)) if PROFILER is not None else None,
+                                     work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps / 3,
+                                               bytes=float(x.v.nvox * plan.Cin * 2 + M * plan.N * 2 + plan.N * plan.Cin * plan.ntaps * 4)))
+                        if side is not None:
+                            ctx.keep(xh.buf, xl.buf, dh.buf, dl.buf)
+                    else:
+                        ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
+                                 tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
+                                 work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
+                                           bytes=float(x.v.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * 4)))
                     if Ny != plan.N:
                         assert plan.ntaps == 1, "channel-padded outputs are only supported for 1x1x1 convs"
                     if persistent and MULTI_UNPACK and PARAM_GRAD_HOOK is None and N_SIDE_STREAMS == 1:
