@@ -87,10 +87,13 @@ def block_case(name, mode, dev, ftol=2e-5, gtol=2e-4):
                 close(v, z["train_stat:" + k], max(1e-5, ftol), name + " " + k)
 
 
-def block_case_compact(name, mode, dev, sample_tol, norm_tol):
+def block_case_compact(name, mode, dev, sample_tol, norm_tol, l2=False):
     """block goldens stored as strided samples + L2 norms (tests/golden/make_goldens.py::_compact: the M = 336-voxel Inception
     blocks have 1.3 M weights).  Per tensor: the same strided sample of ours against the reference's, max abs error relative to
-    the sample's largest magnitude <= sample_tol, and the L2 norm within norm_tol (relative)."""
+    the sample's largest magnitude <= sample_tol, and the L2 norm within norm_tol (relative).
+    l2 (bf16): the sample is held to a relative L2 error <= sample_tol instead, like every other bf16 block test -- a bf16
+    pre-activation that rounds across zero flips a ReLU gate (or a max-pool argmax) and moves single gradient elements by O(1)
+    of the largest one (0.37-0.42 measured on gx here), which an elementwise bound cannot tell from a bug."""
     z, meta = G.load("block_" + name)
     m = blocks()[name]()
     m.load_state_dict(synth.synth_state_dict(m.state_dict(), meta["seed"]))
@@ -110,9 +113,11 @@ def block_case_compact(name, mode, dev, sample_tol, norm_tol):
         mine = t.detach().reshape(-1)[::stride].float().cpu()
         scale = max(1e-6, float(ref.abs().max()))
         es = float((mine - ref).abs().max()) / scale
+        if l2:
+            es = float((mine.double() - ref.double()).norm() / max(1e-30, float(ref.double().norm())))
         en = abs(float(t.detach().double().norm()) - float(z[key + "#norm"])) / max(1e-12, float(z[key + "#norm"]))
         errs[k] = (es, en)
-        assert es <= sample_tol, "%s %s %s: sample error %g (relative to the largest sample) > %g" % (name, mode, k, es, sample_tol)
+        assert es <= sample_tol, "%s %s %s: sample error %g (%s) > %g" % (name, mode, k, es, "relative L2" if l2 else "relative to the largest sample", sample_tol)
         assert en <= norm_tol, "%s %s %s: L2 norm off by %g > %g" % (name, mode, k, en, norm_tol)
     return errs
 
@@ -234,7 +239,7 @@ def e2e_case(tag, dev, tol=1e-4, argmax=True):
 
 
 def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5, grad_factor=3.0, grad_floor=2e-3, worst_max=0.15,
-                    global_tol=None, sq_rtol=8e-2):
+                    global_tol=None, sq_rtol=8e-2, global_factor=None):
     from vinet_amd import loss as VL
     from vinet_amd import model as VM
     from vinet_amd import optim as VO
@@ -274,7 +279,7 @@ def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5, grad
         # the 12-sample BNs) flips a ~1e-5 fraction of ReLU gates, and the gradient's L2 error goes with
         # the square root of that fraction; a 2e-6 perturbation of the oracle's own input moves these
         # gradients by 1e-4..6e-4.  A wrong tap / pad / stride shows up at >= 1e-1.
-        # (the split-bf16 form passes grad_factor 8, grad_floor 0.1 and a bound on the error of the WHOLE gradient vector: with
+        # (the split-bf16 form passes grad_factor 8, grad_floor 0.15 and a bound on the error of the WHOLE gradient vector: with
         #  B = 2 the deep BatchNorms see 12 samples per channel and single small parameters -- a BatchNorm bias of base3, the stem's
         #  weights, residuals of cancelling sums where the reference's OWN fp32 gradient sits 1.6-3.8 % from fp64 -- amplify a 2^-17
         #  operand error to 5-20 %; what a wrong kernel would do, an O(1) error on a large tensor, the global bound catches)
@@ -283,11 +288,19 @@ def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5, grad
     table.sort(reverse=True)
     train_step_case.last_table = table[:8]
     assert worst < worst_max, table[:5]
-    if global_tol is not None:
+    if global_tol is not None or global_factor is not None:
         num = sum(float((params[k].grad.double().cpu() - truth[k]).pow(2).sum()) for k in params)
+        nref = sum(float((ref32[k] - truth[k]).pow(2).sum()) for k in params)
         den = sum(float(truth[k].pow(2).sum()) for k in params)
         train_step_case.global_rel = (num / den) ** 0.5
-        assert train_step_case.global_rel <= global_tol, "whole gradient vector: relative L2 error %.3e > %.3e" % (train_step_case.global_rel, global_tol)
+        train_step_case.global_ref = (nref / den) ** 0.5
+        # the whole gradient vector against fp64, as an absolute bound and / or relative to the reference's OWN fp32 error against
+        # fp64 (this fixture is ill-conditioned on purpose -- B = 2, 12 samples per channel in the deepest BatchNorms: the
+        # reference's fp32 gradient vector sits 3 % from fp64, ours in exact fp32 3.4 %; an operand error of 2^-17 instead of 2^-24
+        # grows the same way, to 15 % measured (direction, not scale: tools/dbg_split_grad.py))
+        bound = min(b for b in (global_tol, None if global_factor is None else global_factor * train_step_case.global_ref + 1e-3) if b is not None)
+        assert train_step_case.global_rel <= bound, "whole gradient vector: relative L2 error %.3e > %.3e (reference fp32 vs fp64: %.3e)" % (
+            train_step_case.global_rel, bound, train_step_case.global_ref)
     names = json.loads(str(z["grad_names"]))
     gq = np.array([float((params[k].grad.double() ** 2).sum()) for k in names])
     np.testing.assert_allclose(gq, z["grad_sqsum"], rtol=sq_rtol, atol=1e-12)

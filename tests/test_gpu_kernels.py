@@ -293,6 +293,26 @@ def test_conv3d_halo_tile(case, mfma32):
         lib.vinet_set_option(b"ht32", 0)
 
 
+@pytest.mark.parametrize("case", HT_CASES, ids=[c[0] for c in HT_CASES])
+def test_conv3d_halo_tile_split_bf16(case):
+    """the halo-tile kernel in the VINET_F32S form (conv_ht.h, SPLIT: fp32 halo image, K steps of 32 channels, hi / lo weight
+    planes, three MFMAs per product) on the same forced cases, held to the split form's 1e-4"""
+    lib = _lib()
+    assert lib.vinet_set_option(b"ht", 2) == 0
+    try:
+        ex = dict(case[7])
+        ex.setdefault("tline", 5)
+        d0 = _run_conv_case(case[:7] + (ex,), E.F32, forced=True, cdt=L.F32S, tol=1e-4)
+        buf = C.create_string_buffer(128)
+        d0.dtype = L.F32S
+        assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_ht3_kernel<"), buf.value
+        assert lib.vinet_set_option(b"ht3", 0) == 0
+        assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_dma3_kernel<"), buf.value
+    finally:
+        lib.vinet_set_option(b"ht", 1)
+        lib.vinet_set_option(b"ht3", 1)
+
+
 # the pointwise streaming kernel (conv_pw.h), forced on small grids: 32- / 64- / 96-column weight tiles with padded and partial
 # column tiles (N = 176, 288, 40), 1 / 2 / 6 / 8 / 9 K steps with a channel tail inside the last one (Cin = 176, 40), row tails,
 # pending BatchNorm + ReLU (NaN-page padding), statistics (one row per workgroup), affine / ReLU epilogue,

@@ -148,7 +148,7 @@ struct HtShape { int nt, tw, tm, pre; };
 struct PwShape { int nt, tilesN, gm, tpw; };
 static PwShape pw_shape(const VinetConvDesc* d);
 static HtShape ht_shape(const VinetConvDesc* d);
-extern int g_vinet_opt_ht, g_vinet_opt_ht32, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
+extern int g_vinet_opt_ht, g_vinet_opt_ht3, g_vinet_opt_ht32, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
 bool vinet_conv_use_ts(const VinetConvDesc* d);
 bool vinet_conv_use_hs(const VinetConvDesc* d);
 bool vinet_conv_use_tsd(const VinetConvDesc* d);
@@ -241,6 +241,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
   if (name && !strcmp(name, "ht")) { g_vinet_opt_ht = value; return 0; }
   if (name && !strcmp(name, "ht32")) { g_vinet_opt_ht32 = value; return 0; }
+  if (name && !strcmp(name, "ht3")) { g_vinet_opt_ht3 = value; return 0; }
   if (name && !strcmp(name, "bn_lean")) { g_vinet_opt_bn_lean = value; return 0; }
   if (name && !strcmp(name, "ht_minhw")) { g_vinet_opt_ht_minhw = value; return 0; }
   if (name && !strcmp(name, "ht_t")) { g_vinet_opt_ht_t = value; return 0; }
@@ -359,6 +360,8 @@ int g_vinet_opt_ht_pre = 0;      // spatial mode on inputs with a pending BatchN
                                  // against conv_dma's per-fragment form) but the engine then skips the materialisation pass, and the row-streaming
                                  // weight gradients of those layers want plain inputs: whole step 613 -> 599 clips/s.  Off.
 int g_vinet_opt_ht_t_minhw = 14 * 24;
+int g_vinet_opt_ht3 = 1;         // halo-tile kernels for the split-bf16 form (VINET_F32S; 0 = conv_dma3 everywhere)
+int vinet_launch_conv_ht_f32s(int nt, int tw, int tm, int pre, const ConvArgs& a, hipStream_t s);
 // temporal mode: tline == 1 with three taps, padding 1, unit stride = taps (dt, 0, 0), dt in {-1, 0, 1}
 static bool ht_temporal(const VinetConvDesc* d) {
   return d->tline == 1 && d->ntaps == 3 && d->tpad == 1 && d->sT == 1;
@@ -370,10 +373,11 @@ static HtShape ht_shape(const VinetConvDesc* d) {
   h.tw = (d->oW % 32 == 0) ? 32 : 16;
   const int N = d->n_valid > 0 ? d->n_valid : d->y.C;
   // 96-, 64- or 32-wide column tiles, whichever pads N least (ties: the widest); a 128-wide tile spills (12 B / lane);
-  // the temporal and PRE forms exist for 96 and 64
+  // the temporal and PRE forms exist for 96 and 64; the split-bf16 form (three MFMAs per product) for 64 and 32
   int best = 4, bestpad = 1 << 30;
   const int nts[3] = {6, 4, 2};
-  for (int i = 0; i < ((h.tm || h.pre) ? 2 : 3); ++i) {
+  const bool split = d->dtype == VINET_F32S;
+  for (int i = split ? 1 : 0; i < ((h.tm || h.pre) && !split ? 2 : 3); ++i) {
     const int bn = nts[i] * 16, pad = (N + bn - 1) / bn * bn;
     if (pad < bestpad) { bestpad = pad; best = nts[i]; }
   }
@@ -381,7 +385,8 @@ static HtShape ht_shape(const VinetConvDesc* d) {
   return h;
 }
 static bool use_ht(const VinetConvDesc* d) {
-  if (!g_vinet_opt_ht || !use_dma(d) || (d->pre.relu && !d->pre.scale)) return false;
+  const bool split = d->dtype == VINET_F32S;
+  if (!g_vinet_opt_ht || !(split ? g_vinet_opt_ht3 && use_dma3(d) : use_dma(d)) || (d->pre.relu && !d->pre.scale)) return false;
   const bool tm = ht_temporal(d);
   if (!tm && d->tline != 5) return false;
   if (d->pre.scale && !(d->pre.relu && d->pre.shift && d->Kp <= 1024)) return false;
@@ -389,12 +394,12 @@ static bool use_ht(const VinetConvDesc* d) {
   if (tm ? ((d->oH * d->oW) % 16 != 0 || d->oT != d->x.T) : (d->oW % 16 != 0)) return false;
   if (g_vinet_opt_ht >= 2) return true;
   if (tm && !(g_vinet_opt_ht_t)) return false;
-  if (!tm && d->pre.scale && !g_vinet_opt_ht_pre) return false;
+  if (!tm && d->pre.scale && !g_vinet_opt_ht_pre && !split) return false;      // (split form: no materialisation pass exists to lose; its weight gradients split x with the affine applied)
   // measured (tools/conv_ab.py --ht, 64 clips): wins wherever the 64-channel K chunks are (nearly) full -- 504 -> 995 TF/s on
   // the 192 -> 64 5x3x3 decoder conv, 528 -> 840 on the data gradient of 64 -> 192, 894 -> 1026 on 480 -> 192 (conv_pp before),
   // 331 -> 510 on 64 -> 32 -- and loses where a chunk is half padding (Cin = 32: 410 -> 310; Cin = 96: 608 -> 535)
   const int N = d->y.C;
-  const int k64 = (d->Kp + 63) / 64 * 64;
+  const int k64 = split ? d->Kp : (d->Kp + 63) / 64 * 64;     // (split form: K steps of 32 channels, never padded)
   // a grid that cannot fill the chip (batch-1 inference: 84 tiles for the 192 -> 64 decoder conv) stays with conv_dma, which
   // splits its K loop over workgroups there (561 fps at batch 1 with graph replay; 515 with the halo tiles)
   const HtShape h = ht_shape(d);
@@ -468,8 +473,9 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   else if (use_pw(d)) snprintf(buf, n, "conv_pw_kernel<%d,%s>", pw_shape(d).nt * 16, d->pre.scale ? "pre" : "plain");
   else if (use_ht(d)) {
     const HtShape h = ht_shape(d);
-    if (h.tm) snprintf(buf, n, "conv_ht_kernel<%d,t,%s>", h.nt * 16, h.pre ? "pre" : "plain");
-    else snprintf(buf, n, h.pre ? "conv_ht_kernel<%d,%d,pre>" : "conv_ht_kernel<%d,%d>", h.nt * 16, h.tw);
+    const char* fam = d->dtype == VINET_F32S ? "conv_ht3_kernel" : "conv_ht_kernel";     // (ht3: the split-bf16 instantiations)
+    if (h.tm) snprintf(buf, n, "%s<%d,t,%s>", fam, h.nt * 16, h.pre ? "pre" : "plain");
+    else snprintf(buf, n, h.pre ? "%s<%d,%d,pre>" : "%s<%d,%d>", fam, h.nt * 16, h.tw);
   }
   else if (use_pp(d)) snprintf(buf, n, "conv_pp_kernel<%d>", pp_bn(d->y.C));
   else if (use_dma(d)) snprintf(buf, n, "conv_dma_kernel<%d,%d,%d,%d,3,%s>", t.MT, t.NT, t.WM, t.WN, d->pre.scale ? "pre" : "plain");
@@ -520,7 +526,8 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
     }
     a.ht_dN = make_fastdiv((uint32_t)a.tilesN); a.ht_dW = make_fastdiv((uint32_t)a.ht_tilesW);
     a.ht_dH = make_fastdiv((uint32_t)a.ht_tilesH);
-    return vinet_launch_conv_ht_bf16(h.nt, h.tw, h.tm, h.pre, a, (hipStream_t)stream);
+    return d->dtype == VINET_F32S ? vinet_launch_conv_ht_f32s(h.nt, h.tw, h.tm, h.pre, a, (hipStream_t)stream)
+                                  : vinet_launch_conv_ht_bf16(h.nt, h.tw, h.tm, h.pre, a, (hipStream_t)stream);
   }
   if (use_pp(d)) {
     const int bn = pp_bn(a.N);

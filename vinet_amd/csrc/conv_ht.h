@@ -33,8 +33,15 @@
 // taps are three ROW offsets into it: every activation byte is staged once per 4 output frames instead of three times.
 // PRE: a pending BatchNorm + ReLU of the input (the conv_t of a SepConv3d reads conv_s's raw output) is applied ONCE per
 // staged element, in LDS, by the wave that staged it -- conv_dma's PRE form pays it at every fragment read, i.e. per tap.
-template <int NT, int TW, int BSLOTS, bool TM = false, bool PRE = false>
+// SPLIT (VINET_F32S, conv_dma3.h's arithmetic on this kernel's tiles): fp32 activations, so a 128-byte halo row holds 32 channels
+// and a K step is (tap, 32 channels); the weight rows are [32 bf16 hi | 32 bf16 lo] of vinet_pack_weights(VINET_F32S) -- the same
+// 128 bytes, pieces and swizzle as the bf16 form.  A fragment read fetches pieces q and q + 4 of a row in both forms: 2 x 8 bf16
+// there, 8 fp32 here (split into hi / lo in registers, once per fragment and K step: three MFMAs per product).
+template <int NT, int TW, int BSLOTS, bool TM = false, bool PRE = false, bool SPLIT = false>
 struct ConvHtCfg {
+  static constexpr int KC = SPLIT ? 32 : 64;            // channels per K step
+  static constexpr int ES = SPLIT ? 4 : 2;              // bytes per activation element
+  static constexpr int PE = 16 / ES;                    // elements per 16-byte piece
   static constexpr int THREADS = 256, BM = 256, TR = TM ? 4 : BM / TW, HW = TM ? 64 : TW + 2, HR = TR + 2;
   static constexpr int NPOS = HR * HW;                  // halo positions
   static constexpr int HPIECES = (NPOS + 7) / 8;        // DMA pieces of 8 positions x 128 B
@@ -54,10 +61,10 @@ struct ConvHtCfg {
   static_assert(BSLOTS >= 2 && BL * (BSLOTS - 2) <= 63, "vmcnt immediate range");
 };
 
-template <int NT, int TW, int BSLOTS, bool TM, bool PRE>
+template <int NT, int TW, int BSLOTS, bool TM, bool PRE, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
-  using Cfg = ConvHtCfg<NT, TW, BSLOTS, TM, PRE>;
-  constexpr int HW = Cfg::HW, TR = Cfg::TR, HL = Cfg::HL, BL = Cfg::BL, MT = 4;
+  using Cfg = ConvHtCfg<NT, TW, BSLOTS, TM, PRE, SPLIT>;
+  constexpr int HW = Cfg::HW, TR = Cfg::TR, HL = Cfg::HL, BL = Cfg::BL, MT = 4, KC = Cfg::KC, ES = Cfg::ES, PE = Cfg::PE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo = smem;
   char* const bring = smem + Cfg::HALO_BYTES;
@@ -94,16 +101,16 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
     const int hr = p / HW, hc = p - hr * HW;
     if constexpr (TM) {     // halo row = frame t0 - 1 + hr (added at issue time: uniform per piece), column = position p0 + hc
       const bool ok = (p < Cfg::NPOS) & (p0 + hc < HWtot);
-      hal_off[j] = ok ? (p0 + hc) * a.ldx + src_chunk * 8 : 0;
+      hal_off[j] = ok ? (p0 + hc) * a.ldx + src_chunk * PE : 0;
       hal_ok |= (unsigned)ok << j;
     } else {
       const int h = h0 - 1 + hr, w = w0 - 1 + hc;
       const bool ok = (p < Cfg::NPOS) & ((unsigned)h < (unsigned)a.Hi) & ((unsigned)w < (unsigned)a.Wi);
-      hal_off[j] = ok ? (h * a.Wi + w) * a.ldx + src_chunk * 8 : 0;
+      hal_off[j] = ok ? (h * a.Wi + w) * a.ldx + src_chunk * PE : 0;
       hal_ok |= (unsigned)ok << j;
     }
   }
-  const char* const xb = a.x + (long)b * a.sBx * 2;
+  const char* const xb = a.x + (long)b * a.sBx * ES;
   const long frame_elems = (long)a.Hi * a.Wi * a.ldx;
   long b_off[BL];
   unsigned b_ok[BL];
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
     const int n = (j * 4 + wave) * 8 + prow;
     const int nn = tile_n * Cfg::BN + n;
     b_ok[j] = (unsigned)(nn < a.Nw);
-    b_off[j] = ((long)(b_ok[j] ? nn : 0) * a.Kp + src_chunk * 8) * 2;
+    b_off[j] = ((long)(b_ok[j] ? nn : 0) * a.Kp * (SPLIT ? 2 : 1) + src_chunk * 8) * 2;      // (split: a row is Kp hi + Kp lo)
   }
-  const long slice_bytes = (long)a.Nw * a.Kp * 2;
+  const long slice_bytes = (long)a.Nw * a.Kp * (SPLIT ? 4 : 2);
 
   auto dma = [&](const char* src, char* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -124,15 +131,15 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   // which of this lane's halo elements are real activations in the image staged last (PRE: the others must stay zero)
   unsigned hal_live = 0;
   auto issue_halo = [&](int dt, int c0) {
-    const unsigned cok = (unsigned)(c0 + src_chunk * 8 < a.Cin);
+    const unsigned cok = (unsigned)(c0 + src_chunk * PE < a.Cin);
     hal_live = 0;
 #pragma unroll
     for (int j = 0; j < HL; ++j) {
       // spatial: one frame (temporal offset dt of the tap group); temporal: piece (j, wave) belongs to frame to - 1 + its halo row
       const int t = TM ? to - 1 + ((j * 4 + wave) * 8) / HW : to * a.sT + dt;
       const unsigned ok = cok & (unsigned)((unsigned)t < (unsigned)a.Ti) & ((hal_ok >> j) & 1u);
-      const char* base = xb + ((long)t * frame_elems + c0) * 2;
-      const char* src = zero + (((base + (long)hal_off[j] * 2) - zero) & -(long)ok);
+      const char* base = xb + ((long)t * frame_elems + c0) * ES;
+      const char* src = zero + (((base + (long)hal_off[j] * ES) - zero) & -(long)ok);
       dma(src, halo + (j * 4 + wave) * 1024);
       hal_live |= ok << j;
     }
@@ -141,6 +148,19 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   // barrier that publishes the image); padding stays zero
   float* const aff = (float*)(smem + Cfg::KLOOP_BYTES);
   auto xform_halo = [&](int c0) {
+    if constexpr (SPLIT) {     // this lane's piece = 4 fp32 channels c0 + 4 src_chunk .. + 3
+      const float* sp_ = aff + c0 + src_chunk * 4;
+      const float4 sc = *(const float4*)sp_, sh = *(const float4*)(sp_ + a.Kp);
+#pragma unroll
+      for (int j = 0; j < HL; ++j) {
+        float4* q = (float4*)(halo + (j * 4 + wave) * 1024 + lane * 16);
+        const float4 v = *q;
+        const bool live = (hal_live >> j) & 1u;
+        *q = live ? make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f), fmaxf(fmaf(v.z, sc.z, sh.z), 0.f),
+                                fmaxf(fmaf(v.w, sc.w, sh.w), 0.f))
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
     const float* sp_ = aff + c0 + src_chunk * 8;
     const float4 s0 = *(const float4*)sp_, s1 = *(const float4*)(sp_ + 4);
     const float4 h0_ = *(const float4*)(sp_ + a.Kp), h1_ = *(const float4*)(sp_ + a.Kp + 4);
@@ -153,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
       const uint32_t m = (hal_live >> j) & 1u ? 0xffffffffu : 0u;
       *q = make_uint4(pre_relu_pair(v.x, sc2[0], sh2[0]) & m, pre_relu_pair(v.y, sc2[1], sh2[1]) & m,
                       pre_relu_pair(v.z, sc2[2], sh2[2]) & m, pre_relu_pair(v.w, sc2[3], sh2[3]) & m);
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the raw s_barrier that follows does not wait for LDS stores)
   };
@@ -167,8 +188,8 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   // weight tile of (slice, c0) into ring slot `slot`; live == false: the same number of DMAs from the zero page
   auto issue_b = [&](int slot, bool live, int slice, int c0) {
     char* dst = bring + slot * Cfg::BSLOT_BYTES + wave * 1024;
-    const long delta = (long)slice * slice_bytes + (long)c0 * 2;
-    const unsigned cok = (unsigned)live & (unsigned)(c0 + src_chunk * 8 < a.Kp);
+    const long delta = (long)slice * slice_bytes + (long)c0 * (SPLIT ? 4 : 2);
+    const unsigned cok = (unsigned)live & (unsigned)(SPLIT || c0 + src_chunk * 8 < a.Kp);
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
       const unsigned ok = cok & b_ok[j];
@@ -219,6 +240,41 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
 
   auto compute = [&](int slot, int tapoff) {
     const char* Bs = bring + slot * Cfg::BSLOT_BYTES;
+    if constexpr (SPLIT) {
+      // 8 fp32 of this lane's K group (pieces q and q + 4 of the row: the K order the hi / lo weight planes are packed in)
+      uint4 ar[MT][2];
+      bf16x8_v bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int p = pl[i] + tapoff;
+        ar[i][0] = *(const uint4*)(halo + (p << 7) + ((kq ^ (p & 7)) << 4));
+        ar[i][1] = *(const uint4*)(halo + (p << 7) + (((4 + kq) ^ (p & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = *(const bf16x8_v*)(Bs + j * 2048 + bfo0);
+        bl[j] = *(const bf16x8_v*)(Bs + j * 2048 + bfo1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8_v ah[MT], al[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        union { bf16x8_v v; uint32_t u[4]; } H, Lo;
+        split_pair(__uint_as_float(ar[i][0].x), __uint_as_float(ar[i][0].y), H.u[0], Lo.u[0]);
+        split_pair(__uint_as_float(ar[i][0].z), __uint_as_float(ar[i][0].w), H.u[1], Lo.u[1]);
+        split_pair(__uint_as_float(ar[i][1].x), __uint_as_float(ar[i][1].y), H.u[2], Lo.u[2]);
+        split_pair(__uint_as_float(ar[i][1].z), __uint_as_float(ar[i][1].w), H.u[3], Lo.u[3]);
+        ah[i] = H.v; al[i] = Lo.v;
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {     // small terms first; weights as the A operand (transposed tile: conv_epilogue)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        }
+    } else {
     // all fragment reads of the K step are issued before its first MFMA (the second half's LDS latency hides behind
     // the first half's MFMAs; hipcc otherwise reads, waits, multiplies, reads, waits, multiplies)
     bf16x8_v af[2][MT], bfr[2][NT];
@@ -239,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) mfma_bf16_acc_t(acc[i][j], af[kk][i], bfr[kk][j]);
+    }
   };
 
   // ---- pipeline ----------------------------------------------------------------------------------------------------------
@@ -274,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
       const uint32_t w16 = j < 8 ? (uint32_t)(q >> ((j & 3) * 16)) : tq2;
       return w16 & 0xffffu;
     };
-    for (int c0 = 0; c0 < a.Kp; c0 += 64) {
+    for (int c0 = 0; c0 < a.Kp; c0 += KC) {
 #ifdef VINET_CONV_TIMING
       tm_h0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -323,10 +380,10 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int NT, int TW, int BSLOTS, bool TM = false, bool PRE = false>
+template <int NT, int TW, int BSLOTS, bool TM = false, bool PRE = false, bool SPLIT = false>
 static int launch_conv_ht_cfg(const ConvArgs& a, hipStream_t s) {
-  using Cfg = ConvHtCfg<NT, TW, BSLOTS, TM, PRE>;
-  auto kern = conv_ht_kernel<NT, TW, BSLOTS, TM, PRE>;
+  using Cfg = ConvHtCfg<NT, TW, BSLOTS, TM, PRE, SPLIT>;
+  auto kern = conv_ht_kernel<NT, TW, BSLOTS, TM, PRE, SPLIT>;
   static bool attr_done[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);

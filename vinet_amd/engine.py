@@ -1079,11 +1079,40 @@ class _NullCtx:
 # the weight gradient of the split-bf16 form (fp32s) as three launches of the bf16 kernels over hi / lo planes (0 = the dedicated
 # register-staged split kernel, conv_wgrad.hip)
 SPLIT_WGRAD_BF16 = int(os.environ.get("VINET_SPLIT_WGRAD_BF16", "1"))
+SPLIT_ON_MAIN = int(os.environ.get("VINET_SPLIT_ON_MAIN", "0"))
+# fp32s: deferral of the decoder's weight gradients (DEFER_DECODER_WGRAD) -- in this form the weight-gradient stream (three launches
+# per conv + the split passes) is the longer one, so it should start with the backward pass, not 35 ms into it
+DEFER_DECODER_WGRAD_F32S = int(os.environ.get("VINET_DEFER_DECODER_WGRAD_F32S", "0"))      # measured at 64 clips: 207.3 -> 212.5 clips/s
+
+
+def _split_planes_folded(ctx, x):
+    """hi / lo planes of the folded RGB stem input (import_video_folded): the zero-padded 4-channel buffer [B][T][H+6][Wp][4]
+    is split as a plain tensor; the planes are the same overlapped view (32 'channels' = 8 pixels, ld = 8) over each half."""
+    v = x.v
+    B, T, Hp, Wp = v.B, v.T, v.H, 2 * v.W
+    n = B * T * Hp * Wp * 4
+    src = View(v.buf, v.off, B, T, Hp, Wp, 4, 4, T * Hp * Wp * 4, F32)
+    acts = []
+    bufs = [torch.empty(n + 64, dtype=TORCH_DT[BF16], device=v.device) for _ in range(2)]
+    for b in bufs:
+        b[n:].zero_()
+    hi, lo = (View(b, 0, B, T, Hp, Wp, 4, 4, T * Hp * Wp * 4, BF16) for b in bufs)
+    ctx.call("vinet_split_bf16", C.byref(src.ct()), L.CAffine(None, None, 0), C.byref(hi.ct()), C.byref(lo.ct()), ctx.stream)
+    for b in bufs:
+        a = Act(View(b, 0, B, T, Hp, Wp // 2, 32, 8, T * Hp * Wp * 4, BF16))
+        a.fold = x.fold
+        acts.append(a)
+    return acts
 
 
 def _split_planes(ctx, x, dy):
     """hi / lo bf16 planes of a conv's input (pending affine applied) and of its output gradient: ((x_hi, x_lo), (dy_hi, dy_lo))"""
     out = []
+    if x.fold is not None:
+        hi = View.alloc(dy.B, dy.T, dy.H, dy.W, dy.C, BF16, dy.device)
+        lo = View.alloc(dy.B, dy.T, dy.H, dy.W, dy.C, BF16, dy.device)
+        ctx.call("vinet_split_bf16", C.byref(dy.ct()), L.CAffine(None, None, 0), C.byref(hi.ct()), C.byref(lo.ct()), ctx.stream)
+        return [tuple(_split_planes_folded(ctx, x)), (hi, lo)]
     for v, aff in ((x.v, x.affine()), (dy, L.CAffine(None, None, 0))):
         hi = View.alloc(v.B, v.T, v.H, v.W, v.C, BF16, v.device)
         lo = View.alloc(v.B, v.T, v.H, v.W, v.C, BF16, v.device)
@@ -1172,6 +1201,14 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         for w_ in plan.grad_targets():
             _param_grad(w_)          # (allocated on the main stream, not inside the side-stream context)
 
+        # fp32s: hi / lo planes of both operands for the three bf16 launches -- any conv with whole 8-channel groups, and the
+        # folded RGB stem (the row-streaming strip kernel, wgrad_hs.hip, over planes of the padded clip)
+        want_planes = bool(SPLIT_WGRAD_BF16 and ctx.cdt == F32S and fused_bnb is None and dy.C % 8 == 0 and x.v.dt == F32 and dy.dt == F32 and
+                           ((not plan.stem and x.fold is None and x.v.C % 8 == 0) or
+                            (plan.stem and x.fold is not None and x.scale is None and x.v.off == 0)))
+        # SPLIT_ON_MAIN: the split passes run on the main stream (the weight-gradient stream is the longer one in this form)
+        planes_main = _split_planes(ctx, x, dy) if (want_planes and SPLIT_ON_MAIN and ctx.side_stream() is not None) else None
+
         def wgrad_job():
             ctx._side_rr = (getattr(ctx, "_side_rr", -1) + 1) % N_SIDE_STREAMS
             side = ctx.side_stream(ctx._side_rr)
@@ -1209,9 +1246,8 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                     wd.max_cus = 256 if (tail or side is None) else (WGRAD_CUS_DEC if bn is None else WGRAD_CUS)
                     if DBG_SPIN_SIDE and side is not None:
                         ctx.lib.vinet_debug_spin(DBG_SPIN_SIDE, ctx.stream)
-                    planes = None
-                    if (SPLIT_WGRAD_BF16 and ctx.cdt == F32S and not plan.stem and x.fold is None and fused_bnb is None and
-                            x.v.C % 8 == 0 and dy.C % 8 == 0 and x.v.dt == F32 and dy.dt == F32):
+                    planes = planes_main
+                    if planes is None and want_planes:
                         planes = _split_planes(ctx, x, dy)
                     if planes is not None:
                         # the split-bf16 weight gradient as THREE launches of the bf16 kernels (the row- / frame-streaming ones
@@ -1219,14 +1255,14 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                         # weight-gradient kernel adds into dw; the pending affine of x went into its planes.
                         (xh, xl), (dh, dl) = planes
                         for xa, da in ((xh, dl), (xl, dh), (xh, dh)):      # small terms first
-                            wq = _wgrad_desc(ctx, plan, Act(xa), da, dw)
+                            wq = _wgrad_desc(ctx, plan, xa if isinstance(xa, Act) else Act(xa), da, dw)
                             wq.dtype, wq.max_cus = BF16, wd.max_cus
                             ctx.call("vinet_conv3d_wgrad", C.byref(wq), ctx.stream,
                                      tag=(_wgrad_kernel_name(ctx, wq) + " | wgrad(split x3) " + plan.site(x.v)) if PROFILER is not None else None,
                                      work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps / 3,
                                                bytes=float(x.v.nvox * plan.Cin * 2 + M * plan.N * 2 + plan.N * plan.Cin * plan.ntaps * 4)))
                         if side is not None:
-                            ctx.keep(xh.buf, xl.buf, dh.buf, dl.buf)
+                            ctx.keep(*((p.v if isinstance(p, Act) else p).buf for p in (xh, xl, dh, dl)))
                     else:
                         ctx.call("vinet_conv3d_wgrad", C.byref(wd), ctx.stream,
                                  tag=(_wgrad_kernel_name(ctx, wd) + " | wgrad " + plan.site(x.v)) if PROFILER is not None else None,
@@ -1251,7 +1287,8 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         # (Under stream capture too: the wrong encoder gradients of round 3's captured step came from the per-job joins of the
         # flush -- a fan-out of redundant graph edges that ROCm 7.2 replays wrongly, see Ctx.flush_deferred -- not from the
         # deferral; with one join per batch the captured step follows the eager trajectory.)
-        if DEFER_DECODER_WGRAD and bn is None and ctx.side_stream() is not None and (not ctx.capturing or os.environ.get("VINET_DBG_DEFER_IN_CAPTURE", "1") != "0"):
+        defer = DEFER_DECODER_WGRAD_F32S if ctx.cdt == F32S else DEFER_DECODER_WGRAD
+        if defer and bn is None and ctx.side_stream() is not None and (not ctx.capturing or os.environ.get("VINET_DBG_DEFER_IN_CAPTURE", "1") != "0"):
             ctx._deferred.append(wgrad_job)
         else:
             ctx.flush_deferred()
