@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--pw", action="store_true", help="A/B of the pointwise streaming kernel (conv_pw.h) against the default dispatch on the 1x1x1 sites")
     ap.add_argument("--opt", action="append", default=[], help="name=v0,v1,...: A/B of one library option on the library's own dispatch (one variant per value)")
     ap.add_argument("--default", action="store_true", help="one variant per library: its own dispatch, no option overrides (A/B of two builds)")
+    ap.add_argument("--tm", action="store_true", help="(3,1,1) temporal sites: the halo-tile temporal mode against the ping-pong GEMM kernel (taps re-staged, no halo reuse) and conv_dma")
     ap.add_argument("--acc", action="store_true", help="accumulate into y (the epilogue of a data gradient that joins an existing gradient)")
     args = ap.parse_args()
     libs = [(os.path.basename(p), bind(p)) for p in (args.lib or [L.LIB_PATH])]
@@ -131,6 +132,15 @@ def main():
             variants.append((ln + ":default+pre", lib, dict(pw=0), True))
             variants.append((ln + ":pw+pre", lib, dict(pw=2, pw_maxtn=99), True))
         libs = []
+    if args.tm:
+        for ln, lib in libs:
+            variants.append((ln + ":ht_t", lib, dict(ht=1, ht_t=1, pp=1), False))
+            variants.append((ln + ":pp192", lib, dict(ht=1, ht_t=0, pp=4), False))
+            variants.append((ln + ":pp256", lib, dict(ht=1, ht_t=0, pp=3), False))
+            variants.append((ln + ":dma", lib, dict(ht=1, ht_t=0, pp=0), False))
+            variants.append((ln + ":ht_t+pre", lib, dict(ht=1, ht_t=1, pp=1), True))
+            variants.append((ln + ":dma+pre", lib, dict(ht=1, ht_t=0, pp=0), True))
+        libs = []
     if args.ht:
         for ln, lib in libs:
             variants.append((ln + ":default", lib, dict(ht=0), False))
@@ -158,6 +168,8 @@ def main():
         if args.pw and k != (1, 1, 1):
             continue
         if args.ht and not ((k[1:] == (3, 3) and W % 16 == 0) or (k == (3, 1, 1) and (H * W) % 16 == 0)):
+            continue
+        if args.tm and k != (3, 1, 1):
             continue
         B = args.batch
         oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]

@@ -271,9 +271,10 @@ __global__ __launch_bounds__(256, WPE) void bn_bwd_reduce8_bf16_kernel(TView x, 
 }
 int g_vinet_opt_bn_lean = 1;    // register-lean bf16 BatchNorm-backward kernels (0 = the generic 8-channel forms)
 
+int g_vinet_opt_bn_rows = 1024;  // cap on the workgroups (= partial rows) of a channel reduction
 static inline int stats_rows_for(long nvox) {
   long rows = (nvox + 63) / 64;
-  if (rows > 1024) rows = 1024;
+  if (rows > g_vinet_opt_bn_rows) rows = g_vinet_opt_bn_rows;
   if (rows < 1) rows = 1;
   return (int)rows;
 }
