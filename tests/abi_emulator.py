@@ -183,7 +183,7 @@ class AbiEmulator:
         # conv_hs.hip::vinet_conv_use_hs -- the row-streaming strip kernel of the folded RGB stem
         if (d.tline == 2 and d.dtype == BF16 and d.out_dtype == BF16 and d.mode == 0 and d.x.C == 32 and d.x.ld == 8 and d.Kp == 32 and
                 d.ntaps == 7 and (d.sT, d.sH, d.sW) == (1, 2, 1) and N == 64 and d.oW % 64 == 0 and not d.pre.scale and not d.pre.relu and
-                not d.accumulate and d.x.B * d.oT * (d.oW // 64) >= 2048 and d.oH >= 8):
+                not d.accumulate and d.x.B * d.oT * (d.oW // 64) >= 512 and d.oH >= 8):
             return 64
         # conv_api.hip::use_pp -- the 256x256x64 kernel takes large plain bf16 convs
         if d.dtype == BF16 and d.mode == 0 and not d.pre.scale and not d.pre.relu and d.ntaps <= 64:

@@ -1023,6 +1023,97 @@ def test_pack_unpack(dt):
         assert float(dw2.get("cpu").abs().max()) == 0.0 and float(dws2.get("cpu").abs().max()) == 0.0
 
 
+PACK_SHAPES = [(48, 24, 9), (100, 40, 27), (192, 480, 45), (16, 1, 64), (32, 16, 32), (7, 5, 1), (130, 70, 3), (256, 832, 1),
+               (8, 8, 300), (33, 65, 2), (64, 64, 7)]
+
+
+@pytest.mark.parametrize("tiled", [1, 0], ids=["tiled", "elementwise"])
+@pytest.mark.parametrize("pdt", [L.F32, L.BF16, L.F32S], ids=["f32", "bf16", "f32s"])
+def test_pack_weights_multi_matches_single_packs(pdt, tiled):
+    """vinet_pack_weights_multi (LDS-tiled kernel and its element-wise predecessor, option pack_tiled) against one
+    vinet_pack_weights per job, bit for bit: plain and transposed packs of odd shapes (row / column tails, 1 ... 300 taps, the
+    64-tap SoundNet conv, padding columns), the 7 x 7 stem, and the side-by-side transposed form of the joint entry convs
+    (ld / col: only the job's own columns may be written)"""
+    lib = _lib()
+    dev = _dev()
+    es = 4 if pdt in (L.F32, L.F32S) else 2
+    tdt = torch.float32 if es == 4 else torch.bfloat16
+    jobs, refs, outs, keep = [], [], [], []
+    off = 0
+    for i, (N, Cin, nt) in enumerate(PACK_SHAPES):
+        w = _rand("pmw%d" % i, (N * Cin * nt,), 1).cuda()
+        keep.append(w)
+        for tr in (0, 1):
+            rows, kp = (N, E.rup(Cin, 32)) if not tr else (Cin, E.rup(N, 32))
+            n = nt * rows * kp
+            ref = torch.full((n,), 7.0, dtype=tdt, device=dev)
+            assert lib.vinet_pack_weights(w.data_ptr(), N, Cin, nt, tr, 0, pdt, ref.data_ptr(), _stream()) == 0
+            out = torch.full((n,), 7.0, dtype=tdt, device=dev)
+            jobs.append([w.data_ptr(), out.data_ptr(), N, Cin, nt, tr, off, 0])
+            off += n
+            refs.append(ref); outs.append(out)
+    # the stem
+    ws = _rand("pmws", (64 * 3 * 49,), 2).cuda()
+    refs_ = torch.full((7 * 64 * 32,), 7.0, dtype=tdt, device=dev)
+    assert lib.vinet_pack_weights(ws.data_ptr(), 64, 3, 49, 0, 1, pdt, refs_.data_ptr(), _stream()) == 0
+    outs_ = torch.full((7 * 64 * 32,), 7.0, dtype=tdt, device=dev)
+    jobs.append([ws.data_ptr(), outs_.data_ptr(), 64, 3, 49, 2, off, 0])
+    off += 7 * 64 * 32
+    refs.append(refs_); outs.append(outs_)
+    # two pointwise convs over one 40-channel input, transposed side by side: rows of ld = 96 elements, columns [0, 24) and [32, 82)
+    if pdt != L.F32S:      # (the split form's pack permutes K inside 32-column groups: the engine packs joint convs for it the same way, covered by the model tests)
+        joint = torch.full((40 * 96,), 7.0, dtype=tdt, device=dev)
+        jref = joint.clone().view(40, 96)
+        for (Nm, col, seed) in ((24, 0, 3), (50, 32, 4)):
+            wm = _rand("pmj%d" % col, (Nm * 40,), seed).cuda()
+            keep.append(wm)
+            jobs.append([wm.data_ptr(), joint.data_ptr(), Nm, 40, 1, 1, off, 96 | (col << 32)])
+            off += 40 * E.rup(Nm, 32)
+            jref[:, col:col + Nm] = wm.view(Nm, 40).t().to(tdt)
+        refs.append(jref.reshape(-1)); outs.append(joint)
+    table = torch.tensor(jobs + [[0, 0, 0, 0, 0, 0, off, 0]], dtype=torch.int64).cuda()
+    assert lib.vinet_set_option(b"pack_tiled", tiled) == 0
+    try:
+        rc = lib.vinet_pack_weights_multi(table.data_ptr(), len(jobs), off, pdt, _stream())
+        assert rc == 0, lib.vinet_last_error()
+        torch.cuda.synchronize()
+    finally:
+        lib.vinet_set_option(b"pack_tiled", 1)
+    for k, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o.view(torch.int32 if es == 4 else torch.int16), r.view(torch.int32 if es == 4 else torch.int16)), "job %d differs" % k
+
+
+@pytest.mark.parametrize("tiled", [1, 0], ids=["tiled", "elementwise"])
+def test_unpack_wgrad_multi_matches_single_unpacks(tiled):
+    """vinet_unpack_wgrad_multi (LDS-tiled / element-wise) against one vinet_unpack_wgrad per job: grad += dw bit for bit, every
+    packed element (padding columns included) handed back zero"""
+    lib = _lib()
+    jobs, checks = [], []
+    off = 0
+    for i, (N, Cin, nt) in enumerate(PACK_SHAPES + [(64, 3, 49)]):
+        stem = 1 if (N, Cin, nt) == (64, 3, 49) else 0
+        nsl, kp = (7, 32) if stem else (nt, E.rup(Cin, 32))
+        dw = _rand("umd%d" % i, (nsl * N * kp,), 5).cuda()
+        g0 = _rand("umg%d" % i, (N * Cin * nt,), 6).cuda()
+        ref, dwr = g0.clone(), dw.clone()
+        assert lib.vinet_unpack_wgrad(dwr.data_ptr(), N, Cin, nt, stem, 3, ref.data_ptr(), _stream()) == 0
+        g = g0.clone()
+        jobs.append([dw.data_ptr(), g.data_ptr(), N, Cin, nt, stem, off, 0])
+        off += nsl * N * kp
+        checks.append((dw, g, ref, dwr))
+    table = torch.tensor(jobs + [[0, 0, 0, 0, 0, 0, off, 0]], dtype=torch.int64).cuda()
+    assert lib.vinet_set_option(b"pack_tiled", tiled) == 0
+    try:
+        rc = lib.vinet_unpack_wgrad_multi(table.data_ptr(), len(jobs), off, 3, _stream())
+        assert rc == 0, lib.vinet_last_error()
+        torch.cuda.synchronize()
+    finally:
+        lib.vinet_set_option(b"pack_tiled", 1)
+    for k, (dw, g, ref, dwr) in enumerate(checks):
+        assert torch.equal(g, ref), "job %d: gradients differ" % k
+        assert float(dw.abs().max()) == 0.0 and float(dwr.abs().max()) == 0.0, "job %d: workspace not handed back zeroed" % k
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_import_export_copy(dt):
     B, Cc, T, H, W = 2, 3, 4, 6, 10

@@ -164,6 +164,7 @@ extern int g_vinet_opt_wgrad_tf;
 extern int g_vinet_opt_wgrad_skinny;
 extern int g_vinet_opt_bn_lean;
 extern int g_vinet_opt_bn_rows;
+extern int g_vinet_opt_pack_tiled;
 
 extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   if (!d) return -1;
@@ -244,6 +245,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "ht32")) { g_vinet_opt_ht32 = value; return 0; }
   if (name && !strcmp(name, "ht3")) { g_vinet_opt_ht3 = value; return 0; }
   if (name && !strcmp(name, "bn_lean")) { g_vinet_opt_bn_lean = value; return 0; }
+  if (name && !strcmp(name, "pack_tiled")) { g_vinet_opt_pack_tiled = value; return 0; }
   if (name && !strcmp(name, "bn_rows")) { g_vinet_opt_bn_rows = value < 1 ? 1 : value; return 0; }
   if (name && !strcmp(name, "ht_minhw")) { g_vinet_opt_ht_minhw = value; return 0; }
   if (name && !strcmp(name, "ht_t")) { g_vinet_opt_ht_t = value; return 0; }

@@ -177,7 +177,7 @@ bool vinet_conv_use_hs(const VinetConvDesc* d) {
                      ((uintptr_t)d->x.ptr % 16) == 0 && ((uintptr_t)d->y.ptr % 16) == 0;
   if (!shape) return false;
   if (g_vinet_opt_conv_hs >= 2) return true;
-  return (long)d->x.B * d->oT * (d->oW / 64) >= 2048 && d->oH >= 8;
+  return (long)d->x.B * d->oT * (d->oW / 64) >= 512 && d->oH >= 8;      // (from 6 clips of 32 x 224 x 384 on: 8 clips 385 -> 402 clips/s with both strip kernels, profiles/r4_experiments.txt)
 }
 
 int vinet_launch_conv_hs(const VinetConvDesc* d, hipStream_t s) {

@@ -206,7 +206,7 @@ bool vinet_wgrad_use_hs(const VinetWgradDesc* d) {
                      ((uintptr_t)d->dy.ptr % 16) == 0;
   if (!shape) return false;
   if (g_vinet_opt_wgrad_hs >= 2) return true;
-  return (long)d->dy.B * d->dy.T * (d->dy.W / 64) >= 2048 && d->dy.H >= 8;
+  return (long)d->dy.B * d->dy.T * (d->dy.W / 64) >= 512 && d->dy.H >= 8;
 }
 
 int vinet_launch_wgrad_hs(const VinetWgradDesc* d, hipStream_t s) {
