@@ -279,7 +279,7 @@ def extras(args, dev):
         # operands (VINET_F32S; tests/test_gpu_model.py::test_e2e_split_bf16_parity_gate holds 1e-4 and the exact argmax)
         res["parity_path"] = leg(lambda: dict(train_cfg(dtype="fp32s", batch=64),
                                               note="fp32 tensors + split-bf16 matrix arithmetic (3 MFMAs per product, 16 significant bits per operand; forward / data "
-                                                   "gradients: conv_dma3, weight gradients: three launches of the bf16 streaming kernels over hi / lo planes): "
+                                                   "gradients: split halo-tile kernels (conv_ht.h SPLIT) and conv_dma3, weight gradients: three launches of the bf16 streaming kernels over hi / lo planes): "
                                                    "same gate as fp32_path (<= 1e-3 abs, bit-exact argmax on all five goldens + AViNet)"))
     if (args.clip, args.height, args.width) == (32, 224, 384) and args.model == "vinet":
         res["other_configs"] = {

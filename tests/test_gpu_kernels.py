@@ -563,7 +563,10 @@ def _run_conv_case(case, dt, forced=False, want_y=False, cdt=None, tol=None):
         bm = _lib().vinet_conv3d_tile_m(C.byref(d0))
         assert forced or bm == AbiEmulator().vinet_conv3d_tile_m(d0)
         r = _lib().vinet_conv3d_stats_rows(C.byref(d0))
-        assert (r >= (M + bm - 1) // bm or ex.get("tline") == 6) and (forced or r == AbiEmulator().vinet_conv3d_stats_rows(d0))   # (pointwise: one row per workgroup)
+        nbuf = C.create_string_buffer(128)
+        _lib().vinet_conv3d_kernel_name(C.byref(d0), nbuf, 128)
+        per_item = nbuf.value.startswith(b"conv_ts_kernel") or nbuf.value.startswith(b"conv_hs_kernel")    # one row per 64-position item, all its frames / rows
+        assert (r >= (M + bm - 1) // bm or ex.get("tline") == 6 or per_item) and (forced or r == AbiEmulator().vinet_conv3d_stats_rows(d0))   # (pointwise: one row per workgroup)
         assert r <= rows
         rc = AbiEmulator().vinet_conv3d_stats_rows(d0)
         sg = stats.get("gpu")[:r * 2 * N].view(r, 2, N).double().sum(0)

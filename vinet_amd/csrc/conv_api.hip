@@ -179,6 +179,10 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
 extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
   if (!d) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
+  // the strip / frame-streaming kernels of the stem keep their partial sums in registers over a whole item (a 64-wide strip of
+  // one frame, 64 positions of one clip) and write ONE row per item
+  if (vinet_conv_use_hs(d)) return (int)((long)d->x.B * d->oT * (d->oW / 64));
+  if (vinet_conv_use_ts(d)) return (int)((long)d->x.B * (((long)d->oH * d->oW) / 64));
   if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_pw(d)) return pw_shape(d).gm;   // one row per workgroup (4 waves x up to 16 tiles of 64 rows)
   if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_ht(d)) {
     const HtShape h = ht_shape(d);

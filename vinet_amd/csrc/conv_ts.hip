@@ -40,13 +40,25 @@ struct ConvTsArgs {
 // either file.  Wherever the register allocator keeps a value, it may copy it (v_accvgpr_write / _read) right in
 // front of the inline-asm MFMA, a VALU-write -> MFMA-read hazard it cannot see through the asm: every MFMA
 // carries its own wait states.  (4 cycles x 56 MFMAs per output frame, against ~3000 cycles of HBM time.)
+// Operands SWAPPED (round 4): the weights are the A operand, so the accumulators arrive transposed -- lane (p = lane & 15,
+// q = lane >> 4) holds 4 consecutive CHANNELS 4q .. 4q+3 of position p per 16 x 16 tile: the epilogue packs them with two
+// conversions and ONE 8-byte LDS write per tile instead of four 2-byte ones with their address arithmetic (the kernel was
+// VALU-issue bound on that: ~12 instructions per output element, ~5 now), and the BN partial sums stay in registers over all
+// output frames of the item (one `stats` row per item).
 VN_DEV void mfma_bf16_acc_bacc(f32x4_v& acc, const bf16x8_v& a, const bf16x8_v& b) {
-  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b));
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(b), "v"(a));
 }
 // first MFMA of an output frame: C = 0 as an inline constant (early clobber: the result must not share registers
-// with B)
+// with the weights)
 VN_DEV void mfma_bf16_first_bacc(f32x4_v& acc, const bf16x8_v& a, const bf16x8_v& b) {
-  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "a"(b));
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc) : "a"(b), "v"(a));
+}
+VN_DEV float ts_row16_sum(float v) {      // sum over the 16 lanes of a row (DPP row_ror 8, 4, 2, 1): every lane gets the total
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
 }
 
 template <bool PRE>
@@ -107,13 +119,23 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
         for (int ks = 0; ks < 2; ++ks) wr[i][nt][ks] = (bf16x8_v){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
-  // epilogue constants of this lane's two output channels
-  float osc[2], osh[2];
+  // epilogue role: position p of a 16-row tile, channel quad q of a 16-column tile; constants of my 2 x 4 output channels
+  const int ep = lane & 15, eq = lane >> 4;
+  float osc[2][4], osh[2][4];
+  int st_off[2][2];                                    // byte offset of my 8 bytes (4 channels) of tile (mt, nt) in the output stage
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    const int n = wn * 32 + nt * 16 + (lane & 15);
-    osc[nt] = a.out_scale ? a.out_scale[n] : 1.f;
-    osh[nt] = a.out_shift ? a.out_shift[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wn * 32 + nt * 16 + eq * 4 + r;
+      osc[nt][r] = a.out_scale ? a.out_scale[n] : 1.f;
+      osh[nt][r] = a.out_shift ? a.out_shift[n] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = wm * 32 + mt * 16 + ep, col = wn * 32 + nt * 16 + eq * 4;
+      st_off[mt][nt] = row * 128 + (((col >> 3) ^ (row & 7)) * 16) + (col & 7) * 2;
+    }
   }
   const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;
   const bool sigm = a.act == VINET_ACT_SIGMOID;
@@ -140,6 +162,13 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
       *(uint4*)(slot + l_off[1]) = v1;
     }
     __syncthreads();
+
+    // BN partial sums of my 2 x 4 channels over every output frame of the item (one `stats` row per ITEM)
+    float ssum[2][4], ssq[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
 
     for (int to = 0; to < a.To; ++to) {
       // ---- loads of the next step's s new frames (named scalars, unconditional: see wgrad_ts.hip) ----------
@@ -183,35 +212,22 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
         }
       }
       mfma_drain();
-      // ---- epilogue: lane holds rows (lane>>4)*4 + r of each 16-row tile, column lane & 15 -------------------
-      float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+      // ---- epilogue: lane holds channels 4q .. 4q+3 of position p of each 16 x 16 tile ------------------------------
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
+          float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = fmaf(acc[mt][nt][r], osc[nt], osh[nt]);
-            ssum[nt] += v; ssq[nt] += v * v;
-            float o = fmaxf(v, relu_floor);
-            if (sigm) o = 1.f / (1.f + __expf(-o));
-            const int row = wm * 32 + mt * 16 + (lane >> 4) * 4 + r, col = wn * 32 + nt * 16 + (lane & 15);
-            *(bf16_t*)(stage + row * 128 + (((col >> 3) ^ (row & 7)) * 16) + (col & 7) * 2) = f2bf(o);
+            const float v = fmaf(acc[mt][nt][r], osc[nt][r], osh[nt][r]);
+            ssum[nt][r] += v; ssq[nt][r] = fmaf(v, v, ssq[nt][r]);
+            o[r] = fmaxf(v, relu_floor);
+            if (sigm) o[r] = 1.f / (1.f + __expf(-o[r]));
           }
-      if (a.stats) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          float ss = ssum[nt], qq = ssq[nt];
-          ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
-          qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
-          if (lane < 16) {
-            const int col = wn * 32 + nt * 16 + lane;
-            red[(wm * 64 + col) * 2 + 0] = ss;
-            red[(wm * 64 + col) * 2 + 1] = qq;
-          }
+          *(uint2*)(stage + st_off[mt][nt]) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
         }
-      }
-      __syncthreads();          // ring frames of this step are free, the output tile and the partial sums are complete
+      __syncthreads();          // ring frames of this step are free, the output tile is complete
       {
         uint4 o0 = *(const uint4*)(stage + l_off[0]), o1 = *(const uint4*)(stage + l_off[1]);
         if (a.accumulate) {
@@ -225,11 +241,6 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
         *(uint4*)yf = o0;
         *(uint4*)(yf + y_r32) = o1;
       }
-      if (a.stats && tid < 64) {
-        const long row = ((long)b * a.To + to) * a.patches + patch;       // = m / 64 of the tile's first voxel
-        a.stats[(row * 2 + 0) * 64 + tid] = red[tid * 2] + red[(64 + tid) * 2];
-        a.stats[(row * 2 + 1) * 64 + tid] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
-      }
       if (more) {
         const uint4 z = make_uint4(0, 0, 0, 0);
         char* slot0 = ring + ((pnew + 2 * KMAX) % k) * TILE;
@@ -240,6 +251,25 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
           *(uint4*)(slot1 + l_off[0]) = in1 ? xform(nx10) : z;
           *(uint4*)(slot1 + l_off[1]) = in1 ? xform(nx11) : z;
         }
+      }
+      __syncthreads();
+    }
+    if (a.stats) {     // once per item: 16 positions of a row by DPP, the two position halves (wm) in LDS
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ss = ts_row16_sum(ssum[nt][r]), qq = ts_row16_sum(ssq[nt][r]);
+          if (ep == 0) {
+            const int col = wn * 32 + nt * 16 + eq * 4 + r;
+            red[(wm * 64 + col) * 2 + 0] = ss;
+            red[(wm * 64 + col) * 2 + 1] = qq;
+          }
+        }
+      __syncthreads();
+      if (tid < 64) {
+        a.stats[((long)item * 2 + 0) * 64 + tid] = red[tid * 2] + red[(64 + tid) * 2];
+        a.stats[((long)item * 2 + 1) * 64 + tid] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
       }
       __syncthreads();
     }
@@ -339,6 +369,14 @@ __global__ __launch_bounds__(256, 2) void conv_tsd_kernel(const ConvTsdArgs a) {
         else wr[i][nt][ks] = (bf16x8_v){0, 0, 0, 0, 0, 0, 0, 0};
       }
   const bf16x8_v zero_a = (bf16x8_v){0, 0, 0, 0, 0, 0, 0, 0};
+  int st_off[2][2];                                    // byte offset of my 8 bytes (4 channels) of tile (mt, nt) in the output stage
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int row = wm * 32 + mt * 16 + (lane & 15), col = wn * 32 + nt * 16 + (lane >> 4) * 4;
+      st_off[mt][nt] = row * 128 + (((col >> 3) ^ (row & 7)) * 16) + (col & 7) * 2;
+    }
 
   for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
     const int b = (int)fdiv((uint32_t)item, a.dPatches);
@@ -398,15 +436,12 @@ __global__ __launch_bounds__(256, 2) void conv_tsd_kernel(const ConvTsdArgs a) {
         }
       }
       mfma_drain();
+      // lane (p = lane & 15, q = lane >> 4) holds channels 4q .. 4q+3 of position p of each tile (operands swapped): 8 bytes per tile
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int row = wm * 32 + mt * 16 + (lane >> 4) * 4 + rr, col = wn * 32 + nt * 16 + (lane & 15);
-            *(bf16_t*)(stage + row * 128 + (((col >> 3) ^ (row & 7)) * 16) + (col & 7) * 2) = f2bf(acc[mt][nt][rr]);
-          }
+          *(uint2*)(stage + st_off[mt][nt]) = make_uint2(pack2bf(acc[mt][nt][0], acc[mt][nt][1]), pack2bf(acc[mt][nt][2], acc[mt][nt][3]));
       __syncthreads();
       {
         uint4 o0 = *(const uint4*)(stage + l_off[0]), o1 = *(const uint4*)(stage + l_off[1]);

@@ -325,7 +325,8 @@ class VideoAudioSaliencyModel(nn.Module):
             self.load_soundnet(self.soundnet_checkpoint)
             print("Loaded SoundNet Weights")
         else:
-            print("SoundNet weights? (%s not found: default init)" % self.soundnet_checkpoint)
+            import sys
+            print("SoundNet weights? (%s not found: default init)" % self.soundnet_checkpoint, file=sys.stderr)   # (stderr: stdout of bench.py is ONE JSON line)
         self.maxpool = _Marker("maxpool3d", kernel_size=(4, 1, 1), stride=(2, 1, 2), padding=(0, 0, 0))
         self.bilinear = _BilinearParams(42, 3, 4 * 7 * 12)
 
