@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 10
+#define VINET_ABI_VERSION 11
 
 enum { VINET_F32 = 0, VINET_BF16 = 1,
        /* conv / weight-gradient descriptors only: fp32 tensors (as VINET_F32), bf16 matrix arithmetic on a two-term split of both
@@ -138,6 +138,20 @@ typedef struct VinetConvDesc {
                            weight tile in LDS and feeds the activations to the matrix cores straight from registers.
                            0 = no promise. */
   int32_t tpad;
+  /* Optional, data gradients only (ABI 11): y is the gradient g behind a BatchNorm (+ ReLU) whose RAW input is bnb_z -- same
+   * extent as y, rows of bnb_ld elements, clips bnb_sB elements apart, dtype of y; bnb_fwd = the forward affine of that
+   * BatchNorm (scale, shift, relu: the ReLU gate is scale * z + shift > 0), bnb_mean / bnb_invstd its batch statistics.
+   * With bnb_partials != NULL the launch ALSO writes the partial sums of vinet_bn_bwd_reduce(g, z) -- [rows][2][C] fp32,
+   * rows = vinet_conv3d_bn_bwd_stats_rows(desc) -- so the caller skips that pass (train.py:193 -> model_utils.py:145: the
+   * stem's first BatchNorm, whose gradient comes out of the fused temporal data gradient, tline == 3).  Only where the rows
+   * query returns > 0; accumulate must be 0. */
+  const void* bnb_z;
+  int32_t bnb_ld;
+  int64_t bnb_sB;
+  VinetAffine bnb_fwd;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  float* bnb_partials;
 } VinetConvDesc;
 
 int vinet_conv3d(const VinetConvDesc* desc, void* stream);
@@ -148,6 +162,10 @@ int vinet_conv3d(const VinetConvDesc* desc, void* stream);
 int64_t vinet_conv3d_splitk_bytes(const VinetConvDesc* desc);
 /* 1 if vinet_conv3d accepts this tline == 3 descriptor (fused stride phases of a temporal data gradient). */
 int vinet_conv3d_fuses_dgrad_phases(const VinetConvDesc* desc);
+/* Rows of BatchNorm-backward partial sums ([rows][2][C] fp32) that vinet_conv3d writes for this descriptor when bnb_partials is
+ * set (bnb_z, bnb_ld, bnb_sB, bnb_fwd, bnb_mean, bnb_invstd filled in; bnb_partials itself is not looked at); 0 = the kernel
+ * this problem takes cannot fold the reduce pass in: leave bnb_partials NULL and call vinet_bn_bwd_reduce. */
+int vinet_conv3d_bn_bwd_stats_rows(const VinetConvDesc* desc);
 /* 1 if the kernel vinet_conv3d picks for this problem applies the pending affine `pre` ONCE per staged activation (the
  * halo-tile kernel transforms its LDS image in place) rather than at every fragment read: callers that would otherwise
  * materialise relu(bn(x)) with vinet_copy_affine first can skip that pass. */

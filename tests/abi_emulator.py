@@ -218,6 +218,9 @@ class AbiEmulator:
         g = _gather(g, np.arange(oW) * d.sW + dw_, 3, x.shape[3])
         return g
 
+    def vinet_conv3d_bn_bwd_stats_rows(self, d):
+        return 0          # the model never folds the BatchNorm-backward reduce pass into a data gradient
+
     @_plain_f32
     def vinet_conv3d_fuses_dgrad_phases(self, d):
         d = _deref(d)

@@ -461,6 +461,72 @@ def test_conv3d_tstream_dgrad_fused(ksp, acc):
     _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt], "fused temporal dgrad")
 
 
+@pytest.mark.parametrize("relu", [1, 0], ids=["relu", "linear"])
+@pytest.mark.parametrize("ksp", [(7, 2, 3), (3, 2, 1)], ids=["k7s2p3", "k3s2p1"])
+def test_conv3d_tstream_dgrad_fused_bn_bwd_stats(ksp, relu):
+    """tline == 3 with VinetConvDesc::bnb_*: the launch also leaves the partial sums of vinet_bn_bwd_reduce(dx, z) -- against that
+    very pass run on the gradient the launch wrote (the ABI model's, summed over rows), on a sliced z view; dx itself unchanged"""
+    lib = _lib()
+    dt = E.BF16
+    k, s, p = ksp
+    B, Ti, H, W, Cc = 2, 11, 8, 16, 64
+    To = (Ti + 2 * p - k) // s + 1
+    xp, xmk = view_pair(B, To, H, W, Cc, dt, "bdy", 1, ld=96, c_off=16)
+    yp, ymk = view_pair(B, Ti, H, W, Cc, dt, "bdx", 2, fill=0.25)
+    yp0, ymk0 = view_pair(B, Ti, H, W, Cc, dt, "bdx0", 2, fill=0.5)
+    zp, zmk = view_pair(B, Ti, H, W, Cc, dt, "bz", 5, ld=160, c_off=32)
+    wp = Pair((_rand("bdw", (k * Cc * Cc,), 3, 0.05)).to(E.TORCH_DT[dt]))
+    sc, sh = fvec("bsc", Cc, 6, 0.5, 1.5), fvec("bsh", Cc, 7)
+    mean, invstd = fvec("bmu", Cc, 8), fvec("bis", Cc, 9, 0.5, 2.0)
+
+    def mk(side, bnb, ymk_):
+        d = L.CConvDesc()
+        d.dtype, d.out_dtype, d.mode = dt, dt, 0
+        d.x, d.y = xmk(side).ct(), ymk_(side).ct()
+        d.oT, d.oH, d.oW = Ti, H, W
+        d.sT, d.sH, d.sW = s, 1, 1
+        d.omT = d.omH = d.omW = 1
+        d.ntaps, d.taps, d.w, d.Kp = k, None, wp.ptr(side), 64
+        d.pre = L.CAffine(None, None, 0)
+        d.tline, d.tpad = 3, p
+        if bnb:
+            z = zmk(side)
+            d.bnb_z, d.bnb_ld, d.bnb_sB = z.ptr(), z.ld, z.sB
+            d.bnb_fwd = L.CAffine(sc.ptr(side), sh.ptr(side), relu)
+            d.bnb_mean, d.bnb_invstd = mean.ptr(side), invstd.ptr(side)
+        return d
+
+    assert lib.vinet_set_option(b"conv_ts", 2) == 0
+    try:
+        d = mk("gpu", True, ymk)
+        rows = lib.vinet_conv3d_bn_bwd_stats_rows(C.byref(d))
+        assert rows == B * (H * W) // 64
+        part = torch.full((rows * 2 * Cc,), float("nan"), device="cuda")
+        d.bnb_partials = part.data_ptr()
+        assert lib.vinet_conv3d(C.byref(d), _stream()) == 0, lib.vinet_last_error()
+        d0 = mk("gpu", False, ymk0)
+        assert lib.vinet_conv3d(C.byref(d0), _stream()) == 0, lib.vinet_last_error()
+        d.accumulate = 1
+        assert lib.vinet_conv3d_bn_bwd_stats_rows(C.byref(d)) == 0      # (an accumulating launch does not see the whole gradient)
+        torch.cuda.synchronize()
+    finally:
+        lib.vinet_set_option(b"conv_ts", 1)
+    assert torch.equal(yp.get("gpu"), yp0.get("gpu")), "dx differs with the statistics folded in"
+    # the separate pass of the ABI model on the gradient the GPU wrote
+    emu = AbiEmulator()
+    g_cpu = Pair(yp.get("gpu").clone())
+    gv = E.View(g_cpu.cpu, 0, B, Ti, H, W, Cc, Cc, Ti * H * W * Cc, dt)
+    zc = zmk("cpu")
+    r2 = emu.vinet_stats_rows(gv.ct())
+    ws = torch.zeros(r2 * 2 * Cc)
+    assert emu.vinet_bn_bwd_reduce(gv.ct(), zc.ct(), dt, L.CAffine(sc.ptr("cpu"), sh.ptr("cpu"), relu), mean.ptr("cpu"), invstd.ptr("cpu"),
+                                   ws.data_ptr(), 0) == 0
+    ref = ws.view(r2, 2, Cc).double().sum(0)
+    got = part.cpu().view(rows, 2, Cc).double().sum(0)
+    assert torch.isfinite(got).all()
+    _cmp(got, ref, 1e-3, "BatchNorm-backward partial sums out of the fused temporal data gradient")
+
+
 @pytest.mark.parametrize("r", [0, 1])
 def test_conv3d_tstream_dgrad_phase(r):
     """one stride phase of the 7x1x1 / 2 data gradient: taps (e - j, slice d0 + 2j) in descending offset order, output

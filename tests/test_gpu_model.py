@@ -790,6 +790,55 @@ def test_bench_self_spawn_path(tmp_path):
                                    backward_end_ms=ar["backward_end_ms"], buckets=ar["buckets"]))
 
 
+def test_stem_bn_backward_statistics_leave_with_the_temporal_data_gradient():
+    """The fused temporal data gradient of the stem's 7 x 1 x 1 / 2 conv (tline == 3) also writes the partial sums of the backward
+    reduce pass of the BatchNorm in front of it (VinetConvDesc::bnb_*; engine.DGRAD_BN_STATS): one vinet_bn_bwd_reduce launch
+    fewer per step, every gradient that does not pass through that BatchNorm unchanged, the three that do (the stem conv's
+    weight, its BatchNorm's weight and bias) equal up to the summation order of the statistics."""
+    from vinet_amd import _lib
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    E.set_default_dtype("bf16")
+    lib = _lib.load()
+    B, T, H, W = 2, 16, 64, 96
+    x = synth.clip(B, T, H, W, 11).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
+    gt = synth.gt_map(B, H, W, 11).to(DEV)
+    grads, counts = {}, {}
+    saved = E.DGRAD_BN_STATS
+    assert lib.vinet_set_option(b"conv_ts", 2) == 0          # (the frame-streaming kernels on this small clip too)
+    try:
+        for flag in (0, 1):
+            E.DGRAD_BN_STATS = flag
+            m = VM.VideoSaliencyModel(num_clips=T)
+            m.load_state_dict(synth.synth_state_dict(m.state_dict(), 11))
+            m = m.to(DEV).train()
+            for _ in range(2):
+                m.zero_grad()
+                E.LAUNCH_LOG = []
+                VL.kldiv(m(x), gt).backward()
+                log, E.LAUNCH_LOG = E.LAUNCH_LOG, None
+            torch.cuda.synchronize()
+            counts[flag] = sum(1 for l in log if l[0] == "vinet_bn_bwd_reduce")
+            grads[flag] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    finally:
+        E.DGRAD_BN_STATS = saved
+        E.LAUNCH_LOG = None
+        lib.vinet_set_option(b"conv_ts", 1)
+    assert counts[1] == counts[0] - 1, counts
+    through = ("backbone.base1.0.conv_s.weight", "backbone.base1.0.bn_s.weight", "backbone.base1.0.bn_s.bias")
+    worst = 0.0
+    for k, g0 in grads[0].items():
+        g1 = grads[1][k]
+        if k in through:
+            rel = float((g1.double() - g0.double()).norm() / (g0.double().norm() + 1e-30))
+            worst = max(worst, rel)
+            assert rel < 5e-3, "%s: %.3e" % (k, rel)
+        else:      # (untouched arithmetic; the fp32 atomics of the weight-gradient kernels leave their accumulation order free)
+            rel = float((g1.double() - g0.double()).norm() / (g0.double().norm() + 1e-30))
+            assert rel < 1e-5, "%s: %.3e" % (k, rel)
+    _note("stem_bn_bwd_stats_fused", dict(reduce_launches=counts, worst_rel_of_the_three=worst))
+
+
 def test_weight_gradient_stream_does_not_change_the_gradients():
     """The second HIP stream (weight gradients beside the data-gradient chain, decoder jobs deferred to the encoder's backward,
     one multi-job unpack at the end) is a schedule, not arithmetic: the gradients must equal those of the one-stream, per-conv

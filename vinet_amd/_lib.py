@@ -16,7 +16,7 @@ F32, BF16 = 0, 1
 F32S = 2     # conv / weight-gradient descriptors: fp32 tensors, split-bf16 matrix arithmetic (include/vinet_hip.h)
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class CTensor(C.Structure):
@@ -37,7 +37,9 @@ class CConvDesc(C.Structure):
                 ("ntaps", C.c_int32), ("taps", C.c_void_p), ("w", C.c_void_p), ("Kp", C.c_int32),
                 ("pre", CAffine), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p),
                 ("act", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p), ("n_valid", C.c_int32),
-                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("tline", C.c_int32), ("tpad", C.c_int32)]
+                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("tline", C.c_int32), ("tpad", C.c_int32),
+                ("bnb_z", C.c_void_p), ("bnb_ld", C.c_int32), ("bnb_sB", C.c_int64), ("bnb_fwd", CAffine),
+                ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p), ("bnb_partials", C.c_void_p)]
 
 
 class CWgradDesc(C.Structure):
@@ -80,6 +82,7 @@ SIGNATURES = {
     "vinet_bn_bwd_reduce": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp],
     "vinet_conv3d_wgrad_fuses_bn_bwd": [_PW],
     "vinet_conv3d_fuses_dgrad_phases": [_PC],
+    "vinet_conv3d_bn_bwd_stats_rows": [_PC],
     "vinet_bn_partials_fold": [_vp, _i32, _i32, _vp, _i32, _vp],
     "vinet_bn_bwd_finalize": [_vp, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "vinet_bn_bwd_apply": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp, _PT, _vp],

@@ -496,6 +496,11 @@ extern "C" int vinet_conv3d_applies_pre_once(const VinetConvDesc* d) {
   return d && d->pre.scale && !vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_ht(d) ? 1 : 0;
 }
 
+int vinet_conv_tsd_bnb_rows(const VinetConvDesc* d);
+extern "C" int vinet_conv3d_bn_bwd_stats_rows(const VinetConvDesc* d) {
+  return (d && d->tline == 3) ? vinet_conv_tsd_bnb_rows(d) : 0;      // (only the fused temporal data gradient folds the reduce pass in)
+}
+
 extern "C" int vinet_conv3d_fuses_dgrad_phases(const VinetConvDesc* d) {
   return d && d->tline == 3 && vinet_conv_use_tsd(d) ? 1 : 0;
 }

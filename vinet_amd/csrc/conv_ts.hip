@@ -61,7 +61,9 @@ VN_DEV float ts_row16_sum(float v) {      // sum over the 16 lanes of a row (DPP
   return v;
 }
 
-template <bool PRE>
+// AFF: an output affine (folded eval-mode BatchNorm, bias) is applied; the training form (raw output + statistics) does without
+// its 16 constant registers
+template <bool PRE, bool AFF>
 __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
   constexpr int KMAX = 7, TILE = 64 * 64 * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,8 +130,8 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = wn * 32 + nt * 16 + eq * 4 + r;
-      osc[nt][r] = a.out_scale ? a.out_scale[n] : 1.f;
-      osh[nt][r] = a.out_shift ? a.out_shift[n] : 0.f;
+      osc[nt][r] = (AFF && a.out_scale) ? a.out_scale[n] : 1.f;
+      osh[nt][r] = (AFF && a.out_shift) ? a.out_shift[n] : 0.f;
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
           float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = fmaf(acc[mt][nt][r], osc[nt][r], osh[nt][r]);
+            const float v = AFF ? fmaf(acc[mt][nt][r], osc[nt][r], osh[nt][r]) : (float)acc[mt][nt][r];
             ssum[nt][r] += v; ssq[nt][r] = fmaf(v, v, ssq[nt][r]);
             o[r] = fmaxf(v, relu_floor);
             if (sigm) o[r] = 1.f / (1.f + __expf(-o[r]));
@@ -305,21 +307,21 @@ int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s) {
   a.items = d->x.B * a.patches;
   a.dPatches = make_fastdiv((uint32_t)a.patches);
   const int smem = 8 * 64 * 64 * 2 + 2 * 64 * 2 * 4;
-  auto kp = conv_ts_kernel<true>;
-  auto kn = conv_ts_kernel<false>;
+  void (*const kern[2][2])(const ConvTsArgs) = {{conv_ts_kernel<false, false>, conv_ts_kernel<false, true>},
+                                                {conv_ts_kernel<true, false>, conv_ts_kernel<true, true>}};     // [PRE][AFF]
   static bool attr_done[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_done[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_ts): %s", hipGetErrorString(e)); return (int)e; }
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern[i >> 1][i & 1], hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_ts): %s", hipGetErrorString(e)); return (int)e; }
+    }
     attr_done[dev & 63] = true;
   }
   int grid = 512;
   if (grid > a.items) grid = a.items;
-  if (d->pre.scale) hipLaunchKernelGGL(kp, dim3(grid), dim3(256), smem, s, a);
-  else hipLaunchKernelGGL(kn, dim3(grid), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern[d->pre.scale ? 1 : 0][(d->out_scale || d->out_shift) ? 1 : 0], dim3(grid), dim3(256), smem, s, a);
   return vn_launch_status("conv_ts");
 }
 
@@ -340,13 +342,30 @@ struct ConvTsdArgs {
   int k, s, pad, accumulate;
   int items, patches;
   FastDiv dPatches;
+  // BNB (VinetConvDesc::bnb_*): dx is the gradient behind a BatchNorm + ReLU whose raw input is z (same dims as dx): the
+  // partial sums of vinet_bn_bwd_reduce(dx, z) leave with it, one row per item
+  const char* z;
+  long sBz;
+  int ldz, z_relu;
+  const float* z_scale;
+  const float* z_shift;
+  const float* z_mean;
+  const float* z_invstd;
+  float* partials;
 };
 
+// BNB: the BatchNorm-backward reduce pass over (dx, z) folded into the epilogue.  With the operands swapped a lane holds 4
+// consecutive channels of a position: one 8-byte load of z per tile (prefetched with the frame's dy), gate + two fused
+// multiply-adds per element into sums that stay in registers over ALL frames of the item, one cross-lane reduction per item.
+// The stem's first BatchNorm (64 channels x 32 x 112 x 192 per clip: the largest BN'd tensor of the net) otherwise costs a
+// separate pass over dx and z at the very end of the backward pass, where nothing is left to overlap it with.
+template <bool BNB>
 __global__ __launch_bounds__(256, 2) void conv_tsd_kernel(const ConvTsdArgs a) {
   constexpr int KMAX = 7, TILE = 64 * 64 * 2, NSLOT = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;                                   // NSLOT dy frames, slot = frame & 7
   char* stage = smem + NSLOT * TILE;
+  float* red = (float*)(smem + (NSLOT + 1) * TILE);    // BNB: [2 position halves][64 channels][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int k = a.k, s = a.s;
@@ -377,6 +396,22 @@ __global__ __launch_bounds__(256, 2) void conv_tsd_kernel(const ConvTsdArgs a) {
       const int row = wm * 32 + mt * 16 + (lane & 15), col = wn * 32 + nt * 16 + (lane >> 4) * 4;
       st_off[mt][nt] = row * 128 + (((col >> 3) ^ (row & 7)) * 16) + (col & 7) * 2;
     }
+  // BNB: gate constants (relu(scale * z + shift) > 0) of the 64 channels in LDS -- read back a float4 at a time in the epilogue:
+  // 16 registers fewer over the K loop --, element offsets of my 8 bytes of z per tile
+  float* zconst = red + 256;                           // [64 scale][64 shift]
+  int z_off[2][2];
+  if constexpr (BNB) {
+    if (tid < 64) {
+      zconst[tid] = a.z_scale ? a.z_scale[tid] : 1.f;
+      zconst[64 + tid] = a.z_shift ? a.z_shift[tid] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        z_off[mt][nt] = (wm * 32 + mt * 16 + (lane & 15)) * a.ldz + wn * 32 + nt * 16 + (lane >> 4) * 4;
+  }
 
   for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
     const int b = (int)fdiv((uint32_t)item, a.dPatches);
@@ -385,6 +420,17 @@ __global__ __launch_bounds__(256, 2) void conv_tsd_kernel(const ConvTsdArgs a) {
     char* yb = a.y + ((long)b * a.sBy + (long)(pos0 + l_row) * a.ldy + l_chunk * 8) * 2;
     const long x_plane = (long)a.HW * a.ldx * 2, y_plane = (long)a.HW * a.ldy * 2;
     const long x_r32 = 32L * a.ldx * 2, y_r32 = 32L * a.ldy * 2;
+    const char* zb = nullptr;
+    long z_plane = 0;
+    float s1[2][4], s2[2][4];                            // sum g, sum g * z of my channels over the item (g gated by the ReLU)
+    if constexpr (BNB) {
+      zb = a.z + ((long)b * a.sBz + (long)pos0 * a.ldz) * 2;
+      z_plane = (long)a.HW * a.ldz * 2;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.f; s2[nt][r] = 0.f; }
+    }
 
     // ---- prologue: dy frames 0 .. pad / s (everything step 0 can read) -------------------------------------
     const int q_first = a.pad / s;
@@ -406,6 +452,13 @@ __global__ __launch_bounds__(256, 2) void conv_tsd_kernel(const ConvTsdArgs a) {
       char* yf = yb + (long)ti * y_plane;
       uint4 old0 = make_uint4(0, 0, 0, 0), old1 = old0;
       if (a.accumulate) { old0 = *(const uint4*)yf; old1 = *(const uint4*)(yf + y_r32); }
+      uint2 zq[2][2];
+      if constexpr (BNB) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) zq[mt][nt] = *(const uint2*)(zb + (long)ti * z_plane + (long)z_off[mt][nt] * 2);
+      }
 
       f32x4_v acc[2][2];
 #pragma unroll
@@ -440,8 +493,24 @@ __global__ __launch_bounds__(256, 2) void conv_tsd_kernel(const ConvTsdArgs a) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          *(uint2*)(stage + st_off[mt][nt]) = make_uint2(pack2bf(acc[mt][nt][0], acc[mt][nt][1]), pack2bf(acc[mt][nt][2], acc[mt][nt][3]));
+        for (int nt = 0; nt < 2; ++nt) {
+          const uint2 g2 = make_uint2(pack2bf(acc[mt][nt][0], acc[mt][nt][1]), pack2bf(acc[mt][nt][2], acc[mt][nt][3]));
+          *(uint2*)(stage + st_off[mt][nt]) = g2;
+          if constexpr (BNB) {      // on the ROUNDED gradient: what the apply pass (and a separate reduce pass) reads back
+            const uint32_t gw[2] = {g2.x, g2.y}, zw[2] = {zq[mt][nt].x, zq[mt][nt].y};
+            const int c4 = wn * 32 + nt * 16 + (lane >> 4) * 4;
+            const float4 sc4 = *(const float4*)(zconst + c4), sh4 = *(const float4*)(zconst + 64 + c4);
+            const float zsc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, zsh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float xv = __uint_as_float((r & 1) ? (zw[r >> 1] & 0xffff0000u) : (zw[r >> 1] << 16));
+              float gg = __uint_as_float((r & 1) ? (gw[r >> 1] & 0xffff0000u) : (gw[r >> 1] << 16));
+              if (a.z_relu && !(fmaf(xv, zsc[r], zsh[r]) > 0.f)) gg = 0.f;
+              s1[nt][r] += gg;
+              s2[nt][r] = fmaf(gg, xv, s2[nt][r]);
+            }
+          }
+        }
       __syncthreads();
       {
         uint4 o0 = *(const uint4*)(stage + l_off[0]), o1 = *(const uint4*)(stage + l_off[1]);
@@ -460,6 +529,26 @@ __global__ __launch_bounds__(256, 2) void conv_tsd_kernel(const ConvTsdArgs a) {
         char* slot = ring + (qn & (NSLOT - 1)) * TILE;
         *(uint4*)(slot + l_off[0]) = nx0;
         *(uint4*)(slot + l_off[1]) = nx1;
+      }
+      __syncthreads();
+    }
+    if constexpr (BNB) {     // once per item: 16 positions of a row by DPP, the two position halves (wm) in LDS
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ss = ts_row16_sum(s1[nt][r]), qq = ts_row16_sum(s2[nt][r]);
+          if ((lane & 15) == 0) {
+            const int col = wn * 32 + nt * 16 + (lane >> 4) * 4 + r;
+            red[(wm * 64 + col) * 2 + 0] = ss;
+            red[(wm * 64 + col) * 2 + 1] = qq;
+          }
+        }
+      __syncthreads();
+      if (tid < 64) {      // sum g, and sum g * (z - mean) * invstd = (sum g z - mean sum g) * invstd
+        const float ss = red[tid * 2] + red[(64 + tid) * 2], qq = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+        a.partials[((long)item * 2 + 0) * 64 + tid] = ss;
+        a.partials[((long)item * 2 + 1) * 64 + tid] = (qq - a.z_mean[tid] * ss) * a.z_invstd[tid];
       }
       __syncthreads();
     }
@@ -482,6 +571,14 @@ bool vinet_conv_use_tsd(const VinetConvDesc* d) {
   return (long)d->x.B * (HW / 64) >= 2048 && d->oT >= 4;
 }
 
+// rows of BatchNorm-backward partial sums a tline == 3 launch with bnb_* set writes (one per item), 0 = cannot
+int vinet_conv_tsd_bnb_rows(const VinetConvDesc* d) {
+  if (!d || !vinet_conv_use_tsd(d) || d->accumulate) return 0;
+  if (!d->bnb_z || !d->bnb_mean || !d->bnb_invstd || d->bnb_ld % 4 != 0 || d->bnb_sB % 4 != 0 || ((uintptr_t)d->bnb_z % 8) != 0) return 0;
+  if (d->bnb_fwd.relu && !(d->bnb_fwd.scale && d->bnb_fwd.shift)) return 0;
+  return (int)((long)d->x.B * (((long)d->oH * d->oW) / 64));
+}
+
 int vinet_launch_conv_tsd(const VinetConvDesc* d, hipStream_t s) {
   ConvTsdArgs a;
   a.x = (const char*)d->x.ptr; a.y = (char*)d->y.ptr; a.w = (const char*)d->w;
@@ -490,17 +587,27 @@ int vinet_launch_conv_tsd(const VinetConvDesc* d, hipStream_t s) {
   a.patches = a.HW / 64;
   a.items = d->x.B * a.patches;
   a.dPatches = make_fastdiv((uint32_t)a.patches);
-  const int smem = 9 * 64 * 64 * 2;
+  const int smem = 9 * 64 * 64 * 2 + 1024 + 512;
   static bool attr_done[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_done[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_tsd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_tsd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_tsd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_tsd): %s", hipGetErrorString(e)); return (int)e; }
     attr_done[dev & 63] = true;
   }
   int grid = 512;
   if (grid > a.items) grid = a.items;
-  hipLaunchKernelGGL(conv_tsd_kernel, dim3(grid), dim3(256), smem, s, a);
+  a.z = nullptr; a.partials = nullptr;
+  if (d->bnb_partials) {
+    VN_CHECK_ARG(vinet_conv_tsd_bnb_rows(d) > 0, "conv tsd: the BatchNorm-backward statistics (bnb_*) are not available for this problem; ask vinet_conv3d_bn_bwd_stats_rows first");
+    a.z = (const char*)d->bnb_z; a.sBz = d->bnb_sB; a.ldz = d->bnb_ld; a.z_relu = d->bnb_fwd.relu;
+    a.z_scale = d->bnb_fwd.scale; a.z_shift = d->bnb_fwd.shift; a.z_mean = d->bnb_mean; a.z_invstd = d->bnb_invstd;
+    a.partials = d->bnb_partials;
+    hipLaunchKernelGGL(conv_tsd_kernel<true>, dim3(grid), dim3(256), smem, s, a);
+    return vn_launch_status("conv_tsd<bnb>");
+  }
+  hipLaunchKernelGGL(conv_tsd_kernel<false>, dim3(grid), dim3(256), smem, s, a);
   return vn_launch_status("conv_tsd");
 }

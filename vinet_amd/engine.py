@@ -204,7 +204,7 @@ class View:
 class Act:
     """activation = view + pending affine/relu + gradient bookkeeping."""
     __slots__ = ("v", "scale", "shift", "relu", "_grad", "grad_ready", "needs_grad", "parent", "pc0", "pt0", "fold",
-                 "indep", "ready_of")
+                 "indep", "ready_of", "grad_marks", "bn_keep", "bnb_part")
 
     def __init__(self, v, scale=None, shift=None, relu=False, needs_grad=False):
         self.v, self.scale, self.shift, self.relu = v, scale, shift, relu
@@ -213,6 +213,9 @@ class Act:
         self.fold = None
         self.indep = False       # channel region with its own "gradient written" flag (see region())
         self.ready_of = None     # span over several regions: ready when all of them are
+        self.grad_marks = 0      # writers of this gradient so far (mark_grad_ready calls on the root)
+        self.bn_keep = None      # training-mode BatchNorm of the producing conv: dict(mean, invstd) (conv_forward)
+        self.bnb_part = None     # (partials, rows, grad_marks): BN-backward partial sums a data gradient left with the gradient
 
     @property
     def plain(self):
@@ -274,7 +277,9 @@ class Act:
         return self.root().grad_ready
 
     def mark_grad_ready(self):
-        self.root().grad_ready = True
+        r = self.root()
+        r.grad_ready = True
+        r.grad_marks += 1
 
 
 class Ctx:
@@ -1062,6 +1067,8 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         bn.finalize(ctx, stats, rows, plan.N, M, mean, invstd, scale, shift)
         res.scale, res.shift, res.relu = scale, shift, (act == L.ACT_RELU)
         keep.update(mean=mean, invstd=invstd)
+        if not isinstance(bn, JointBN):
+            res.bn_keep = keep      # (a consumer's data gradient may fold this BatchNorm's backward reduce pass in: _conv_backward)
 
     if ctx.recording:
         ctx.record(lambda: _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M))
@@ -1080,6 +1087,9 @@ class _NullCtx:
 # register-staged split kernel, conv_wgrad.hip)
 SPLIT_WGRAD_BF16 = int(os.environ.get("VINET_SPLIT_WGRAD_BF16", "1"))
 SPLIT_ON_MAIN = int(os.environ.get("VINET_SPLIT_ON_MAIN", "0"))
+# a data gradient that is the only writer of the gradient behind a BatchNorm + ReLU also writes that BatchNorm's backward
+# partial sums where the library can (vinet_conv3d_bn_bwd_stats_rows: the fused temporal data gradient of the stem); 0 = off
+DGRAD_BN_STATS = int(os.environ.get("VINET_DGRAD_BN_STATS", "1"))
 # fp32s: deferral of the decoder's weight gradients (DEFER_DECODER_WGRAD) -- in this form the weight-gradient stream (three launches
 # per conv + the split passes) is the longer one, so it should start with the backward pass, not 35 ms into it
 DEFER_DECODER_WGRAD_F32S = int(os.environ.get("VINET_DEFER_DECODER_WGRAD_F32S", "0"))      # measured at 64 clips: 207.3 -> 212.5 clips/s
@@ -1150,14 +1160,20 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
     fused_bnb = None
     # ---- through BN / activation: dz -> dy (w.r.t. the raw conv output) --------
     if bn is not None:
-        rows = ctx.lib.vinet_stats_rows(C.byref(dz.ct()))
-        ws = ctx.f32(rows * 2 * Ny)
         fwd = res.affine()
         nb = float(dz.nvox * dz.C * ESIZE[dz.dt])
-        ctx.call("vinet_bn_bwd_reduce", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
-                 keep["invstd"].data_ptr(), ws.data_ptr(), ctx.stream,
-                 tag=("vinet_bn_bwd_reduce | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
-                 work=dict(flops=0.0, bytes=2 * nb))
+        part = res.bnb_part
+        if part is not None and part[2] == res.root().grad_marks:
+            # the data gradient that wrote dz (its only writer: the count of writers has not moved since) left the partial
+            # sums of this reduce pass with it (VinetConvDesc::bnb_*)
+            ws, rows = part[0], part[1]
+        else:
+            rows = ctx.lib.vinet_stats_rows(C.byref(dz.ct()))
+            ws = ctx.f32(rows * 2 * Ny)
+            ctx.call("vinet_bn_bwd_reduce", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
+                     keep["invstd"].data_ptr(), ws.data_ptr(), ctx.stream,
+                     tag=("vinet_bn_bwd_reduce | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
+                     work=dict(flops=0.0, bytes=2 * nb))
         c1, c2 = ctx.f32(Ny), ctx.f32(Ny)
         bn.bwd_finalize(ctx, ws, rows, Ny, M, res.scale, train_bn, keep["invstd"], c1, c2)
         # A conv whose input needs no gradient (the RGB stem) has one consumer of dz, its weight gradient: kernels
@@ -1321,11 +1337,26 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             d.tline, d.tpad = 3, plan.p[0]
             if ctx.lib.vinet_conv3d_fuses_dgrad_phases(C.byref(d)):
                 es = ESIZE[ctx.dt]
+                bnb_ws = None
+                if (DGRAD_BN_STATS and not acc and x.bn_keep is not None and x.scale is not None and x.parent is None and
+                        x.fold is None and xv.dt == dx.dt and xv.C == plan.Cin and dx.same_dims(xv)):
+                    # x = relu(bn(z)), this launch is the first (for the stem: the only) writer of its gradient: the partial
+                    # sums of that BatchNorm's backward reduce pass leave with the gradient
+                    d.bnb_z, d.bnb_ld, d.bnb_sB, d.bnb_fwd = xv.ptr(), xv.ld, xv.sB, x.affine()
+                    d.bnb_mean, d.bnb_invstd = x.bn_keep["mean"].data_ptr(), x.bn_keep["invstd"].data_ptr()
+                    brows = ctx.lib.vinet_conv3d_bn_bwd_stats_rows(C.byref(d))
+                    if brows > 0:
+                        bnb_ws = ctx.f32(brows * 2 * xv.C)
+                        d.bnb_partials = bnb_ws.data_ptr()
                 ctx.call("vinet_conv3d", C.byref(d), ctx.stream,
                          tag=("conv_tsd_kernel | dgrad " + plan.site(xv)) if PROFILER is not None else None,
                          work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps,
                                    bytes=float(xv.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * es)))
                 phases = []
+                if bnb_ws is not None:
+                    x.mark_grad_ready()
+                    x.bnb_part = (bnb_ws, brows, x.root().grad_marks)
+                    return
         for ph in phases:
             d = L.CConvDesc()
             d.dtype, d.out_dtype, d.mode = ctx.cdt, dx.dt, L.CONV_GENERIC
