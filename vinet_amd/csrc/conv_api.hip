@@ -165,6 +165,8 @@ extern int g_vinet_opt_wgrad_skinny;
 extern int g_vinet_opt_bn_lean;
 extern int g_vinet_opt_bn_rows;
 extern int g_vinet_opt_pack_tiled;
+extern int g_vinet_opt_wgrad_pp_cap;
+extern int g_vinet_opt_wgrad_ts_cap;
 
 extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   if (!d) return -1;
@@ -249,6 +251,8 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "ht32")) { g_vinet_opt_ht32 = value; return 0; }
   if (name && !strcmp(name, "ht3")) { g_vinet_opt_ht3 = value; return 0; }
   if (name && !strcmp(name, "bn_lean")) { g_vinet_opt_bn_lean = value; return 0; }
+  if (name && !strcmp(name, "wgrad_ts_cap")) { g_vinet_opt_wgrad_ts_cap = value; return 0; }
+  if (name && !strcmp(name, "wgrad_pp_cap")) { g_vinet_opt_wgrad_pp_cap = value; return 0; }
   if (name && !strcmp(name, "pack_tiled")) { g_vinet_opt_pack_tiled = value; return 0; }
   if (name && !strcmp(name, "bn_rows")) { g_vinet_opt_bn_rows = value < 1 ? 1 : value; return 0; }
   if (name && !strcmp(name, "ht_minhw")) { g_vinet_opt_ht_minhw = value; return 0; }

@@ -387,6 +387,7 @@ static int launch_wpp(const WgradPPArgs& a, hipStream_t s) {
 
 extern int g_vinet_opt_wgrad_pp;
 extern int g_vinet_opt_tperm;
+int g_vinet_opt_wgrad_pp_cap = 1;   // the 256 x 256 ping-pong weight gradient honours VinetWgradDesc::max_cus (one round of workgroups under a cap)
 #ifdef VINET_CONV_TIMING
 static float* g_wpp_dbg = nullptr;
 extern "C" void vinet_debug_wgrad_ptr(float* p) { g_wpp_dbg = p; }
@@ -454,17 +455,23 @@ int vinet_launch_wgrad_pp(const VinetWgradDesc* d, hipStream_t s) {
   // split-K: one workgroup per CU, so the grid should be a whole number of 256-workgroup rounds.
   // Pick the split count that wastes the least of its last round (>= 32 K tiles per split; among
   // near-equal fills the fewest splits: every split adds a 256x256 fp32 atomics pass per tile).
+  // Under a CU cap (VinetWgradDesc::max_cus < 256: the caller's other stream wants the rest of the chip) the launch must not hold
+  // more workgroups than the cap at ANY time: a grid of several rounds refills every CU the moment a workgroup retires, and a
+  // workgroup lives for a millisecond -- a 7-microsecond BatchNorm finalize launch of the main stream took 1.39 ms beside the
+  // 832 -> 480 decoder weight gradient (176 tiles x 7 splits = 4.8 rounds of 256; profiles/r4_experiments.txt).  So: one round.
   const long base_blocks = (long)a.tilesN * a.tilesS;
+  const int cus = g_vinet_opt_wgrad_pp_cap ? vn_wgrad_cus(d) : 256;
   long sk = 1;
   {
     long max_sk = a.nkt / 32;
     if (max_sk < 1) max_sk = 1;
     if (max_sk > 1024) max_sk = 1024;
+    if (cus < 256 && base_blocks <= cus && max_sk > cus / base_blocks) max_sk = cus / base_blocks;
     double best = -1.0;
     for (long k = 1; k <= max_sk; ++k) {
       const long blocks = base_blocks * k;
-      const long rounds = (blocks + 255) / 256;
-      const double fill = (double)blocks / (double)(rounds * 256);
+      const long rounds = (blocks + cus - 1) / cus;
+      const double fill = (double)blocks / (double)(rounds * cus);
       if (fill > best + 0.04) { best = fill; sk = k; }
     }
   }

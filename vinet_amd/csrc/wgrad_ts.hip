@@ -199,6 +199,7 @@ bool vinet_wgrad_use_ts(const VinetWgradDesc* d) {
   return (long)d->dy.B * (HW / 64) >= 2048 && d->dy.T >= 4;      // enough items for a persistent grid, a walk worth its prologue
 }
 
+int g_vinet_opt_wgrad_ts_cap = 0;   // 1 = the persistent grid honours VinetWgradDesc::max_cus (measured: 677.5 -> 675.6 clips/s -- this launch is on the tail of the step, where the weight-gradient stream is the longer one)
 int vinet_launch_wgrad_ts(const VinetWgradDesc* d, hipStream_t s) {
   WgradTsArgs a;
   a.x = (const char*)d->x.ptr; a.dy = (const char*)d->dy.ptr; a.dw = d->dw;
@@ -221,7 +222,7 @@ int vinet_launch_wgrad_ts(const VinetWgradDesc* d, hipStream_t s) {
     if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(wgrad_ts): %s", hipGetErrorString(e)); return (int)e; }
     attr_done[dev & 63] = true;
   }
-  int grid = 512;
+  int grid = g_vinet_opt_wgrad_ts_cap ? 2 * vn_wgrad_cus(d) : 512;      // two workgroups per CU, on no more CUs than the caller's cap
   if (grid > a.items) grid = a.items;
   if (d->pre.scale) hipLaunchKernelGGL(kp, dim3(grid), dim3(256), smem, s, a);
   else hipLaunchKernelGGL(kn, dim3(grid), dim3(256), smem, s, a);
