@@ -324,6 +324,11 @@ int vinet_bn_bwd_finalize(const float* partials, int32_t rows, int32_t C, int32_
 int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_raw, int32_t dtype, VinetAffine fwd,
                        const float* mean, const float* invstd, const float* c1, const float* c2,
                        const VinetTensor* dx, void* stream);
+/* vinet_bn_bwd_apply on fp32 tensors + vinet_split_bf16 of its result in the same pass: dx as usual and its hi / lo bf16 planes
+ * (hi = bf16(v), lo = bf16(v - hi)) -- the operand planes of the VINET_F32S weight gradient (three bf16 launches).  C % 8 == 0. */
+int vinet_bn_bwd_apply_split(const VinetTensor* dz, const VinetTensor* x_raw, VinetAffine fwd, const float* mean,
+                             const float* invstd, const float* c1, const float* c2, const VinetTensor* dx,
+                             const VinetTensor* hi, const VinetTensor* lo, void* stream);
 /* dy = dz * act'(z) for z = relu(.) or sigmoid(.) outputs (threshold_backward /
  * sigmoid_backward of the decoder, model.py:257-283).  z may be fp32. */
 int vinet_act_bwd(const VinetTensor* dz, int32_t dz_dtype, const VinetTensor* z, int32_t z_dtype, int32_t act,
@@ -354,6 +359,9 @@ int vinet_maxpool3d_bwd(const VinetPoolDesc* d, const VinetTensor* dy, const uin
  * (model.py:254,258,263,268,273,278) and its backward. */
 int vinet_upsample2x(const VinetTensor* x, const VinetTensor* y, int32_t dtype, void* stream);
 int vinet_upsample2x_bwd(const VinetTensor* dy, const VinetTensor* dx, int32_t dtype, int32_t accumulate, void* stream);
+/* The same with the backward of the ReLU in FRONT of the upsample folded in (the decoder's conv -> ReLU -> upsample,
+ * model.py:256-258): dx = [xf > 0] * upsample2x^T(dy), xf = the ReLU's output (the upsample's input, dx's extent).  Stores. */
+int vinet_upsample2x_bwd_relu(const VinetTensor* dy, const VinetTensor* dx, const VinetTensor* xf, int32_t dtype, void* stream);
 
 /* SoundNet's first conv (model.py:751: Conv2d(1, 16, (64,1), stride (2,1), padding (32,0))) as a pointwise conv over the
  * unfolded waveform: y[b, m, 0, 0, c] = x[b, stride*m - pad + c, 0, 0, channel 0], zero outside; x = [B][L][1][1][C>=1],

@@ -618,6 +618,16 @@ class AbiEmulator:
         wr(dx, dtype, gx.permute(0, 2, 3, 4, 1).contiguous().numpy(), bool(accumulate))
         return 0
 
+    def vinet_bn_bwd_apply_split(self, dz, x_raw, fwd, mean, invstd, c1, c2, dx, hi, lo, stream):
+        rc = self.vinet_bn_bwd_apply(dz, x_raw, F32, fwd, mean, invstd, c1, c2, dx, stream)
+        return rc or self.vinet_split_bf16(dx, L.CAffine(None, None, 0), hi, lo, stream)
+
+    def vinet_upsample2x_bwd_relu(self, dy, dx, xf, dtype, stream):
+        rc = self.vinet_upsample2x_bwd(dy, dx, dtype, 0, stream)
+        dx, xf = _deref(dx), _deref(xf)
+        wr(dx, dtype, rd(dx, dtype) * (rd(xf, dtype) > 0))
+        return rc
+
     # -- losses / optimizer -----------------------------------------------------------
     @staticmethod
     def _loss_value(which, s, g):

@@ -1288,6 +1288,18 @@ def test_bn_kernels(dt, Cc):
     dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "bndx", 8)
     run_both("vinet_bn_bwd_apply", lambda s: [C.byref(gmk(s).ct()), C.byref(xmk(s).ct()), dt, aff(s), mean.ptr(s), istd.ptr(s), c1.ptr(s), c2.ptr(s), C.byref(dxmk(s).ct()), _stream() if s == "gpu" else 0])
     _cmp(dxp.get("gpu"), dxp.get("cpu"), 1e-5 if dt == E.F32 else 2e-2, "bn_bwd_apply")
+    if dt == E.F32 and Cc % 8 == 0:
+        # the VINET_F32S training form: the same pass also writes the hi / lo bf16 planes of its result (vinet_split_bf16's arithmetic)
+        dsp, dsmk = view_pair(B, T, H, W, Cc, dt, "bnds", 9)
+        hp, hmk = view_pair(B, T, H, W, Cc, E.BF16, "bnhi", 10, ld=Cc + 8)
+        lp, lmk = view_pair(B, T, H, W, Cc, E.BF16, "bnlo", 11)
+        run_both("vinet_bn_bwd_apply_split", lambda s: [C.byref(gmk(s).ct()), C.byref(xmk(s).ct()), aff(s), mean.ptr(s), istd.ptr(s), c1.ptr(s), c2.ptr(s),
+                                                        C.byref(dsmk(s).ct()), C.byref(hmk(s).ct()), C.byref(lmk(s).ct()), _stream() if s == "gpu" else 0])
+        assert torch.equal(dsp.get("gpu"), dxp.get("gpu")), "bn_bwd_apply_split: dx differs from vinet_bn_bwd_apply's"
+        v = dsp.get("gpu").view(B, T, H, W, Cc)
+        hi = E.View(hp.get("gpu"), 0, B, T, H, W, Cc, Cc + 8, T * H * W * (Cc + 8), E.BF16).torch5()
+        lo = lp.get("gpu").view(B, T, H, W, Cc)
+        assert torch.equal(hi, v.bfloat16()) and torch.equal(lo, (v - v.bfloat16().float()).bfloat16()), "hi / lo planes are not the split of dx"
     # channel_sum with folding
     out = Pair(torch.ones(Cc // 4))
     ws = Pair(torch.zeros(rows * 2 * Cc))
@@ -1453,6 +1465,12 @@ def test_upsample(dt):
     dxp, dxmk = view_pair(B, T, H, W, Cc, dt, "udx", 3)
     run_both("vinet_upsample2x_bwd", lambda s: [C.byref(ymk(s).ct()), C.byref(dxmk(s).ct()), dt, 1, _stream() if s == "gpu" else 0])
     _cmp(dxp.get("gpu"), dxp.get("cpu"), 1e-5 if dt == E.F32 else 2e-2, "upsample bwd")
+    # the backward of a ReLU in front of the upsample folded in: dx = [xf > 0] * upsample^T(dy), stored
+    dmp, dmmk = view_pair(B, T, H, W, Cc, dt, "udm", 4, ld=48, c_off=8)
+    run_both("vinet_upsample2x_bwd_relu", lambda s: [C.byref(ymk(s).ct()), C.byref(dmmk(s).ct()), C.byref(xmk(s).ct()), dt, _stream() if s == "gpu" else 0])
+    _cmp(dmp.get("gpu"), dmp.get("cpu"), 1e-5 if dt == E.F32 else 2e-2, "upsample bwd + ReLU gate")
+    gated = E.View(dmp.get("gpu"), 8, B, T, H, W, Cc, 48, T * H * W * 48, dt).torch5()
+    assert bool((gated[xmk("cpu").torch5() <= 0] == 0).all()) and bool((gated != 0).any())
 
 
 @pytest.mark.parametrize("which", [0, 1, 2])

@@ -86,6 +86,7 @@ SIGNATURES = {
     "vinet_bn_partials_fold": [_vp, _i32, _i32, _vp, _i32, _vp],
     "vinet_bn_bwd_finalize": [_vp, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "vinet_bn_bwd_apply": [_PT, _PT, _i32, CAffine, _vp, _vp, _vp, _vp, _PT, _vp],
+    "vinet_bn_bwd_apply_split": [_PT, _PT, CAffine, _vp, _vp, _vp, _vp, _PT, _PT, _PT, _vp],
     "vinet_act_bwd": [_PT, _i32, _PT, _i32, _i32, _PT, _i32, _vp],
     "vinet_channel_sum": [_PT, _i32, _vp, _i32, _vp, _i32, _vp],
     "vinet_maxpool3d": [_PP, _PT, CAffine, _PT, _vp, _vp],
@@ -93,6 +94,7 @@ SIGNATURES = {
     "vinet_upsample2x": [_PT, _PT, _i32, _vp],
     "vinet_unfold1d": [_PT, _PT, _i32, _i32, _i32, _vp],
     "vinet_upsample2x_bwd": [_PT, _PT, _i32, _i32, _vp],
+    "vinet_upsample2x_bwd_relu": [_PT, _PT, _PT, _i32, _vp],
     "vinet_loss_fwd": [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "vinet_loss_bwd": [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp],
     "vinet_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],

@@ -456,9 +456,11 @@ __global__ void bn_bwd_apply_kernel(TView dz, TView x, Affine fwd, const float* 
 // 8-channel, voxel-looping form: the six per-channel parameter vectors are folded into four
 // coefficients held in registers (dx = A*g + B*x + D with the ReLU gate from sc*x + sh), so a
 // lane issues two 16-byte loads and one 16-byte store per voxel and nothing else.
-template <typename T>
+// SPLIT (T = float, the VINET_F32S training form): the result also leaves as hi / lo bf16 planes (hi = bf16(v), lo = bf16(v - hi):
+// vinet_split_bf16's arithmetic) -- the operand planes of the three bf16 weight-gradient launches, without a second pass over dx
+template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(TView dz, TView x, Affine fwd, const float* mean, const float* invstd,
-                                                            const float* c1, const float* c2, TView dx, long nvox, long vb) {
+                                                            const float* c1, const float* c2, TView dx, TView hi, TView lo, long nvox, long vb) {
   const int G = x.C / 8;
   const int Gb = G < 256 ? G : 256;
   const int R = 256 / Gb;
@@ -500,6 +502,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(TView dz, TView x, A
           o[e] = fmaf(A[e], gg, fmaf(Bc[e], xv[u][e], D[e]));
         }
         st8<T>((T*)dx.p + vox_lin(dx, vq + (long)u * R) + g * 8, o);
+        if constexpr (SPLIT) {
+          uint32_t h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            h[e] = pack2bf(o[2 * e], o[2 * e + 1]);
+            l[e] = pack2bf(o[2 * e] - __uint_as_float(h[e] << 16), o[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u));
+          }
+          *(uint4*)((bf16_t*)hi.p + vox_lin(hi, vq + (long)u * R) + g * 8) = make_uint4(h[0], h[1], h[2], h[3]);
+          *(uint4*)((bf16_t*)lo.p + vox_lin(lo, vq + (long)u * R) + g * 8) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
       }
     }
   }
@@ -582,9 +594,9 @@ extern "C" int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_ra
                            make_view(*dz), make_view(*x_raw), make_affine(fwd), mean, invstd, c1, c2, make_view(*dx), nvox, vb);
       return vn_launch_status("bn_bwd_apply8_bf16");
     }
-    DISPATCH_T(dtype, T, hipLaunchKernelGGL(bn_bwd_apply8_kernel<T>, dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0,
+    DISPATCH_T(dtype, T, hipLaunchKernelGGL((bn_bwd_apply8_kernel<T, false>), dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0,
                                             (hipStream_t)stream, make_view(*dz), make_view(*x_raw), make_affine(fwd), mean,
-                                            invstd, c1, c2, make_view(*dx), nvox, vb);)
+                                            invstd, c1, c2, make_view(*dx), make_view(*dx), make_view(*dx), nvox, vb);)
     return vn_launch_status("bn_bwd_apply8");
   }
   const long total = view_voxels(*dz) * (dz->C / 4);
@@ -592,6 +604,24 @@ extern "C" int vinet_bn_bwd_apply(const VinetTensor* dz, const VinetTensor* x_ra
                                           (hipStream_t)stream, make_view(*dz), make_view(*x_raw), make_affine(fwd), mean,
                                           invstd, c1, c2, make_view(*dx), total);)
   return vn_launch_status("bn_bwd_apply");
+}
+
+/* fp32 tensors (the VINET_F32S training form): vinet_bn_bwd_apply + vinet_split_bf16 of its result in one pass -- dx as usual, and
+ * its hi / lo bf16 planes (views of dx's extent) for the split-bf16 weight gradient.  Channel counts in whole groups of 8. */
+extern "C" int vinet_bn_bwd_apply_split(const VinetTensor* dz, const VinetTensor* x_raw, VinetAffine fwd, const float* mean,
+                                        const float* invstd, const float* c1, const float* c2, const VinetTensor* dx,
+                                        const VinetTensor* hi, const VinetTensor* lo, void* stream) {
+  VN_CHECK_ARG(dz && x_raw && dx && hi && lo && fwd.scale && fwd.shift && mean && invstd && c1 && c2, "bn_bwd_apply_split: null argument");
+  VN_CHECK_ARG(oct_ok(*dz) && oct_ok(*x_raw) && oct_ok(*dx) && oct_ok(*hi) && oct_ok(*lo) && same_dims(*dz, *x_raw) && same_dims(*dz, *dx) &&
+                   same_dims(*dz, *hi) && same_dims(*dz, *lo) && quad_ok(*dz, 4) && quad_ok(*x_raw, 4) && quad_ok(*dx, 4) && quad_ok(*hi, 2) &&
+                   quad_ok(*lo, 2), "bn_bwd_apply_split: bad views (fp32 tensors, bf16 planes, C a multiple of 8)");
+  const long nvox = view_voxels(*dz);
+  const int G = dz->C / 8, R = 256 / (G < 256 ? G : 256);
+  long vb = R * 16;
+  while ((nvox + vb - 1) / vb > 16384) vb *= 2;
+  hipLaunchKernelGGL((bn_bwd_apply8_kernel<float, true>), dim3((unsigned)((nvox + vb - 1) / vb)), dim3(256), 0, (hipStream_t)stream,
+                     make_view(*dz), make_view(*x_raw), make_affine(fwd), mean, invstd, c1, c2, make_view(*dx), make_view(*hi), make_view(*lo), nvox, vb);
+  return vn_launch_status("bn_bwd_apply8<split>");
 }
 
 template <typename TG, typename TZ, typename TO>

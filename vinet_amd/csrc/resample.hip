@@ -100,8 +100,10 @@ VN_DEV void up_bwd_taps(int i, int n, int* o, float* wgt) {
   o[3] = 2 * i + 2; wgt[3] = i <= n - 2 ? 0.25f : 0.f;
 }
 
-template <typename T>
-__global__ void upsample2x_bwd_kernel(TView dy, TView dx, int accumulate, long total) {
+// MASK: dx = [xf > 0] * (transposed stencil of dy) -- the backward of the ReLU in front of the upsample (xf = its output, the
+// upsample's input) folded into the pass that writes the gradient (the decoder: conv -> ReLU -> upsample, model.py:256-258)
+template <typename T, bool MASK>
+__global__ void upsample2x_bwd_kernel(TView dy, TView dx, TView xf, int accumulate, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const uint32_t vox_u = fdiv((uint32_t)i, dx.dQ);
@@ -126,13 +128,17 @@ __global__ void upsample2x_bwd_kernel(TView dy, TView dx, int accumulate, long t
     }
   }
   T* dst = (T*)dx.p + vox_off(dx, b, t, h, w) + q * 4;
+  if constexpr (MASK) {
+    const float4 f = ldq<T>((const T*)xf.p + vox_off(xf, b, t, h, w) + q * 4);
+    g.x = f.x > 0.f ? g.x : 0.f; g.y = f.y > 0.f ? g.y : 0.f; g.z = f.z > 0.f ? g.z : 0.f; g.w = f.w > 0.f ? g.w : 0.f;
+  }
   if (accumulate) { const float4 o = ldq<T>(dst); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
   stq<T>(dst, g);
 }
 
 // 8-channel form of the backward gather (16-byte loads, index math per 16 instead of 8 bytes written)
-template <typename T>
-__global__ __launch_bounds__(256) void upsample2x_bwd8_kernel(TView dy, TView dx, int accumulate, long total) {
+template <typename T, bool MASK>
+__global__ __launch_bounds__(256) void upsample2x_bwd8_kernel(TView dy, TView dx, TView xf, int accumulate, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int G = dx.C >> 3;
@@ -159,6 +165,12 @@ __global__ __launch_bounds__(256) void upsample2x_bwd8_kernel(TView dy, TView dx
     }
   }
   T* dst = (T*)dx.p + vox_off(dx, b, t, h, w) + g * 8;
+  if constexpr (MASK) {
+    float f[8];
+    ld8<T>((const T*)xf.p + vox_off(xf, b, t, h, w) + g * 8, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gr[e] = f[e] > 0.f ? gr[e] : 0.f;
+  }
   if (accumulate) {
     float o[8];
     ld8<T>(dst, o);
@@ -168,18 +180,36 @@ __global__ __launch_bounds__(256) void upsample2x_bwd8_kernel(TView dy, TView dx
   st8<T>(dst, gr);
 }
 
-extern "C" int vinet_upsample2x_bwd(const VinetTensor* dy, const VinetTensor* dx, int32_t dtype, int32_t accumulate,
-                                    void* stream) {
+static int launch_upsample2x_bwd(const VinetTensor* dy, const VinetTensor* dx, const VinetTensor* xf, int32_t dtype, int32_t accumulate,
+                                void* stream) {
   VN_CHECK_ARG(dy && dx && quad_ok(*dy, esize(dtype)) && quad_ok(*dx, esize(dtype)) && dx->C == dy->C && dx->B == dy->B &&
                    dx->T == dy->T && dy->H == 2 * dx->H && dy->W == 2 * dx->W, "upsample2x_bwd: bad views");
+  VN_CHECK_ARG(!xf || (quad_ok(*xf, esize(dtype)) && same_dims(*xf, *dx)), "upsample2x_bwd: the forward tensor must have dx's extent");
   const long total = view_voxels(*dx) * (dx->C / 4);
-  if (g_vinet_opt_up_blk && oct_ok(*dx) && oct_ok(*dy)) {
+  const TView fv = xf ? make_view(*xf) : make_view(*dx);
+  if (g_vinet_opt_up_blk && oct_ok(*dx) && oct_ok(*dy) && (!xf || oct_ok(*xf))) {
     const long total8 = view_voxels(*dx) * (dx->C / 8);
-    DISPATCH_T(dtype, T, hipLaunchKernelGGL(upsample2x_bwd8_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
-                                            make_view(*dy), make_view(*dx), accumulate, total8);)
+    if (xf) { DISPATCH_T(dtype, T, hipLaunchKernelGGL((upsample2x_bwd8_kernel<T, true>), dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
+                                                      make_view(*dy), make_view(*dx), fv, accumulate, total8);) }
+    else { DISPATCH_T(dtype, T, hipLaunchKernelGGL((upsample2x_bwd8_kernel<T, false>), dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
+                                                   make_view(*dy), make_view(*dx), fv, accumulate, total8);) }
     return vn_launch_status("upsample2x_bwd(8)");
   }
-  DISPATCH_T(dtype, T, hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0,
-                                          (hipStream_t)stream, make_view(*dy), make_view(*dx), accumulate, total);)
+  if (xf) { DISPATCH_T(dtype, T, hipLaunchKernelGGL((upsample2x_bwd_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0,
+                                                    (hipStream_t)stream, make_view(*dy), make_view(*dx), fv, accumulate, total);) }
+  else { DISPATCH_T(dtype, T, hipLaunchKernelGGL((upsample2x_bwd_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0,
+                                                 (hipStream_t)stream, make_view(*dy), make_view(*dx), fv, accumulate, total);) }
   return vn_launch_status("upsample2x_bwd");
+}
+
+extern "C" int vinet_upsample2x_bwd(const VinetTensor* dy, const VinetTensor* dx, int32_t dtype, int32_t accumulate,
+                                    void* stream) {
+  return launch_upsample2x_bwd(dy, dx, nullptr, dtype, accumulate, stream);
+}
+
+/* dx = [xf > 0] * upsample2x^T(dy): the backward of conv -> ReLU -> upsample (model.py:256-258) behind the conv in ONE pass; xf = the
+ * ReLU's output (= the upsample's input), dx's extent.  Stores (the ReLU gates the whole gradient, so nothing may be there yet). */
+extern "C" int vinet_upsample2x_bwd_relu(const VinetTensor* dy, const VinetTensor* dx, const VinetTensor* xf, int32_t dtype, void* stream) {
+  VN_CHECK_ARG(xf != nullptr, "upsample2x_bwd_relu: forward tensor missing");
+  return launch_upsample2x_bwd(dy, dx, xf, dtype, 0, stream);
 }

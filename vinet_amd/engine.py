@@ -204,7 +204,7 @@ class View:
 class Act:
     """activation = view + pending affine/relu + gradient bookkeeping."""
     __slots__ = ("v", "scale", "shift", "relu", "_grad", "grad_ready", "needs_grad", "parent", "pc0", "pt0", "fold",
-                 "indep", "ready_of", "grad_marks", "bn_keep", "bnb_part")
+                 "indep", "ready_of", "grad_marks", "bn_keep", "bnb_part", "act_out", "grad_masked")
 
     def __init__(self, v, scale=None, shift=None, relu=False, needs_grad=False):
         self.v, self.scale, self.shift, self.relu = v, scale, shift, relu
@@ -216,6 +216,8 @@ class Act:
         self.grad_marks = 0      # writers of this gradient so far (mark_grad_ready calls on the root)
         self.bn_keep = None      # training-mode BatchNorm of the producing conv: dict(mean, invstd) (conv_forward)
         self.bnb_part = None     # (partials, rows, grad_marks): BN-backward partial sums a data gradient left with the gradient
+        self.act_out = 0         # activation the producing conv applied in its epilogue (no BatchNorm): conv_forward
+        self.grad_masked = -1    # grad_marks at which the gradient already carries that activation's backward (upsample2x backward)
 
     @property
     def plain(self):
@@ -1021,6 +1023,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
         res.scale = res.shift = None
         res.relu = False
+        res.act_out = act
     elif not train_bn:
         scale = ctx.f32(plan.N) if scale_out is None else scale_out
         shift = ctx.f32(plan.N) if shift_out is None else shift_out
@@ -1087,9 +1090,13 @@ class _NullCtx:
 # register-staged split kernel, conv_wgrad.hip)
 SPLIT_WGRAD_BF16 = int(os.environ.get("VINET_SPLIT_WGRAD_BF16", "1"))
 SPLIT_ON_MAIN = int(os.environ.get("VINET_SPLIT_ON_MAIN", "0"))
+# fp32s: the planes of dy are written by the BatchNorm-backward apply pass that produces dy (vinet_bn_bwd_apply_split); 0 = a split pass
+SPLIT_IN_APPLY = int(os.environ.get("VINET_SPLIT_IN_APPLY", "1"))
 # a data gradient that is the only writer of the gradient behind a BatchNorm + ReLU also writes that BatchNorm's backward
 # partial sums where the library can (vinet_conv3d_bn_bwd_stats_rows: the fused temporal data gradient of the stem); 0 = off
 DGRAD_BN_STATS = int(os.environ.get("VINET_DGRAD_BN_STATS", "1"))
+# the backward of a ReLU that sits between a conv and an upsample (the decoder) inside the upsample's backward pass; 0 = vinet_act_bwd
+UPSAMPLE_BWD_RELU = int(os.environ.get("VINET_UPSAMPLE_BWD_RELU", "1"))
 # fp32s: deferral of the decoder's weight gradients (DEFER_DECODER_WGRAD) -- in this form the weight-gradient stream (three launches
 # per conv + the split passes) is the longer one, so it should start with the backward pass, not 35 ms into it
 DEFER_DECODER_WGRAD_F32S = int(os.environ.get("VINET_DEFER_DECODER_WGRAD_F32S", "0"))      # measured at 64 clips: 207.3 -> 212.5 clips/s
@@ -1115,19 +1122,24 @@ def _split_planes_folded(ctx, x):
     return acts
 
 
-def _split_planes(ctx, x, dy):
-    """hi / lo bf16 planes of a conv's input (pending affine applied) and of its output gradient: ((x_hi, x_lo), (dy_hi, dy_lo))"""
+def _split_planes(ctx, x, dy, dy_planes=None):
+    """hi / lo bf16 planes of a conv's input (pending affine applied) and of its output gradient: ((x_hi, x_lo), (dy_hi, dy_lo));
+    dy_planes: those of dy exist already (vinet_bn_bwd_apply_split)"""
     out = []
     if x.fold is not None:
-        hi = View.alloc(dy.B, dy.T, dy.H, dy.W, dy.C, BF16, dy.device)
-        lo = View.alloc(dy.B, dy.T, dy.H, dy.W, dy.C, BF16, dy.device)
-        ctx.call("vinet_split_bf16", C.byref(dy.ct()), L.CAffine(None, None, 0), C.byref(hi.ct()), C.byref(lo.ct()), ctx.stream)
-        return [tuple(_split_planes_folded(ctx, x)), (hi, lo)]
-    for v, aff in ((x.v, x.affine()), (dy, L.CAffine(None, None, 0))):
+        if dy_planes is None:
+            hi = View.alloc(dy.B, dy.T, dy.H, dy.W, dy.C, BF16, dy.device)
+            lo = View.alloc(dy.B, dy.T, dy.H, dy.W, dy.C, BF16, dy.device)
+            ctx.call("vinet_split_bf16", C.byref(dy.ct()), L.CAffine(None, None, 0), C.byref(hi.ct()), C.byref(lo.ct()), ctx.stream)
+            dy_planes = (hi, lo)
+        return [tuple(_split_planes_folded(ctx, x)), dy_planes]
+    for v, aff in ((x.v, x.affine()),) + (((dy, L.CAffine(None, None, 0)),) if dy_planes is None else ()):
         hi = View.alloc(v.B, v.T, v.H, v.W, v.C, BF16, v.device)
         lo = View.alloc(v.B, v.T, v.H, v.W, v.C, BF16, v.device)
         ctx.call("vinet_split_bf16", C.byref(v.ct()), aff, C.byref(hi.ct()), C.byref(lo.ct()), ctx.stream)
         out.append((hi, lo))
+    if dy_planes is not None:
+        out.append(dy_planes)
     return out
 
 
@@ -1158,6 +1170,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
     assert res.is_grad_ready(), "conv backward reached before any consumer produced a gradient"
     Ny = out.C
     fused_bnb = None
+    dy_planes = None        # fp32s: (hi, lo) planes of dy written by the BatchNorm-backward apply pass
     # ---- through BN / activation: dz -> dy (w.r.t. the raw conv output) --------
     if bn is not None:
         fwd = res.affine()
@@ -1185,12 +1198,24 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             q.bnb_c1, q.bnb_c2 = c1.data_ptr(), c2.data_ptr()
             if ctx.lib.vinet_conv3d_wgrad_fuses_bn_bwd(C.byref(q)):
                 fused_bnb = (out, fwd, keep["mean"], keep["invstd"], c1, c2)
-        if fused_bnb is None:
+        if (fused_bnb is None and SPLIT_IN_APPLY and SPLIT_WGRAD_BF16 and ctx.cdt == F32S and plan.wants_wgrad() and dz.dt == F32 and
+                out.dt == F32 and dz.C % 8 == 0 and dz.ld % 8 == 0 and out.ld % 8 == 0 and ctx.device.type == "cuda"):
+            # fp32s: the hi / lo planes of dy (an operand of the three bf16 weight-gradient launches) leave with the apply pass
+            dh = View.alloc(dz.B, dz.T, dz.H, dz.W, dz.C, BF16, dz.device)
+            dl = View.alloc(dz.B, dz.T, dz.H, dz.W, dz.C, BF16, dz.device)
+            ctx.call("vinet_bn_bwd_apply_split", C.byref(dz.ct()), C.byref(out.ct()), fwd, keep["mean"].data_ptr(),
+                     keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), C.byref(dz.ct()), C.byref(dh.ct()), C.byref(dl.ct()), ctx.stream,
+                     tag=("vinet_bn_bwd_apply | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
+                     work=dict(flops=0.0, bytes=4 * nb))
+            dy_planes = (dh, dl)
+        elif fused_bnb is None:
             ctx.call("vinet_bn_bwd_apply", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
                      keep["invstd"].data_ptr(), c1.data_ptr(), c2.data_ptr(), C.byref(dz.ct()), ctx.stream,
                      tag=("vinet_bn_bwd_apply | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
                      work=dict(flops=0.0, bytes=3 * nb))
         dy = dz
+    elif act == L.ACT_RELU and res.grad_masked == res.root().grad_marks and dz.dt == ctx.dt:
+        dy = dz         # the only writer of dz (the upsample's backward) already gated it with this ReLU
     elif act != L.ACT_NONE:
         if dz.dt == ctx.dt:
             dy = dz
@@ -1223,7 +1248,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                            ((not plan.stem and x.fold is None and x.v.C % 8 == 0) or
                             (plan.stem and x.fold is not None and x.scale is None and x.v.off == 0)))
         # SPLIT_ON_MAIN: the split passes run on the main stream (the weight-gradient stream is the longer one in this form)
-        planes_main = _split_planes(ctx, x, dy) if (want_planes and SPLIT_ON_MAIN and ctx.side_stream() is not None) else None
+        planes_main = _split_planes(ctx, x, dy, dy_planes) if (want_planes and SPLIT_ON_MAIN and ctx.side_stream() is not None) else None
 
         def wgrad_job():
             ctx._side_rr = (getattr(ctx, "_side_rr", -1) + 1) % N_SIDE_STREAMS
@@ -1264,7 +1289,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                         ctx.lib.vinet_debug_spin(DBG_SPIN_SIDE, ctx.stream)
                     planes = planes_main
                     if planes is None and want_planes:
-                        planes = _split_planes(ctx, x, dy)
+                        planes = _split_planes(ctx, x, dy, dy_planes)
                     if planes is not None:
                         # the split-bf16 weight gradient as THREE launches of the bf16 kernels (the row- / frame-streaming ones
                         # included) over hi / lo planes of both operands: dw += dy_hi x_hi + dy_lo x_hi + dy_hi x_lo.  Every bf16
@@ -1424,6 +1449,13 @@ def upsample2x_forward(ctx, x, dst=None):
         def bwd():
             dy = dst.grad_view()
             dx = x.grad_view()
+            if UPSAMPLE_BWD_RELU and x.act_out == L.ACT_RELU and not x.is_grad_ready() and x.parent is None and dx.dt == xv.dt:
+                # conv -> ReLU -> upsample (the decoder): this pass is the only writer of the conv's output gradient, the ReLU's
+                # backward goes with it (no vinet_act_bwd pass in the conv's backward)
+                ctx.call("vinet_upsample2x_bwd_relu", C.byref(dy.ct()), C.byref(dx.ct()), C.byref(xv.ct()), dx.dt, ctx.stream)
+                x.mark_grad_ready()
+                x.grad_masked = x.root().grad_marks
+                return
             ctx.call("vinet_upsample2x_bwd", C.byref(dy.ct()), C.byref(dx.ct()), dx.dt, 1 if x.is_grad_ready() else 0, ctx.stream)
             x.mark_grad_ready()
         ctx.record(bwd)
