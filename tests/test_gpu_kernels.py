@@ -762,6 +762,45 @@ def test_stem_folded(dt, hw):
                 sc = stats.get("cpu")[:rc * 2 * N].view(rc, 2, N).double().sum(0)
                 _cmp(sg, sc, 2e-2, "folded stem conv stats")
         run_both("vinet_conv3d", mk)      # (restore y for the checks below)
+    if dt == E.F32 and oW % 64 == 0:
+        # the strip kernel in the split-bf16 form (conv_hs3_kernel: fp32 folded clip, hi / lo weight planes from vinet_pack_weights),
+        # with statistics / with a folded-BN epilogue, against the fp32 model
+        lib = _lib()
+        os_, oh_ = fvec("sfos3", N, 6, 0.5, 1.5), fvec("sfoh3", N, 7)
+        M = B * T * oH * oW
+        w3 = torch.zeros(7 * N * 32, device="cuda")
+        assert lib.vinet_pack_weights(wm.contiguous().cuda().data_ptr(), N, 3, 49, 0, 1, L.F32S, w3.data_ptr(), _stream()) == 0
+        y_ref = yp.get("cpu").clone()
+        for with_stats in (True, False):
+            stats = Pair(torch.zeros((M // 64) * 2 * N))
+
+            def mk_hs3(side):
+                args = mk(side)
+                d = args[0]._obj
+                d.tline = 2
+                if side == "gpu":
+                    d.dtype, d.w = L.F32S, w3.data_ptr()
+                if with_stats:
+                    d.stats = stats.ptr(side)
+                else:
+                    d.out_scale, d.out_shift, d.act = os_.ptr(side), oh_.ptr(side), 1
+                return args
+            lib.vinet_set_option(b"conv_hs", 2)
+            try:
+                run_both("vinet_conv3d", mk_hs3)
+                nbuf = C.create_string_buffer(128)
+                d0 = mk_hs3("gpu")[0]._obj
+                assert lib.vinet_conv3d_kernel_name(C.byref(d0), nbuf, 128) == 0 and nbuf.value == b"conv_hs3_kernel", nbuf.value
+                rows3 = lib.vinet_conv3d_stats_rows(C.byref(d0))
+            finally:
+                lib.vinet_set_option(b"conv_hs", 1)
+            _cmp(yp.get("gpu"), yp.get("cpu"), 1e-4, "folded stem conv (split-bf16 strips)")
+            if with_stats:
+                assert rows3 == B * T * (oW // 64)
+                sg = stats.get("gpu").view(M // 64, 2, N).double().sum(0)
+                sc = stats.get("cpu").view(M // 64, 2, N).double().sum(0)
+                _cmp(sg, sc, 1e-3, "folded stem conv stats (split-bf16 strips)")
+        run_both("vinet_conv3d", mk)      # (restore y for the checks below)
     if dt == E.F32:
         ref = torch.nn.functional.conv3d(src.cpu, wm.view(N, 3, 1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3))
         _cmp(yp.get("gpu").view(B, T, oH, oW, N).permute(0, 4, 1, 2, 3), ref, 2e-5, "folded stem vs torch")

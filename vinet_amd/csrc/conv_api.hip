@@ -480,7 +480,7 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32));
   if (d->tline == 3) snprintf(buf, n, vinet_conv_use_tsd(d) ? "conv_tsd_kernel" : "(unsupported)");
-  else if (vinet_conv_use_hs(d)) snprintf(buf, n, "conv_hs_kernel");
+  else if (vinet_conv_use_hs(d)) snprintf(buf, n, d->dtype == VINET_F32S ? "conv_hs3_kernel" : "conv_hs_kernel");
   else if (vinet_conv_use_ts(d)) snprintf(buf, n, "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
   else if (use_pw(d)) snprintf(buf, n, "conv_pw_kernel<%d,%s>", pw_shape(d).nt * 16, d->pre.scale ? "pre" : "plain");
   else if (use_ht(d)) {

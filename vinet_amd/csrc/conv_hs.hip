@@ -192,16 +192,190 @@ __global__ __launch_bounds__(256, 2) void conv_hs_kernel(const ConvHsArgs a) {
   }
 }
 
+
+// ---- the same strip kernel in the split-bf16 form (VINET_F32S): fp32 folded clip, fp32 output, hi / lo weight planes ------------
+// A position of the overlapped view is 8 fp32 pixels-x-channels = 32 bytes (position v starts 32 bytes after position v - 1); the K
+// order inside a 32-wide chunk is the one vinet_pack_weights(VINET_F32S) gives the weight planes (conv_dma3.h): lane group q holds
+// elements 4q .. 4q+3 and 16+4q .. 16+4q+3, i.e. the two 16-byte pieces at 32 v + 16 q and 32 v + 64 + 16 q of the row; the 8
+// values are split into hi / lo in registers and every product takes three MFMAs (lo.hi + hi.lo + hi.hi, weights as the A operand).
+// conv_dma3 staged the seven rows of every 128 output positions again (12.2 ms at 64 clips, 1.0 TB/s); here every input byte is
+// fetched once.
+VN_DEV void mfma_hs3(f32x4_v& acc, const bf16x8_v& w, const bf16x8_v& a) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(a));
+}
+VN_DEV void mfma_hs3_first(f32x4_v& acc, const bf16x8_v& w, const bf16x8_v& a) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc) : "a"(w), "v"(a));
+}
+VN_DEV void hs3_split(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  hi = pack2bf(x0, x1);
+  lo = pack2bf(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
+__global__ __launch_bounds__(256, 2) void conv_hs3_kernel(const ConvHsArgs a) {
+  constexpr int ROW = 2176, NP = 134, TILE = 64 * 64 * 4;      // 67 positions x 32 B per input row; fp32 output tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* stage = smem;                                  // output tile [64 positions][64 channels] fp32, 16-byte chunk ^ (row & 15)
+  float* red = (float*)(smem + TILE);                  // [2 position halves][64 channels][2]
+  char* ring = smem + TILE + 1024;                     // 7 input rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l_chunk = tid & 15, l_row = tid >> 4;      // store role: 16-byte chunk of a row, rows l_row + 16 j
+  const int ep = lane & 15, eq = lane >> 4;
+
+  bf16x8_v wh[7][2], wl[7][2];
+#pragma unroll
+  for (int g = 0; g < 7; ++g)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = wn * 32 + nt * 16 + (lane & 15);
+      const char* wr = a.w + (((long)g * 64 + n) * 64 + eq * 8) * 2;     // row = [32 hi | 32 lo] bf16
+      wh[g][nt] = *(const bf16x8_v*)wr;
+      wl[g][nt] = *(const bf16x8_v*)(wr + 64);
+    }
+  float osc[2][4], osh[2][4];
+  int st_off[2][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = wn * 32 + nt * 16 + eq * 4 + r;
+      osc[nt][r] = a.out_scale ? a.out_scale[n] : 1.f;
+      osh[nt][r] = a.out_shift ? a.out_shift[n] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = wm * 32 + mt * 16 + ep, chunk = wn * 8 + nt * 4 + eq;
+      st_off[mt][nt] = row * 256 + ((chunk ^ (row & 15)) * 16);
+    }
+  }
+  const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;
+  const bool sigm = a.act == VINET_ACT_SIGMOID;
+  // input role: piece tid of the step's 2 x 134 pieces, and piece 256 + tid for the first 12 threads
+  const int p0r = tid >= NP ? 1 : 0, p0c = tid - p0r * NP;
+  const bool two = tid < 2 * NP - 256;
+  const int p1c = 256 + tid - NP;                      // (row 1)
+
+  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const int bt = (int)fdiv((uint32_t)item, a.dStrips);
+    const int strip = item - bt * a.strips;
+    const int wo0 = strip * 64;
+    const int b = (int)fdiv((uint32_t)bt, a.dT);
+    const int t = bt - b * a.T;
+    const char* xrow0 = a.x + ((long)b * a.sBx + ((long)t * a.Hp * a.Wv + wo0) * (long)a.ldx) * 4;
+    const long x_rowb = (long)a.Wv * a.ldx * 4;
+    char* yb = a.y + ((long)b * a.sBy + ((long)t * a.oH * a.oW + wo0 + l_row) * (long)a.ldy) * 4 + l_chunk * 16;
+    const long y_rowb = (long)a.oW * a.ldy * 4, y_r16 = 16L * a.ldy * 4;
+
+    for (int q = tid; q < 7 * NP; q += 256) {
+      const int h = q / NP, pc = q - h * NP;
+      *(uint4*)(ring + h * ROW + pc * 16) = *(const uint4*)(xrow0 + h * x_rowb + pc * 16);
+    }
+    __syncthreads();
+
+    float ssum[2][4], ssq[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
+
+    for (int ho = 0; ho < a.oH; ++ho) {
+      const bool more = ho + 1 < a.oH;
+      const int hn = more ? 2 * ho + 7 : 0;
+      const uint4 nx0 = *(const uint4*)(xrow0 + (long)(hn + (more ? p0r : 0)) * x_rowb + p0c * 16);
+      const uint4 nx1 = *(const uint4*)(xrow0 + (long)(hn + (more ? 1 : 0)) * x_rowb + (two ? p1c : 0) * 16);
+
+      f32x4_v acc[2][2];
+      const int s0 = (2 * ho) % 7;
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+        const int si = s0 + g - (s0 + g >= 7 ? 7 : 0);
+        const char* row = ring + si * ROW;
+        bf16x8_v ah[2], al[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int v = wm * 32 + mt * 16 + (lane & 15);
+          const uint4 f0 = *(const uint4*)(row + v * 32 + eq * 16), f1 = *(const uint4*)(row + v * 32 + 64 + eq * 16);
+          union { bf16x8_v v8; uint32_t u[4]; } H, Lo;
+          hs3_split(__uint_as_float(f0.x), __uint_as_float(f0.y), H.u[0], Lo.u[0]);
+          hs3_split(__uint_as_float(f0.z), __uint_as_float(f0.w), H.u[1], Lo.u[1]);
+          hs3_split(__uint_as_float(f1.x), __uint_as_float(f1.y), H.u[2], Lo.u[2]);
+          hs3_split(__uint_as_float(f1.z), __uint_as_float(f1.w), H.u[3], Lo.u[3]);
+          ah[mt] = H.v8; al[mt] = Lo.v8;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {      // small terms first
+            if (g == 0) mfma_hs3_first(acc[mt][nt], wl[g][nt], ah[mt]);
+            else mfma_hs3(acc[mt][nt], wl[g][nt], ah[mt]);
+            mfma_hs3(acc[mt][nt], wh[g][nt], al[mt]);
+            mfma_hs3(acc[mt][nt], wh[g][nt], ah[mt]);
+          }
+      }
+      mfma_drain();
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = fmaf(acc[mt][nt][r], osc[nt][r], osh[nt][r]);
+            ssum[nt][r] += v; ssq[nt][r] = fmaf(v, v, ssq[nt][r]);
+            o[r] = fmaxf(v, relu_floor);
+            if (sigm) o[r] = 1.f / (1.f + __expf(-o[r]));
+          }
+          *(float4*)(stage + st_off[mt][nt]) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      __syncthreads();
+      {
+        char* yf = yb + ho * y_rowb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = l_row + 16 * j;
+          *(uint4*)(yf + j * y_r16) = *(const uint4*)(stage + row * 256 + ((l_chunk ^ (row & 15)) * 16));
+        }
+      }
+      if (more) {
+        *(uint4*)(ring + ((2 * ho + 7 + p0r) % 7) * ROW + p0c * 16) = nx0;
+        if (two) *(uint4*)(ring + ((2 * ho + 8) % 7) * ROW + p1c * 16) = nx1;
+      }
+      __syncthreads();
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ss = hs_row16_sum(ssum[nt][r]), qq = hs_row16_sum(ssq[nt][r]);
+          if (ep == 0) {
+            const int col = wn * 32 + nt * 16 + eq * 4 + r;
+            red[(wm * 64 + col) * 2 + 0] = ss;
+            red[(wm * 64 + col) * 2 + 1] = qq;
+          }
+        }
+      __syncthreads();
+      if (tid < 64) {
+        a.stats[((long)item * 2 + 0) * 64 + tid] = red[tid * 2] + red[(64 + tid) * 2];
+        a.stats[((long)item * 2 + 1) * 64 + tid] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+      }
+      __syncthreads();
+    }
+  }
+}
+
 int g_vinet_opt_conv_hs = 1;   // 0 = off, 2 = force on every eligible shape (tests)
 
 // VinetConvDesc::tline == 2: the caller promises taps (0, kh, 0, slice kh), kh = 0..6 (the folded stem)
 bool vinet_conv_use_hs(const VinetConvDesc* d) {
-  if (!g_vinet_opt_conv_hs || d->tline != 2 || d->dtype != VINET_BF16 || d->out_dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
+  const bool split = d->dtype == VINET_F32S && d->out_dtype == VINET_F32;       // conv_hs3_kernel: fp32 folded clip, fp32 output
+  if (!g_vinet_opt_conv_hs || d->tline != 2 || !((d->dtype == VINET_BF16 && d->out_dtype == VINET_BF16) || split) || d->mode != VINET_CONV_GENERIC) return false;
+  if (split && (d->y.ld % 4 != 0 || d->y.sB % 4 != 0 || d->x.sB % 4 != 0)) return false;
   if (d->pre.scale || d->pre.relu || d->accumulate) return false;
   const bool shape = d->x.C == 32 && d->x.ld == 8 && d->Kp == 32 && d->ntaps == 7 && d->sT == 1 && d->sH == 2 && d->sW == 1 &&
                      d->y.C == 64 && (d->n_valid == 0 || d->n_valid == 64) && d->oW % 64 == 0 && d->oT == d->x.T && d->x.W >= d->oW + 3 &&
                      d->x.H >= 2 * d->oH + 5 && d->omT == 1 && d->omH == 1 && d->omW == 1 && d->ooT == 0 && d->ooH == 0 && d->ooW == 0 &&
-                     d->y.T == d->oT && d->y.H == d->oH && d->y.W == d->oW && d->y.ld % 8 == 0 && d->y.sB % 8 == 0 && d->x.sB % 8 == 0 &&
+                     d->y.T == d->oT && d->y.H == d->oH && d->y.W == d->oW && (split || (d->y.ld % 8 == 0 && d->y.sB % 8 == 0 && d->x.sB % 8 == 0)) &&
                      ((uintptr_t)d->x.ptr % 16) == 0 && ((uintptr_t)d->y.ptr % 16) == 0;
   if (!shape) return false;
   if (g_vinet_opt_conv_hs >= 2) return true;
@@ -219,6 +393,13 @@ int vinet_launch_conv_hs(const VinetConvDesc* d, hipStream_t s) {
   a.items = d->x.B * a.T * a.strips;
   a.dStrips = make_fastdiv((uint32_t)a.strips);
   a.dT = make_fastdiv((uint32_t)a.T);
+  if (d->dtype == VINET_F32S) {
+    const int smem3 = 64 * 64 * 4 + 1024 + 7 * 2176;
+    int grid3 = 512;    // 2 workgroups per CU (28 weight fragments in the accumulator file)
+    if (grid3 > a.items) grid3 = a.items;
+    hipLaunchKernelGGL(conv_hs3_kernel, dim3(grid3), dim3(256), smem3, s, a);
+    return vn_launch_status("conv_hs3");
+  }
   const int smem = 64 * 64 * 2 + 1024 + 7 * 1088;
   int grid = 768;     // 3 workgroups per CU (152 registers, 17 KB of LDS)
   if (grid > a.items) grid = a.items;
