@@ -426,6 +426,22 @@ def test_conv3d_tstream(case):
         lib.vinet_set_option(b"conv_ts", 1)
 
 
+@pytest.mark.parametrize("case", CONV_TS_CASES, ids=[c[0] for c in CONV_TS_CASES])
+def test_conv3d_tstream_split_bf16(case):
+    """the frame-streaming kernel in the VINET_F32S form (conv_ts3_kernel: fp32 tensors, frames split into hi / lo planes on the way
+    into the LDS ring, three MFMAs per product) on the same forced cases, held to the split form's 1e-4"""
+    lib = _lib()
+    assert lib.vinet_set_option(b"conv_ts", 2) == 0
+    try:
+        ex = dict(case[7], tline=True)
+        d0 = _run_conv_case(case[:7] + (ex,), E.F32, forced=True, cdt=L.F32S, tol=1e-4)
+        d0.dtype = L.F32S
+        buf = C.create_string_buffer(128)
+        assert lib.vinet_conv3d_kernel_name(C.byref(d0), buf, 128) == 0 and buf.value.startswith(b"conv_ts3_kernel<"), buf.value
+    finally:
+        lib.vinet_set_option(b"conv_ts", 1)
+
+
 @pytest.mark.parametrize("ksp", [(7, 2, 3), (3, 2, 1), (2, 2, 0), (5, 3, 2)], ids=["k7s2p3", "k3s2p1", "k2s2p0", "k5s3p2"])
 @pytest.mark.parametrize("acc", [0, 1])
 def test_conv3d_tstream_dgrad_fused(ksp, acc):
@@ -631,7 +647,7 @@ def _run_conv_case(case, dt, forced=False, want_y=False, cdt=None, tol=None):
         r = _lib().vinet_conv3d_stats_rows(C.byref(d0))
         nbuf = C.create_string_buffer(128)
         _lib().vinet_conv3d_kernel_name(C.byref(d0), nbuf, 128)
-        per_item = nbuf.value.startswith(b"conv_ts_kernel") or nbuf.value.startswith(b"conv_hs_kernel")    # one row per 64-position item, all its frames / rows
+        per_item = nbuf.value.startswith(b"conv_ts") or nbuf.value.startswith(b"conv_hs")    # one row per 64-position item, all its frames / rows
         assert (r >= (M + bm - 1) // bm or ex.get("tline") == 6 or per_item) and (forced or r == AbiEmulator().vinet_conv3d_stats_rows(d0))   # (pointwise: one row per workgroup)
         assert r <= rows
         rc = AbiEmulator().vinet_conv3d_stats_rows(d0)

@@ -150,6 +150,7 @@ static PwShape pw_shape(const VinetConvDesc* d);
 static HtShape ht_shape(const VinetConvDesc* d);
 extern int g_vinet_opt_ht, g_vinet_opt_ht3, g_vinet_opt_ht32, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
 bool vinet_conv_use_ts(const VinetConvDesc* d);
+int vinet_conv_ts_positions(const VinetConvDesc* d);
 bool vinet_conv_use_hs(const VinetConvDesc* d);
 bool vinet_conv_use_tsd(const VinetConvDesc* d);
 int vinet_launch_conv_tsd(const VinetConvDesc* d, hipStream_t s);
@@ -184,7 +185,7 @@ extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
   // the strip / frame-streaming kernels of the stem keep their partial sums in registers over a whole item (a 64-wide strip of
   // one frame, 64 positions of one clip) and write ONE row per item
   if (vinet_conv_use_hs(d)) return (int)((long)d->x.B * d->oT * (d->oW / 64));
-  if (vinet_conv_use_ts(d)) return (int)((long)d->x.B * (((long)d->oH * d->oW) / 64));
+  if (vinet_conv_use_ts(d)) return (int)((long)d->x.B * (((long)d->oH * d->oW) / vinet_conv_ts_positions(d)));
   if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_pw(d)) return pw_shape(d).gm;   // one row per workgroup (4 waves x up to 16 tiles of 64 rows)
   if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_ht(d)) {
     const HtShape h = ht_shape(d);
@@ -481,7 +482,7 @@ extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32));
   if (d->tline == 3) snprintf(buf, n, vinet_conv_use_tsd(d) ? "conv_tsd_kernel" : "(unsupported)");
   else if (vinet_conv_use_hs(d)) snprintf(buf, n, d->dtype == VINET_F32S ? "conv_hs3_kernel" : "conv_hs_kernel");
-  else if (vinet_conv_use_ts(d)) snprintf(buf, n, "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
+  else if (vinet_conv_use_ts(d)) snprintf(buf, n, d->dtype == VINET_F32S ? "conv_ts3_kernel<%s>" : "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
   else if (use_pw(d)) snprintf(buf, n, "conv_pw_kernel<%d,%s>", pw_shape(d).nt * 16, d->pre.scale ? "pre" : "plain");
   else if (use_ht(d)) {
     const HtShape h = ht_shape(d);

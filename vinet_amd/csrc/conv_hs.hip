@@ -200,11 +200,10 @@ __global__ __launch_bounds__(256, 2) void conv_hs_kernel(const ConvHsArgs a) {
 // values are split into hi / lo in registers and every product takes three MFMAs (lo.hi + hi.lo + hi.hi, weights as the A operand).
 // conv_dma3 staged the seven rows of every 128 output positions again (12.2 ms at 64 clips, 1.0 TB/s); here every input byte is
 // fetched once.
+// (the compiler's own MFMA: three dependent products per accumulator -- it pads their hazards itself; conv_ts3_kernel's inline-asm
+//  form with fixed wait states returned stale accumulator elements)
 VN_DEV void mfma_hs3(f32x4_v& acc, const bf16x8_v& w, const bf16x8_v& a) {
-  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(a));
-}
-VN_DEV void mfma_hs3_first(f32x4_v& acc, const bf16x8_v& w, const bf16x8_v& a) {
-  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc) : "a"(w), "v"(a));
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
 }
 VN_DEV void hs3_split(float x0, float x1, uint32_t& hi, uint32_t& lo) {
   hi = pack2bf(x0, x1);
@@ -306,13 +305,12 @@ __global__ __launch_bounds__(256, 2) void conv_hs3_kernel(const ConvHsArgs a) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {      // small terms first
-            if (g == 0) mfma_hs3_first(acc[mt][nt], wl[g][nt], ah[mt]);
-            else mfma_hs3(acc[mt][nt], wl[g][nt], ah[mt]);
+            if (g == 0) acc[mt][nt] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+            mfma_hs3(acc[mt][nt], wl[g][nt], ah[mt]);
             mfma_hs3(acc[mt][nt], wh[g][nt], al[mt]);
             mfma_hs3(acc[mt][nt], wh[g][nt], ah[mt]);
           }
       }
-      mfma_drain();
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

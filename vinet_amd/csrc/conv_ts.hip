@@ -278,22 +278,229 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
   }
 }
 
+
+// ---- the same frame-streaming kernel in the split-bf16 form (VINET_F32S: fp32 x and y, hi / lo weight planes) --------------------
+// The split happens ONCE per loaded element, on the way into the LDS ring (where the pending BatchNorm + ReLU is applied anyway):
+// a frame is kept as a hi and a lo bf16 plane, [32 positions][64 channels] each, with the channels of every 32-wide chunk in the K
+// order of vinet_pack_weights(VINET_F32S) (lane group q: elements 4q .. 4q+3 and 16+4q .. 16+4q+3 -- the 4 consecutive channels a
+// loader thread holds land as 8 contiguous bytes), so a fragment is one ds_read_b128 per plane and the MFMAs read hi / lo operands
+// directly: weights_lo x hi + weights_hi x lo + weights_hi x hi.  32 positions per workgroup (ring 7 x 8 KB + an fp32 stage tile of
+// 8 KB: two workgroups per CU); the four waves split the 64 output channels (16 each, all 32 positions), so a wave's weights are
+// 7 x 2 hi + 7 x 2 lo fragments = 112 registers, as in the bf16 kernel.  conv_dma3 staged every tap's frame again (10.7 ms forward,
+// 5.9 + 4.8 ms for the two stride phases of the data gradient at 64 clips, 1.0-1.6 TB/s).
+VN_DEV void ts3_split(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  hi = pack2bf(x0, x1);
+  lo = pack2bf(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+// (the compiler's own MFMA: it pads the hazards of three dependent products on one accumulator itself -- an inline-asm form with
+//  fixed wait states returned stale accumulator elements for the second row tile)
+VN_DEV void mfma_ts3(f32x4_v& acc, const bf16x8_v& w, const bf16x8_v& a) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void conv_ts3_kernel(const ConvTsArgs a) {
+  constexpr int KMAX = 7, P = 32, PLANE = P * 128, FRAME = 2 * PLANE, STAGE = P * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;                                   // KMAX frames: [hi plane | lo plane], [32 positions][128 B]
+  char* stage = smem + KMAX * FRAME;                   // output tile [32 positions][64 channels] fp32, 16-byte chunk ^ (row & 15)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = a.k, s = a.s;
+  const int ep = lane & 15, eq = lane >> 4;
+  // load / store role: 16 bytes = 4 fp32 channels 4 c4 .. 4 c4 + 3 of row l_row (+ 16)
+  const int c4 = tid & 15, l_row = tid >> 4;
+  // where my 4 channels go inside a plane row: 16-byte column (chunk * 4 + group), 8-byte half, XOR (row & 7) on the column
+  const int w_col16 = (c4 >> 3) * 4 + (c4 & 3), w_half = (c4 >> 2) & 1;
+  int w_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = l_row + 16 * j;
+    w_off[j] = r * 128 + ((w_col16 ^ (r & 7)) * 16) + w_half * 8;
+  }
+  float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PRE) { psc = *(const float4*)(a.in_scale + c4 * 4); psh = *(const float4*)(a.in_shift + c4 * 4); }
+  // fp32 -> (pending BatchNorm + ReLU) -> hi / lo halves of my 4 channels
+  auto put = [&](char* slot, int j, uint4 v, bool live) {
+    float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    if constexpr (PRE) {
+      f[0] = fmaxf(fmaf(f[0], psc.x, psh.x), 0.f); f[1] = fmaxf(fmaf(f[1], psc.y, psh.y), 0.f);
+      f[2] = fmaxf(fmaf(f[2], psc.z, psh.z), 0.f); f[3] = fmaxf(fmaf(f[3], psc.w, psh.w), 0.f);
+    }
+    uint32_t h0, l0, h1, l1;
+    ts3_split(f[0], f[1], h0, l0);
+    ts3_split(f[2], f[3], h1, l1);
+    *(uint2*)(slot + w_off[j]) = live ? make_uint2(h0, h1) : make_uint2(0, 0);
+    *(uint2*)(slot + PLANE + w_off[j]) = live ? make_uint2(l0, l1) : make_uint2(0, 0);
+  };
+
+  // ---- taps (scalar) and this wave's weights: channels 16 wave .. + 15, hi and lo planes of every tap ------------------
+  int rel[KMAX];
+  bf16x8_v wh[KMAX][2], wl[KMAX][2];                   // [tap][k step]
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) {
+    rel[i] = 0;
+    if (i < k) {
+      const int4 tp = load_tap(a.taps, i);
+      rel[i] = tp.x + a.pad;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int n = wave * 16 + (lane & 15);
+        const char* wr = a.w + ((((long)tp.w * 64 + n) * 2 + ks) * 64 + eq * 8) * 2;     // row = 2 chunks of [32 hi | 32 lo]
+        wh[i][ks] = *(const bf16x8_v*)wr;
+        wl[i][ks] = *(const bf16x8_v*)(wr + 64);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { wh[i][ks] = (bf16x8_v){0, 0, 0, 0, 0, 0, 0, 0}; wl[i][ks] = wh[i][ks]; }
+    }
+  }
+  float osc[4], osh[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = wave * 16 + eq * 4 + r;
+    osc[r] = a.out_scale ? a.out_scale[n] : 1.f;
+    osh[r] = a.out_shift ? a.out_shift[n] : 0.f;
+  }
+  const bool aff_out = a.out_scale != nullptr || a.out_shift != nullptr;
+  int st_off[2], fr_off[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = mt * 16 + ep;
+    st_off[mt] = row * 256 + (((wave * 4 + eq) ^ (row & 15)) * 16);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fr_off[mt][ks] = row * 128 + (((ks * 4 + eq) ^ (row & 7)) * 16);
+  }
+  const float relu_floor = a.act == VINET_ACT_RELU ? 0.f : -INFINITY;
+  const bool sigm = a.act == VINET_ACT_SIGMOID;
+
+  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const int b = (int)fdiv((uint32_t)item, a.dPatches);
+    const int patch = item - b * a.patches;
+    const int pos0 = patch * P;
+    const char* xb = a.x + ((long)b * a.sBx + (long)(pos0 + l_row) * a.ldx + c4 * 4) * 4;
+    char* yb = a.y + ((long)b * a.sBy + (long)(pos0 + l_row) * a.ldy + c4 * 4) * 4;
+    const long x_plane = (long)a.HW * a.ldx * 4, y_plane = (long)a.HW * a.ldy * 4;
+    const long x_r16 = 16L * a.ldx * 4, y_r16 = 16L * a.ldy * 4;
+
+    for (int g = 0; g < k; ++g) {
+      const int p = g - a.pad;
+      const bool live = (unsigned)p < (unsigned)a.Ti;
+      const uint4 v0 = *(const uint4*)(xb + (live ? p : 0) * x_plane), v1 = *(const uint4*)(xb + (live ? p : 0) * x_plane + x_r16);
+      char* slot = ring + ((p + 2 * KMAX) % k) * FRAME;
+      put(slot, 0, v0, live);
+      put(slot, 1, v1, live);
+    }
+    __syncthreads();
+
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int to = 0; to < a.To; ++to) {
+      const bool more = to + 1 < a.To;
+      const int pnew = (to + 1) * s - a.pad + k - s;
+      const bool in0 = more && (unsigned)pnew < (unsigned)a.Ti;
+      const bool in1 = more && s == 2 && (unsigned)(pnew + 1) < (unsigned)a.Ti;
+      const char* xs0 = xb + (in0 ? pnew : 0) * x_plane;
+      const char* xs1 = xb + (in1 ? pnew + 1 : 0) * x_plane;
+      const uint4 nx00 = *(const uint4*)xs0, nx01 = *(const uint4*)(xs0 + x_r16);
+      const uint4 nx10 = *(const uint4*)xs1, nx11 = *(const uint4*)(xs1 + x_r16);
+      char* yf = yb + (long)(to * a.omT + a.ooT) * y_plane;
+      float4 old0 = make_float4(0.f, 0.f, 0.f, 0.f), old1 = old0;
+      if (a.accumulate) { old0 = *(const float4*)yf; old1 = *(const float4*)(yf + y_r16); }
+
+      f32x4_v acc[2];
+      acc[0] = (f32x4_v){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+      const int s0 = (to * s - a.pad + 2 * KMAX) % k;
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        if (i < k) {
+          int si = s0 + rel[i];
+          si -= si >= k ? k : 0;
+          const char* fr = ring + si * FRAME;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_v ah[2], al[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              ah[mt] = *(const bf16x8_v*)(fr + fr_off[mt][ks]);
+              al[mt] = *(const bf16x8_v*)(fr + PLANE + fr_off[mt][ks]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {      // small terms first
+              mfma_ts3(acc[mt], wl[i][ks], ah[mt]);
+              mfma_ts3(acc[mt], wh[i][ks], al[mt]);
+              mfma_ts3(acc[mt], wh[i][ks], ah[mt]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = aff_out ? fmaf(acc[mt][r], osc[r], osh[r]) : (float)acc[mt][r];
+          ssum[r] += v; ssq[r] = fmaf(v, v, ssq[r]);
+          o[r] = fmaxf(v, relu_floor);
+          if (sigm) o[r] = 1.f / (1.f + __expf(-o[r]));
+        }
+        *(float4*)(stage + st_off[mt]) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+      __syncthreads();          // ring frames of this step are free, the output tile is complete
+      {
+        float4 o0 = *(const float4*)(stage + l_row * 256 + ((c4 ^ (l_row & 15)) * 16));
+        float4 o1 = *(const float4*)(stage + (l_row + 16) * 256 + ((c4 ^ ((l_row + 16) & 15)) * 16));
+        if (a.accumulate) {
+          o0.x += old0.x; o0.y += old0.y; o0.z += old0.z; o0.w += old0.w;
+          o1.x += old1.x; o1.y += old1.y; o1.z += old1.z; o1.w += old1.w;
+        }
+        *(float4*)yf = o0;
+        *(float4*)(yf + y_r16) = o1;
+      }
+      if (more) {
+        char* slot0 = ring + ((pnew + 2 * KMAX) % k) * FRAME;
+        put(slot0, 0, nx00, in0);
+        put(slot0, 1, nx01, in0);
+        if (s == 2) {
+          char* slot1 = ring + ((pnew + 1 + 2 * KMAX) % k) * FRAME;
+          put(slot1, 0, nx10, in1);
+          put(slot1, 1, nx11, in1);
+        }
+      }
+      __syncthreads();
+    }
+    if (a.stats) {     // a wave holds all 32 positions of its 16 channels: 16 lanes of a row by DPP, no LDS
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ss = ts_row16_sum(ssum[r]), qq = ts_row16_sum(ssq[r]);
+        if (ep == 0) {
+          const int n = wave * 16 + eq * 4 + r;
+          a.stats[((long)item * 2 + 0) * 64 + n] = ss;
+          a.stats[((long)item * 2 + 1) * 64 + n] = qq;
+        }
+      }
+    }
+  }
+}
+
 int g_vinet_opt_conv_ts = 1;   // 0 = off, 2 = force on every eligible shape (tests)
 
 bool vinet_conv_use_ts(const VinetConvDesc* d) {
-  if (!g_vinet_opt_conv_ts || d->tline != 1 || d->dtype != VINET_BF16 || d->out_dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
+  const bool split = d->dtype == VINET_F32S && d->out_dtype == VINET_F32;       // conv_ts3_kernel: fp32 tensors, hi / lo weight planes
+  if (!g_vinet_opt_conv_ts || d->tline != 1 || !((d->dtype == VINET_BF16 && d->out_dtype == VINET_BF16) || split) || d->mode != VINET_CONV_GENERIC) return false;
   if (d->pre.scale && !(d->pre.relu && d->pre.shift)) return false;
   if (d->pre.relu && !d->pre.scale) return false;
   const long HW = (long)d->oH * d->oW;
+  const int al = split ? 4 : 8;
   const bool shape = d->x.C == 64 && d->y.C == 64 && (d->n_valid == 0 || d->n_valid == 64) && d->Kp == 64 && d->ntaps >= 2 && d->ntaps <= 7 &&
                      (d->sT == 1 || d->sT == 2) && d->ntaps >= d->sT && d->sH == 1 && d->sW == 1 && d->omH == 1 && d->omW == 1 && d->ooH == 0 &&
                      d->ooW == 0 && d->x.H == d->oH && d->x.W == d->oW && d->y.H == d->oH && d->y.W == d->oW && HW % 64 == 0 &&
-                     d->tpad >= 0 && d->tpad < d->ntaps && d->x.ld % 8 == 0 && d->y.ld % 8 == 0 && d->x.sB % 8 == 0 && d->y.sB % 8 == 0 &&
+                     d->tpad >= 0 && d->tpad < d->ntaps && d->x.ld % al == 0 && d->y.ld % al == 0 && d->x.sB % al == 0 && d->y.sB % al == 0 &&
                      ((uintptr_t)d->x.ptr % 16) == 0 && ((uintptr_t)d->y.ptr % 16) == 0;
   if (!shape) return false;
   if (g_vinet_opt_conv_ts >= 2) return true;
   return (long)d->x.B * (HW / 64) >= 2048 && d->oT >= 4;
 }
+// positions per workgroup = per statistics row
+int vinet_conv_ts_positions(const VinetConvDesc* d) { return d->dtype == VINET_F32S ? 32 : 64; }
 
 int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s) {
   ConvTsArgs a;
@@ -303,6 +510,26 @@ int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s) {
   a.Ti = d->x.T; a.To = d->oT; a.HW = d->oH * d->oW; a.ldx = d->x.ld; a.ldy = d->y.ld; a.sBx = d->x.sB; a.sBy = d->y.sB;
   a.k = d->ntaps; a.s = d->sT; a.pad = d->tpad; a.omT = d->omT; a.ooT = d->ooT; a.act = d->act; a.accumulate = d->accumulate;
   VN_CHECK_ARG((d->oT - 1) * d->omT + d->ooT < d->y.T && d->ooT >= 0 && d->omT > 0, "conv_ts: output placement outside y");
+  if (d->dtype == VINET_F32S) {
+    a.patches = a.HW / 32;
+    a.items = d->x.B * a.patches;
+    a.dPatches = make_fastdiv((uint32_t)a.patches);
+    const int smem3 = 7 * 2 * 32 * 128 + 32 * 256;
+    static bool attr3_done[64] = {false};
+    int dev3 = 0;
+    (void)hipGetDevice(&dev3);
+    if (!attr3_done[dev3 & 63]) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv_ts3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_ts3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+      if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(conv_ts3): %s", hipGetErrorString(e)); return (int)e; }
+      attr3_done[dev3 & 63] = true;
+    }
+    int grid3 = 512;
+    if (grid3 > a.items) grid3 = a.items;
+    if (d->pre.scale) hipLaunchKernelGGL(conv_ts3_kernel<true>, dim3(grid3), dim3(256), smem3, s, a);
+    else hipLaunchKernelGGL(conv_ts3_kernel<false>, dim3(grid3), dim3(256), smem3, s, a);
+    return vn_launch_status("conv_ts3");
+  }
   a.patches = a.HW / 64;
   a.items = d->x.B * a.patches;
   a.dPatches = make_fastdiv((uint32_t)a.patches);
