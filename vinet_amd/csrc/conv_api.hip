@@ -394,6 +394,10 @@ static HtShape ht_shape(const VinetConvDesc* d) {
     const int bn = nts[i] * 16, pad = (N + bn - 1) / bn * bn;
     if (pad < bestpad) { bestpad = pad; best = nts[i]; }
   }
+  // split form: the 32-wide tile halves the work per staged halo image; it is worth it only where the 64-wide one would pad N by more
+  // than 15 % (N = 32).  (N = 480, the data gradient of the 480 -> 192 decoder conv: 512 columns of 64-wide tiles run at 290 TF/s,
+  // 480 columns of 32-wide ones at 190.)
+  if (split && best == 2 && (N + 63) / 64 * 64 * 100 <= (N + 31) / 32 * 32 * 115) best = 4;
   h.nt = best;
   return h;
 }
