@@ -148,39 +148,17 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   // barrier that publishes the image); padding stays zero
   float* const aff = (float*)(smem + Cfg::KLOOP_BYTES);
   auto xform_halo = [&](int c0) {
-    if constexpr (SPLIT) {
-      // this lane's piece = 4 fp32 channels c0 + 4 src_chunk .. + 3.  The row is split here, once per halo image, and
-      // not once per tap in the K loop: pieces q and q + 4 of a row (the 8 channels of lane group q's K slice) trade
-      // places with lane ^ 4, piece q is rewritten as the 8 hi halves and piece q + 4 as the 8 lo halves -- in place,
-      // so the K loop reads its two fragments ready-made from the addresses it read the fp32 values from.
-      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (PRE) {
-        const float* sp_ = aff + c0 + src_chunk * 4;
-        sc = *(const float4*)sp_; sh = *(const float4*)(sp_ + a.Kp);
-      }
-      const bool upper = (src_chunk & 4) != 0;
-#pragma unroll 1
+    if constexpr (SPLIT) {     // this lane's piece = 4 fp32 channels c0 + 4 src_chunk .. + 3
+      const float* sp_ = aff + c0 + src_chunk * 4;
+      const float4 sc = *(const float4*)sp_, sh = *(const float4*)(sp_ + a.Kp);
+#pragma unroll
       for (int j = 0; j < HL; ++j) {
         float4* q = (float4*)(halo + (j * 4 + wave) * 1024 + lane * 16);
-        float4 v = *q;
-        if constexpr (PRE) {
-          const bool live = (hal_live >> j) & 1u;
-          v = live ? make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f), fmaxf(fmaf(v.z, sc.z, sh.z), 0.f),
-                                 fmaxf(fmaf(v.w, sc.w, sh.w), 0.f))
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float4 w;            // lane ^ 4's piece (ds_swizzle, bit mode: and 0x1f, or 0, xor 4)
-        w.x = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v.x), 0x101f));
-        w.y = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v.y), 0x101f));
-        w.z = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v.z), 0x101f));
-        w.w = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v.w), 0x101f));
-        const float4 f0 = upper ? w : v, f1 = upper ? v : w;
-        uint32_t h[4], l[4];
-        split_pair(f0.x, f0.y, h[0], l[0]);
-        split_pair(f0.z, f0.w, h[1], l[1]);
-        split_pair(f1.x, f1.y, h[2], l[2]);
-        split_pair(f1.z, f1.w, h[3], l[3]);
-        *(uint4*)q = upper ? make_uint4(l[0], l[1], l[2], l[3]) : make_uint4(h[0], h[1], h[2], h[3]);
+        const float4 v = *q;
+        const bool live = (hal_live >> j) & 1u;
+        *q = live ? make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f), fmaxf(fmaf(v.z, sc.z, sh.z), 0.f),
+                                fmaxf(fmaf(v.w, sc.w, sh.w), 0.f))
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
     const float* sp_ = aff + c0 + src_chunk * 8;
@@ -263,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   auto compute = [&](int slot, int tapoff) {
     const char* Bs = bring + slot * Cfg::BSLOT_BYTES;
     if constexpr (SPLIT) {
-      // this lane's K group: pieces q (hi) and q + 4 (lo) of the row, the K order the hi / lo weight planes are packed in
+      // 8 fp32 of this lane's K group (pieces q and q + 4 of the row: the K order the hi / lo weight planes are packed in)
       uint4 ar[MT][2];
       bf16x8_v bh[NT], bl[NT];
 #pragma unroll
@@ -278,11 +256,14 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
         bl[j] = *(const bf16x8_v*)(Bs + j * 2048 + bfo1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      bf16x8_v ah[MT], al[MT];      // (split by xform_halo: piece q = hi halves, piece q + 4 = lo halves)
+      bf16x8_v ah[MT], al[MT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        union { bf16x8_v v; uint4 u; } H, Lo;
-        H.u = ar[i][0]; Lo.u = ar[i][1];
+        union { bf16x8_v v; uint32_t u[4]; } H, Lo;
+        split_pair(__uint_as_float(ar[i][0].x), __uint_as_float(ar[i][0].y), H.u[0], Lo.u[0]);
+        split_pair(__uint_as_float(ar[i][0].z), __uint_as_float(ar[i][0].w), H.u[1], Lo.u[1]);
+        split_pair(__uint_as_float(ar[i][1].x), __uint_as_float(ar[i][1].y), H.u[2], Lo.u[2]);
+        split_pair(__uint_as_float(ar[i][1].z), __uint_as_float(ar[i][1].w), H.u[3], Lo.u[3]);
         ah[i] = H.v; al[i] = Lo.v;
       }
 #pragma unroll
@@ -362,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
       int slot = 0, fill = BSLOTS - 1;
       for (int j = 0; j < nt; ++j) {
         wait_vmcnt<BL*(BSLOTS - 2)>();             // halo image (first step) and my weight DMAs of this step have landed
-        if constexpr (PRE || SPLIT) {
+        if constexpr (PRE) {
           if (j == 0) xform_halo(c0);
         }
 #ifdef VINET_CONV_TIMING

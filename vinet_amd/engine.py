@@ -54,6 +54,12 @@ _UNPACK_TABLES = {}
 # weight-gradient streams the jobs are dealt over round robin (1 = one side stream)
 N_SIDE_STREAMS = int(os.environ.get("VINET_SIDE_STREAMS", "1"))
 _SIDE_STREAMS = {}
+# Inference at small batches: the four branches of an Inception stage are independent kernels whose grids cannot fill
+# 256 CUs (batch 1: 3 .. 170 workgroups), so below this many input voxels a stage forks them over two more streams
+# (entry -> branch 1 on the caller's stream, branch 2 on one, pool -> branch 3 on the other) and joins at the concat:
+# 3 kernels on the stage's critical path instead of 7.  Under capture the fork / join events become graph edges (fan-out
+# <= 3: below the 6-8 outgoing edges that the runtime's replay mishandles, profiles/r4_capture_fanout.txt).  0 = never.
+BRANCH_STREAMS_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_VOX", "65536"))
 
 
 def set_default_dtype(name):
@@ -337,6 +343,22 @@ class Ctx:
         if st is None:
             st = _SIDE_STREAMS[(self.device.index, k)] = torch.cuda.Stream(self.device)
         return st
+
+    def branch_streams(self, nvox):
+        """the two extra streams an Inception stage forks its branches over in small-batch inference (None: run in order)"""
+        if self.training or self.recording or self.device.type != "cuda" or nvox > BRANCH_STREAMS_VOX:
+            return None
+        out = []
+        for k in ("b1", "b2"):
+            st = _SIDE_STREAMS.get((self.device.index, k))
+            if st is None:
+                st = _SIDE_STREAMS[(self.device.index, k)] = torch.cuda.Stream(self.device)
+            out.append(st)
+        return out
+
+    def on_stream(self, st):
+        """with ctx.on_stream(st): launches (and torch allocations) go to `st`"""
+        return _OnStream(self, st)
 
     def side_streams(self):
         """every weight-gradient stream in use (N_SIDE_STREAMS of them; empty without a GPU)"""
@@ -1076,6 +1098,22 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     if ctx.recording:
         ctx.record(lambda: _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M))
     return res
+
+
+class _OnStream:
+    def __init__(self, ctx, st):
+        self.ctx, self.st = ctx, st
+
+    def __enter__(self):
+        self.prev = self.ctx.stream
+        self.cm = torch.cuda.stream(self.st)
+        self.cm.__enter__()
+        self.ctx.stream = self.st.cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.stream = self.prev
+        return self.cm.__exit__(*exc)
 
 
 class _NullCtx:

@@ -187,6 +187,23 @@ class _Mixed(_Block):
         o1, o2, o3 = b0, b0 + b1, b0 + b1 + b2
         # the pool branch FIRST: backward then reaches the entry conv before the pool, so the entry conv's data gradient is the
         # first writer of x.grad (a plain store: the pointwise streaming kernel, conv_pw.h) and the pool backward accumulates
+        fork = ctx.branch_streams(xv.B * xv.T * xv.H * xv.W)
+        if fork is not None:      # small-batch inference: the branches run side by side (engine.BRANCH_STREAMS_VOX)
+            main = torch.cuda.current_stream(ctx.device)
+            fork[1].wait_stream(main)
+            with ctx.on_stream(fork[1]):
+                pooled = E.maxpool_forward(ctx, x, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+                self.branch3[1]._fwd(ctx, pooled, cat.sub_chan(o3, o3 + b3))
+                del pooled
+            mods, jp, jbn = self._entry()
+            E.conv_forward(ctx, jp, x, bn=jbn, act=L.ACT_RELU, dst=entry)
+            fork[0].wait_stream(main)
+            with ctx.on_stream(fork[0]):
+                self.branch2[1]._fwd(ctx, r2, cat.sub_chan(o2, o3))
+            self.branch1[1]._fwd(ctx, r1, cat.sub_chan(o1, o2))
+            main.wait_stream(fork[0])
+            main.wait_stream(fork[1])
+            return cat
         pooled = E.maxpool_forward(ctx, x, (3, 3, 3), (1, 1, 1), (1, 1, 1))
         self.branch3[1]._fwd(ctx, pooled, cat.sub_chan(o3, o3 + b3))
         mods, jp, jbn = self._entry()
