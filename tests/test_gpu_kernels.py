@@ -380,6 +380,9 @@ SPLITK_CASES = [
     ("sk_tslice", (2, 3, 5, 5), 96, 48, (3, 3, 3), (3, 1, 1), (0, 1, 1), dict(in_ttotal=5, in_toff=1)),
     ("sk_pre", (1, 2, 9, 11), 160, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(pre=True)),
     ("sk_m300", (1, 3, 10, 10), 832, 384, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(epi=True, act=1)),
+    # long K on >= 1024 voxels: the large tiles that split-K makes affordable (128 x 192 for N = 192, 128 x 128 otherwise)
+    ("sk_tile192", (1, 5, 28, 48), 480, 192, (5, 3, 3), (5, 1, 1), (0, 1, 1), dict(act=1, epi=True)),
+    ("sk_tile128", (1, 3, 28, 48), 160, 480, (3, 3, 3), (3, 1, 1), (0, 1, 1), dict(act=1)),
 ]
 
 

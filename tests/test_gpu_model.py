@@ -388,6 +388,37 @@ def test_graphed_inference_matches_eager():
     assert torch.equal(g(x1), e1)
 
 
+def test_inference_branch_streams_do_not_change_the_maps(monkeypatch):
+    """small-batch inference forks the branches of every Inception stage over two more streams (engine.BRANCH_STREAMS_VOX):
+    same kernels, same bits -- eager and under capture, over repeated replays (a lost edge shows as a stale branch)"""
+    from vinet_amd import model as VM
+    from vinet_amd.graph import GraphedInference
+    E.set_default_dtype("bf16")
+    m = VM.VideoSaliencyModel(num_clips=8).eval()
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 3))
+    m = m.to(DEV)
+    xs = [synth.clip(1, 8, 96, 192, k).to(DEV).permute(0, 2, 1, 3, 4).contiguous() for k in (1, 2, 5)]
+    monkeypatch.setattr(E, "BRANCH_STREAMS_VOX", 0)
+    with torch.no_grad():
+        ref = [m(x).clone() for x in xs]
+    monkeypatch.setattr(E, "BRANCH_STREAMS_VOX", 1 << 20)
+    monkeypatch.setattr(E, "BRANCH_STREAMS_EAGER", True)
+    E.LAUNCH_LOG = []
+    try:
+        with torch.no_grad():
+            got = [m(x).clone() for x in xs]
+        streams = {a[1] for a in E.LAUNCH_LOG if a[0] == "vinet_conv3d"}
+    finally:
+        E.LAUNCH_LOG = None
+    assert len(streams) == 3, "the branches were not forked"
+    for r, g_ in zip(ref, got):
+        assert torch.equal(r, g_)
+    g = GraphedInference(m, xs[0])
+    for _ in range(5):
+        for x, r in zip(xs, ref):
+            assert torch.equal(g(x), r)
+
+
 def test_harness_postprocessed_maps_eager_graph_and_oracle():
     """generate_result.py:48-104 on device: the sliding-window schedule with the resize + blur + uint8 step; eager ==
     hipGraph replay, and the bytes are the oracle's post-processing of the raw maps"""

@@ -8,6 +8,7 @@ static thread_local char g_err[512] = "";
 extern int g_vinet_opt_tperm;
 extern int g_vinet_opt_epi_rows;
 extern int g_vinet_opt_n64_tile;
+extern int g_vinet_opt_sk_tile;
 extern int g_vinet_opt_n192_tile;
 extern int g_vinet_opt_n64_kmax;
 extern int g_vinet_opt_n128_kmax;
@@ -23,9 +24,16 @@ void vinet_set_error(const char* fmt, ...) {
 extern "C" const char* vinet_last_error(void) { return g_err; }
 extern "C" int vinet_abi_version(void) { return VINET_ABI_VERSION; }
 
+extern int g_vinet_opt_splitk;
+// may this launch split its K loop?  (no statistics, no accumulation, and scratch lent -- or, for the size query that
+// precedes the lending, assumed lent)
+static bool vinet_conv_may_split(const VinetConvDesc* d, bool query) {
+  return g_vinet_opt_splitk && d->dtype == VINET_BF16 && !d->stats && !d->accumulate && (query || d->splitk_ws != nullptr);
+}
+
 // Largest BN whose padded width is within 25% of the best achievable padding;
 // then shrink BM while the grid would leave most of the 256 CUs idle.
-ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks) {
+ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks, bool may_split) {
   if (mode == VINET_CONV_STEM) return dtype == VINET_BF16 ? ConvTile{4, 4, 4, 1} : ConvTile{2, 4, 4, 1};
   static const int nts[6] = {8, 6, 4, 3, 2, 1};
   int best_pad = 1 << 30;
@@ -41,6 +49,13 @@ ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks) 
     if (pad * 4 <= best_pad * 5) { nt = nts[i]; break; }
   }
   if (vn_f32_storage(dtype)) return ConvTile{2, nt, 4, 1};  // BM = 128
+  // long K loops on grids far below the chip (batch-1 decoder convs) whose caller lends split-K scratch: split-K supplies the
+  // workgroups, so the tile can be the large one (fewer LDS bytes per MFMA, and 128 x 192 covers N = 192 without padding it
+  // to 256): batch-1 replay 644 -> 668 fps, batch 2 959 -> 980
+  if (may_split && g_vinet_opt_sk_tile && kchunks >= 96 && M >= 1024 && ((M + 127) / 128) * ((N + 127) / 128) < 256) {
+    if ((g_vinet_opt_sk_tile & 1) && N % 192 == 0) return ConvTile{4, 6, 2, 2};
+    if ((g_vinet_opt_sk_tile & 2) && N >= 128) return ConvTile{4, 4, 2, 2};
+  }
   ConvTile t{4, nt, 4, 1};                               // BM = 256
   if (g_vinet_opt_n64_tile && nt == 4) return g_vinet_opt_n64_tile == 1 ? ConvTile{4, 2, 2, 2} : ConvTile{2, 2, 2, 2};   // tuning
   // 64-wide outputs with a short K loop (the stem, its 7x1x1 partner and their dgrads: 7-16 K steps at
@@ -115,7 +130,7 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   a.epi_rows = g_vinet_opt_epi_rows;
   const int oeb = a.out_f32 ? 4 : 2;
   a.vec_ok = (a.N % 4 == 0) && (a.ldy % 4 == 0) && (a.sBy % 4 == 0) && ((((uintptr_t)d->y.ptr) % (4 * oeb)) == 0);
-  t = vinet_pick_conv_tile(d->dtype, d->mode, M, a.N, (long)d->ntaps * (d->Kp / 32));
+  t = vinet_pick_conv_tile(d->dtype, d->mode, M, a.N, (long)d->ntaps * (d->Kp / 32), vinet_conv_may_split(d, false));
   a.perm_P = a.perm_T = 0;
   a.dPT = a.dPermT = make_fastdiv(1);
   if (g_vinet_opt_tperm && d->dtype == VINET_BF16 && d->mode == VINET_CONV_GENERIC && t.BM() == 256 && d->oT > 1 &&
@@ -174,7 +189,7 @@ extern "C" int vinet_conv3d_tile_m(const VinetConvDesc* d) {
   if (vinet_conv_use_ts(d) || vinet_conv_use_hs(d)) return 64;
   if (use_ht(d) || use_pp(d)) return 256;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
-  return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32)).BM();
+  return vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32), vinet_conv_may_split(d, false)).BM();
 }
 
 /* rows of the [rows][2][N] statistics table this problem's launch fills (one per M tile; the halo-tile kernel's tiles
@@ -261,6 +276,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "ht_pre")) { g_vinet_opt_ht_pre = value; return 0; }
   if (name && !strcmp(name, "ht_t_minhw")) { g_vinet_opt_ht_t_minhw = value; return 0; }
   if (name && !strcmp(name, "splitk")) { g_vinet_opt_splitk = value; return 0; }
+  if (name && !strcmp(name, "sk_tile")) { g_vinet_opt_sk_tile = value; return 0; }
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
   if (name && !strcmp(name, "wgrad_dma")) { g_vinet_opt_wgrad_dma = value; return 0; }
@@ -427,13 +443,14 @@ static bool use_ht(const VinetConvDesc* d) {
 
 // ---- split-K for grids that cannot fill the chip (batch-1 inference) ---------------------------
 int g_vinet_opt_splitk = 1;     // 0 = off; n >= 2 = tuning: minimum K chunks (of 32) per split
+int g_vinet_opt_sk_tile = 3;    // bit 0: 128 x 192 tiles, bit 1: 128 x 128 tiles for long-K small-grid convs (vinet_pick_conv_tile)
 struct SplitK { int splits, per; long bytes; };
-static SplitK splitk_plan(const VinetConvDesc* d) {
+static SplitK splitk_plan(const VinetConvDesc* d, bool query) {
   SplitK p{1, 0, 0};
   if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || use_ht(d) || use_pw(d) || vinet_conv_use_ts(d) || vinet_conv_use_hs(d) || d->stats || d->accumulate) return p;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const int nchunks = d->ntaps * (d->Kp / 32);
-  const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, nchunks);
+  const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, nchunks, vinet_conv_may_split(d, query));
   const long tiles = vn_div_up(M, t.BM()) * vn_div_up(d->y.C, t.BN());
   const int min_per = g_vinet_opt_splitk >= 2 ? g_vinet_opt_splitk : 6;   // measured flat between 3 and 8 (batch-1 graph replay)
   // workgroup slots of the chip for this tile shape: 3 stages of (BM + BN) rows x 64 B in 160 KB of LDS, 4 at most
@@ -454,7 +471,7 @@ static SplitK splitk_plan(const VinetConvDesc* d) {
 
 extern "C" int64_t vinet_conv3d_splitk_bytes(const VinetConvDesc* d) {
   if (!d) return 0;
-  return splitk_plan(d).bytes;
+  return splitk_plan(d, true).bytes;
 }
 
 // y = act(scale * sum_s ws[s][m][n] + shift) with the placement of the conv epilogue
@@ -483,7 +500,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs 
 extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32_t n) {
   if (!d || !buf || n <= 0) return -1;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
-  const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32));
+  const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, (long)d->ntaps * (d->Kp / 32), vinet_conv_may_split(d, false));
   if (d->tline == 3) snprintf(buf, n, vinet_conv_use_tsd(d) ? "conv_tsd_kernel" : "(unsupported)");
   else if (vinet_conv_use_hs(d)) snprintf(buf, n, d->dtype == VINET_F32S ? "conv_hs3_kernel" : "conv_hs_kernel");
   else if (vinet_conv_use_ts(d)) snprintf(buf, n, d->dtype == VINET_F32S ? "conv_ts3_kernel<%s>" : "conv_ts_kernel<%s>", d->pre.scale ? "pre" : "plain");
@@ -558,7 +575,7 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
     return vinet_launch_conv_pp_bf16(bn, a, (hipStream_t)stream);
   }
   if (use_dma(d)) {
-    const SplitK sp = splitk_plan(d);
+    const SplitK sp = splitk_plan(d, false);
     if (sp.splits > 1 && d->splitk_ws && d->splitk_ws_bytes >= sp.bytes) {
       a.splits = sp.splits; a.chunks_per_split = sp.per; a.ws = d->splitk_ws;
       rc = vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);

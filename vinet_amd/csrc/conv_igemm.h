@@ -705,7 +705,7 @@ struct ConvTile { int MT, NT, WM, WN; int BM() const { return 16 * MT * WM; } in
 
 // Tile choice is a pure function of (dtype, mode, M, N) so callers can size the
 // statistics workspace (vinet_conv3d_tile_m).
-ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks);
+ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks, bool may_split = false);
 int vinet_launch_conv_bf16(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s);
 int vinet_launch_conv_f32(const ConvTile& t, int mode, const ConvArgs& a, hipStream_t s, bool split = false);
 int vinet_launch_conv_dma_bf16(const ConvTile& t, const ConvArgs& a, hipStream_t s);

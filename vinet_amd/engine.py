@@ -59,7 +59,10 @@ _SIDE_STREAMS = {}
 # (entry -> branch 1 on the caller's stream, branch 2 on one, pool -> branch 3 on the other) and joins at the concat:
 # 3 kernels on the stage's critical path instead of 7.  Under capture the fork / join events become graph edges (fan-out
 # <= 3: below the 6-8 outgoing edges that the runtime's replay mishandles, profiles/r4_capture_fanout.txt).  0 = never.
+# Only under capture by default: an eager batch-1 forward is bound by the host's launch rate, and the fork / join events
+# are more host work (307 -> 263 fps eager; 586 -> 645 fps replayed).  VINET_BRANCH_STREAMS_EAGER=1 forks in eager too.
 BRANCH_STREAMS_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_VOX", "65536"))
+BRANCH_STREAMS_EAGER = os.environ.get("VINET_BRANCH_STREAMS_EAGER", "0") != "0"
 
 
 def set_default_dtype(name):
@@ -347,6 +350,8 @@ class Ctx:
     def branch_streams(self, nvox):
         """the two extra streams an Inception stage forks its branches over in small-batch inference (None: run in order)"""
         if self.training or self.recording or self.device.type != "cuda" or nvox > BRANCH_STREAMS_VOX:
+            return None
+        if not BRANCH_STREAMS_EAGER and not torch.cuda.is_current_stream_capturing():
             return None
         out = []
         for k in ("b1", "b2"):
