@@ -56,6 +56,8 @@ ConvTile vinet_pick_conv_tile(int dtype, int mode, long M, int N, long kchunks, 
     if ((g_vinet_opt_sk_tile & 1) && N % 192 == 0) return ConvTile{4, 6, 2, 2};
     if ((g_vinet_opt_sk_tile & 2) && N >= 128) return ConvTile{4, 4, 2, 2};
   }
+  if (may_split && (g_vinet_opt_sk_tile & 12) && kchunks >= 96 && M >= 4096 && N > 32 && N <= 64 && (M + 63) / 64 < 512)
+    return (g_vinet_opt_sk_tile & 8) ? ConvTile{4, 4, 4, 1} : ConvTile{4, 2, 2, 2};      // 64-wide: 256 x 64 / 128 x 64 instead of 64 x 64
   ConvTile t{4, nt, 4, 1};                               // BM = 256
   if (g_vinet_opt_n64_tile && nt == 4) return g_vinet_opt_n64_tile == 1 ? ConvTile{4, 2, 2, 2} : ConvTile{2, 2, 2, 2};   // tuning
   // 64-wide outputs with a short K loop (the stem, its 7x1x1 partner and their dgrads: 7-16 K steps at
@@ -443,7 +445,7 @@ static bool use_ht(const VinetConvDesc* d) {
 
 // ---- split-K for grids that cannot fill the chip (batch-1 inference) ---------------------------
 int g_vinet_opt_splitk = 1;     // 0 = off; n >= 2 = tuning: minimum K chunks (of 32) per split
-int g_vinet_opt_sk_tile = 3;    // bit 0: 128 x 192 tiles, bit 1: 128 x 128 tiles for long-K small-grid convs (vinet_pick_conv_tile)
+int g_vinet_opt_sk_tile = 7;    // bit 0: 128 x 192 tiles, bit 1: 128 x 128 tiles for long-K small-grid convs (vinet_pick_conv_tile)
 struct SplitK { int splits, per; long bytes; };
 static SplitK splitk_plan(const VinetConvDesc* d, bool query) {
   SplitK p{1, 0, 0};
@@ -452,7 +454,9 @@ static SplitK splitk_plan(const VinetConvDesc* d, bool query) {
   const int nchunks = d->ntaps * (d->Kp / 32);
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, nchunks, vinet_conv_may_split(d, query));
   const long tiles = vn_div_up(M, t.BM()) * vn_div_up(d->y.C, t.BN());
-  const int min_per = g_vinet_opt_splitk >= 2 ? g_vinet_opt_splitk : 6;   // measured flat between 3 and 8 (batch-1 graph replay)
+  // batch-1 graph replay with the Inception branches side by side (three convs share the chip): 6: 663 fps, 8: 679, 12: 694,
+  // 16: 702, 20: 688 (batch 4: 1265 / 1302 / 1313 / 1333 / 1348)
+  const int min_per = g_vinet_opt_splitk >= 2 ? g_vinet_opt_splitk : 16;
   // workgroup slots of the chip for this tile shape: 3 stages of (BM + BN) rows x 64 B in 160 KB of LDS, 4 at most
   const long smem = 3L * (t.BM() + t.BN()) * 64 + (d->pre.scale ? 2L * d->Kp * 4 : 0);
   long per_cu = (160 * 1024) / smem;
@@ -495,6 +499,43 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs 
   }
   if (a.out_f32) ((float*)a.y)[off] = v;
   else ((bf16_t*)a.y)[off] = f2bf(v);
+}
+
+// the same, four consecutive columns per thread (N % 4 == 0, 16-byte aligned rows of y): one 16-byte load per slab and one
+// 8- / 16-byte store instead of four of each; the sums are formed in the same order (same bits)
+__global__ __launch_bounds__(256) void conv_splitk_finish4_kernel(const ConvArgs a) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = a.N >> 2;
+  if (e >= (long)a.M * n4) return;
+  const int m = (int)(e / n4), n = (int)(e - (long)m * n4) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.splits; ++s) {
+    const float4 q = *(const float4*)(a.ws + ((long)s * a.M + m) * a.N + n);
+    v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool nok = n + r < a.Nw;
+    v[r] = fmaf(v[r], (a.out_scale && nok) ? a.out_scale[n + r] : 1.f, (a.out_shift && nok) ? a.out_shift[n + r] : 0.f);
+    if (a.act == VINET_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+    else if (a.act == VINET_ACT_SIGMOID) v[r] = 1.f / (1.f + __expf(-v[r]));
+  }
+  long off;
+  if (a.y_linear) {
+    off = (long)m * a.ldy + n;
+  } else {
+    int b, to, ho, wo;
+    decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
+    off = (long)b * a.sBy + ((long)((to * a.omT + a.ooT) * a.yH + (ho * a.omH + a.ooH)) * a.yW + (wo * a.omW + a.ooW)) * (long)a.ldy + n;
+  }
+  if (a.out_f32) {
+    *(float4*)((float*)a.y + off) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    union { bf16_t h[4]; uint2 u; } o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.h[r] = f2bf(v[r]);
+    *(uint2*)((bf16_t*)a.y + off) = o.u;
+  }
 }
 
 extern "C" int vinet_conv3d_kernel_name(const VinetConvDesc* d, char* buf, int32_t n) {
@@ -581,7 +622,10 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
       rc = vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);
       if (rc) return rc;
       const long n = (long)a.M * a.N;
-      hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)vn_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+      const int esz = a.out_f32 ? 4 : 2;
+      const bool vec4 = (a.N & 3) == 0 && (a.ldy & 3) == 0 && ((uintptr_t)a.y % 16) == 0 && (((long)a.sBy * esz) % 16) == 0;
+      if (vec4) hipLaunchKernelGGL(conv_splitk_finish4_kernel, dim3((unsigned)vn_div_up(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)vn_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
       return vn_launch_status("conv_splitk_finish");
     }
     return vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);

@@ -63,6 +63,11 @@ _SIDE_STREAMS = {}
 # are more host work (307 -> 263 fps eager; 586 -> 645 fps replayed).  VINET_BRANCH_STREAMS_EAGER=1 forks in eager too.
 BRANCH_STREAMS_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_VOX", "65536"))
 BRANCH_STREAMS_EAGER = os.environ.get("VINET_BRANCH_STREAMS_EAGER", "0") != "0"
+# Which branch leaves the capturing stream: the replayed graph runs the entry conv and the FORKED stream's first kernel
+# back to back on one hardware queue and pays ~12 us of cross-queue latency to start the branch that stayed on the capturing
+# stream (rocprofv3 trace of a replay: profiles/r4_trace_infer_b1.txt), so the longer chain (branch 1: the wide 3x3 pair) is
+# the one to fork: 690 -> 737 fps at batch 1, 1033 -> 1076 at batch 2.  0 = branch 2 forks instead.
+BRANCH_STREAMS_SWAP = os.environ.get("VINET_BRANCH_STREAMS_SWAP", "1") != "0"
 
 
 def set_default_dtype(name):

@@ -198,9 +198,14 @@ class _Mixed(_Block):
             mods, jp, jbn = self._entry()
             E.conv_forward(ctx, jp, x, bn=jbn, act=L.ACT_RELU, dst=entry)
             fork[0].wait_stream(main)
-            with ctx.on_stream(fork[0]):
+            if E.BRANCH_STREAMS_SWAP:
+                with ctx.on_stream(fork[0]):
+                    self.branch1[1]._fwd(ctx, r1, cat.sub_chan(o1, o2))
                 self.branch2[1]._fwd(ctx, r2, cat.sub_chan(o2, o3))
-            self.branch1[1]._fwd(ctx, r1, cat.sub_chan(o1, o2))
+            else:
+                with ctx.on_stream(fork[0]):
+                    self.branch2[1]._fwd(ctx, r2, cat.sub_chan(o2, o3))
+                self.branch1[1]._fwd(ctx, r1, cat.sub_chan(o1, o2))
             main.wait_stream(fork[0])
             main.wait_stream(fork[1])
             return cat
