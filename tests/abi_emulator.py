@@ -178,12 +178,14 @@ class AbiEmulator:
         if (d.tline == 1 and d.dtype == BF16 and d.out_dtype == BF16 and d.mode == 0 and d.x.C == 64 and N == 64 and d.Kp == 64 and
                 2 <= d.ntaps <= 7 and d.sT in (1, 2) and d.ntaps >= d.sT and (d.sH, d.sW, d.omH, d.omW, d.ooH, d.ooW) == (1, 1, 1, 1, 0, 0) and
                 (d.x.H, d.x.W, d.y.H, d.y.W) == (d.oH, d.oW, d.oH, d.oW) and HW % 64 == 0 and 0 <= d.tpad < d.ntaps and
-                d.x.B * (HW // 64) >= 2048 and d.oT >= 4 and not (d.pre.relu and not d.pre.scale)):
+                d.oT >= 4 and d.x.B * (HW // 64) * max(1, min(-(-512 // (d.x.B * (HW // 64))), d.oT // 4)) >= 384 and
+                not (d.pre.relu and not d.pre.scale)):       # (frame segments: vinet_conv_ts_segments)
             return 64
         # conv_hs.hip::vinet_conv_use_hs -- the row-streaming strip kernel of the folded RGB stem
         if (d.tline == 2 and d.dtype == BF16 and d.out_dtype == BF16 and d.mode == 0 and d.x.C == 32 and d.x.ld == 8 and d.Kp == 32 and
                 d.ntaps == 7 and (d.sT, d.sH, d.sW) == (1, 2, 1) and N == 64 and d.oW % 64 == 0 and not d.pre.scale and not d.pre.relu and
-                not d.accumulate and d.x.B * d.oT * (d.oW // 64) >= 512 and d.oH >= 8):
+                not d.accumulate and d.oH >= 8 and
+                d.x.B * d.oT * (d.oW // 64) * max(1, min(-(-768 // (d.x.B * d.oT * (d.oW // 64))), d.oH // 7)) >= 384):   # (row segments)
             return 64
         # conv_api.hip::use_pp -- the 256x256x64 kernel takes large plain bf16 convs
         if d.dtype == BF16 and d.mode == 0 and not d.pre.scale and not d.pre.relu and d.ntaps <= 64:

@@ -412,6 +412,11 @@ CONV_TS_CASES = [
     ("ts_fwd_k2s2", (1, 8, 8, 8), 64, 64, (2, 1, 1), (2, 1, 1), (0, 0, 0), dict(act=1)),
     ("ts_fwd_long", (1, 32, 8, 24), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), dict(pre=True, stats=True)),
     ("ts_acc", (2, 6, 8, 8), 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(accumulate=True)),
+    # without statistics the frames of a patch split into segments (small batches): 4 x 4 output frames; 6 + 5 with accumulation;
+    # a stride phase's placement (every second frame of y)
+    ("ts_segs_k7s2", (1, 32, 8, 8), 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), dict(epi=True, act=1)),
+    ("ts_segs_acc", (1, 11, 8, 8), 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(accumulate=True)),
+    ("ts_segs_phase", (1, 10, 8, 8), 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(om=(2, 1))),
 ]
 
 
@@ -700,7 +705,7 @@ def test_conv3d_stem_mode(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("hw", [(18, 22), (17, 23), (32, 48), (20, 128), (16, 256)])
+@pytest.mark.parametrize("hw", [(18, 22), (17, 23), (32, 48), (20, 128), (16, 256), (60, 128)])     # (60, 128): 4 row segments, the last ragged
 def test_stem_folded(dt, hw):
     """padded import + overlapped [.., (W+8)/2, C=32] ld=8 view: the stem as a generic 7-tap conv,
     forward and weight gradient, vs the emulator and (fp32) torch's conv3d"""

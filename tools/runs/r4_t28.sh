@@ -1,0 +1,12 @@
+export TMPDIR=/tmp; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x -k "tstream or stem" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_model.py -q -m gpu -k "branch_streams or graphed or harness or golden or e2e" 2>&1 | tail -2
+for r in 1 2; do
+for o in "conv_ts_segs=0" "conv_ts_segs=1"; do
+for b in 1 2 4; do
+  VINET_OPT="$o" python bench.py --mode infer --batch $b --graph --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('graph $o batch=$b', round(d['value'],1), round(d['ms_per_step'],3))"
+done; done; done
+for o in "conv_ts_segs=0,conv_hs_segs=0" "conv_ts_segs=1,conv_hs_segs=1"; do
+for b in 2 4; do
+  VINET_OPT="$o" python bench.py --batch $b --steps 20 --warmup 3 --no-sweep --no-extras --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train $o batch=$b', round(d['value'],1), round(d['ms_per_step'],3))"
+done; done

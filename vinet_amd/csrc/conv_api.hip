@@ -168,13 +168,17 @@ static HtShape ht_shape(const VinetConvDesc* d);
 extern int g_vinet_opt_ht, g_vinet_opt_ht3, g_vinet_opt_ht32, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
 bool vinet_conv_use_ts(const VinetConvDesc* d);
 int vinet_conv_ts_positions(const VinetConvDesc* d);
+int vinet_conv_ts_segments(const VinetConvDesc* d);
+int vinet_conv_hs_segments(const VinetConvDesc* d);
 bool vinet_conv_use_hs(const VinetConvDesc* d);
 bool vinet_conv_use_tsd(const VinetConvDesc* d);
 int vinet_launch_conv_tsd(const VinetConvDesc* d, hipStream_t s);
 int vinet_launch_conv_hs(const VinetConvDesc* d, hipStream_t s);
 extern int g_vinet_opt_conv_hs;
+extern int g_vinet_opt_conv_hs_segs;
 int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s);
 extern int g_vinet_opt_conv_ts;
+extern int g_vinet_opt_conv_ts_segs;
 extern int g_vinet_opt_wgrad_hs;
 extern int g_vinet_opt_wgrad_rs;
 extern int g_vinet_opt_wgrad_rs4;
@@ -201,8 +205,8 @@ extern "C" int vinet_conv3d_stats_rows(const VinetConvDesc* d) {
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   // the strip / frame-streaming kernels of the stem keep their partial sums in registers over a whole item (a 64-wide strip of
   // one frame, 64 positions of one clip) and write ONE row per item
-  if (vinet_conv_use_hs(d)) return (int)((long)d->x.B * d->oT * (d->oW / 64));
-  if (vinet_conv_use_ts(d)) return (int)((long)d->x.B * (((long)d->oH * d->oW) / vinet_conv_ts_positions(d)));
+  if (vinet_conv_use_hs(d)) return (int)((long)d->x.B * d->oT * (d->oW / 64) * vinet_conv_hs_segments(d));
+  if (vinet_conv_use_ts(d)) return (int)((long)d->x.B * (((long)d->oH * d->oW) / vinet_conv_ts_positions(d)) * vinet_conv_ts_segments(d));
   if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_pw(d)) return pw_shape(d).gm;   // one row per workgroup (4 waves x up to 16 tiles of 64 rows)
   if (!vinet_conv_use_ts(d) && !vinet_conv_use_hs(d) && use_ht(d)) {
     const HtShape h = ht_shape(d);
@@ -279,6 +283,8 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "ht_t_minhw")) { g_vinet_opt_ht_t_minhw = value; return 0; }
   if (name && !strcmp(name, "splitk")) { g_vinet_opt_splitk = value; return 0; }
   if (name && !strcmp(name, "sk_tile")) { g_vinet_opt_sk_tile = value; return 0; }
+  if (name && !strcmp(name, "conv_hs_segs")) { g_vinet_opt_conv_hs_segs = value; return 0; }
+  if (name && !strcmp(name, "conv_ts_segs")) { g_vinet_opt_conv_ts_segs = value; return 0; }
   if (name && !strcmp(name, "wgrad_pp")) { g_vinet_opt_wgrad_pp = value; return 0; }
   if (name && !strcmp(name, "wgrad_tr")) { g_vinet_opt_wgrad_tr = value; return 0; }
   if (name && !strcmp(name, "wgrad_dma")) { g_vinet_opt_wgrad_dma = value; return 0; }

@@ -25,6 +25,10 @@ struct ConvHsArgs {
   int oH, oW, ldy, act;
   int items, strips;
   FastDiv dStrips, dT;
+  // row segments (conv_hs_kernel, small batches): an item is rows [seg * seg_rows, ...) of a strip, so that
+  // a batch-1 clip (96 strips) still fills the chip; 1 = whole strips
+  int segs, seg_rows;
+  FastDiv dSegs;
 };
 
 // MFMAs (see conv_ts.hip): B (the weights) is read from the accumulator file -- the 112 weight registers do not fit in
@@ -98,8 +102,11 @@ __global__ __launch_bounds__(256, 2) void conv_hs_kernel(const ConvHsArgs a) {
   const bool sigm = a.act == VINET_ACT_SIGMOID;
 
   for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
-    const int bt = (int)fdiv((uint32_t)item, a.dStrips);
-    const int strip = item - bt * a.strips;
+    const int sitem = a.segs > 1 ? (int)fdiv((uint32_t)item, a.dSegs) : item;      // (strip item, row segment)
+    const int h0 = (item - sitem * a.segs) * a.seg_rows;
+    const int h1 = h0 + a.seg_rows < a.oH ? h0 + a.seg_rows : a.oH;
+    const int bt = (int)fdiv((uint32_t)sitem, a.dStrips);
+    const int strip = sitem - bt * a.strips;
     const int wo0 = strip * 64;
     const int b = (int)fdiv((uint32_t)bt, a.dT);
     const int t = bt - b * a.T;
@@ -108,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void conv_hs_kernel(const ConvHsArgs a) {
     char* yb = a.y + ((long)b * a.sBy + ((long)t * a.oH * a.oW + wo0 + l_row) * (long)a.ldy + l_chunk * 8) * 2;
     const long y_rowb = (long)a.oW * a.ldy * 2, y_r32 = 32L * a.ldy * 2;
 
-    for (int q = tid; q < 7 * NP; q += 256) {
+    for (int q = tid; q < 7 * NP; q += 256) {      // input rows 2 h0 .. 2 h0 + 6 into their ring slots (row % 7)
       const int h = q / NP, pc = q - h * NP;
-      *(uint4*)(ring + h * ROW + pc * 16) = *(const uint4*)(xrow0 + h * x_rowb + pc * 16);
+      *(uint4*)(ring + ((2 * h0 + h) % 7) * ROW + pc * 16) = *(const uint4*)(xrow0 + (2 * h0 + h) * x_rowb + pc * 16);
     }
     __syncthreads();
 
@@ -121,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void conv_hs_kernel(const ConvHsArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
 
-    for (int ho = 0; ho < a.oH; ++ho) {
-      const bool more = ho + 1 < a.oH;
+    for (int ho = h0; ho < h1; ++ho) {
+      const bool more = ho + 1 < h1;
       const int hn = more ? 2 * ho + 7 + x_r : 0;
       const uint4 nx = *(const uint4*)(xrow0 + hn * x_rowb + (xl ? x_p : 0) * 16);
 
@@ -363,6 +370,18 @@ __global__ __launch_bounds__(256, 2) void conv_hs3_kernel(const ConvHsArgs a) {
 }
 
 int g_vinet_opt_conv_hs = 1;   // 0 = off, 2 = force on every eligible shape (tests)
+int g_vinet_opt_conv_hs_segs = 1;   // row segments for launches without statistics (0 = whole strips only)
+
+// row segments per strip: enough items for one round of 768 workgroups, at least 7 output rows each (a segment re-reads 5 input
+// rows of its upper neighbour); 1 in the split form.  (Not a function of d->stats: the engine asks vinet_conv3d_stats_rows
+// before it has a statistics buffer to point at.)
+int vinet_conv_hs_segments(const VinetConvDesc* d) {
+  if (!g_vinet_opt_conv_hs_segs || d->dtype == VINET_F32S) return 1;
+  const long strips = (long)d->x.B * d->oT * (d->oW / 64);
+  long segs = (768 + strips - 1) / strips;
+  if (segs > d->oH / 7) segs = d->oH / 7;
+  return segs < 1 ? 1 : (int)segs;
+}
 
 // VinetConvDesc::tline == 2: the caller promises taps (0, kh, 0, slice kh), kh = 0..6 (the folded stem)
 bool vinet_conv_use_hs(const VinetConvDesc* d) {
@@ -377,6 +396,9 @@ bool vinet_conv_use_hs(const VinetConvDesc* d) {
                      ((uintptr_t)d->x.ptr % 16) == 0 && ((uintptr_t)d->y.ptr % 16) == 0;
   if (!shape) return false;
   if (g_vinet_opt_conv_hs >= 2) return true;
+  // a strip splits into row segments, so small batches fill the chip too: batch 1 = 96 strips x 8 segments of 14 rows (conv_dma's
+  // stem form: 66 us per clip whatever the batch)
+  if (!split && g_vinet_opt_conv_hs_segs && d->oH >= 8) return (long)d->x.B * d->oT * (d->oW / 64) * vinet_conv_hs_segments(d) >= 384;
   return (long)d->x.B * d->oT * (d->oW / 64) >= 512 && d->oH >= 8;      // (from 6 clips of 32 x 224 x 384 on: 8 clips 385 -> 402 clips/s with both strip kernels, profiles/r4_experiments.txt)
 }
 
@@ -388,7 +410,11 @@ int vinet_launch_conv_hs(const VinetConvDesc* d, hipStream_t s) {
   a.T = d->x.T; a.Hp = d->x.H; a.Wv = d->x.W; a.ldx = d->x.ld;
   a.oH = d->oH; a.oW = d->oW; a.ldy = d->y.ld; a.act = d->act;
   a.strips = a.oW / 64;
-  a.items = d->x.B * a.T * a.strips;
+  a.segs = vinet_conv_hs_segments(d);
+  a.seg_rows = (a.oH + a.segs - 1) / a.segs;
+  a.segs = (a.oH + a.seg_rows - 1) / a.seg_rows;
+  a.dSegs = make_fastdiv((uint32_t)a.segs);
+  a.items = d->x.B * a.T * a.strips * a.segs;
   a.dStrips = make_fastdiv((uint32_t)a.strips);
   a.dT = make_fastdiv((uint32_t)a.T);
   if (d->dtype == VINET_F32S) {

@@ -33,6 +33,10 @@ struct ConvTsArgs {
   int k, s, pad, omT, ooT, act, accumulate;
   int items, patches;
   FastDiv dPatches;
+  // frame segments (conv_ts_kernel, small batches): an item is output frames [seg * seg_frames, ...) of a
+  // 64-position patch, so that a batch-1 clip (336 patches) fills the chip; 1 = all frames
+  int segs, seg_frames;
+  FastDiv dSegs;
 };
 
 // MFMAs of this kernel: B (the weights) is read from the accumulator file -- the 112 weight registers do not fit in
@@ -143,17 +147,20 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
   const bool sigm = a.act == VINET_ACT_SIGMOID;
 
   for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
-    const int b = (int)fdiv((uint32_t)item, a.dPatches);
-    const int patch = item - b * a.patches;
+    const int pitem = a.segs > 1 ? (int)fdiv((uint32_t)item, a.dSegs) : item;      // (patch item, frame segment)
+    const int t0 = (item - pitem * a.segs) * a.seg_frames;
+    const int t1 = t0 + a.seg_frames < a.To ? t0 + a.seg_frames : a.To;
+    const int b = (int)fdiv((uint32_t)pitem, a.dPatches);
+    const int patch = pitem - b * a.patches;
     const int pos0 = patch * 64;
     const char* xb = a.x + ((long)b * a.sBx + (long)(pos0 + l_row) * a.ldx + l_chunk * 8) * 2;
     char* yb = a.y + ((long)b * a.sBy + (long)(pos0 + l_row) * a.ldy + l_chunk * 8) * 2;
     const long x_plane = (long)a.HW * a.ldx * 2, y_plane = (long)a.HW * a.ldy * 2;
     const long x_r32 = 32L * a.ldx * 2, y_r32 = 32L * a.ldy * 2;
 
-    // ---- prologue: the k frames of output frame 0 ----------------------------------------------------------
+    // ---- prologue: the k frames of the first output frame --------------------------------------------------
     for (int g = 0; g < k; ++g) {
-      const int p = g - a.pad;
+      const int p = t0 * s + g - a.pad;
       uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
       if ((unsigned)p < (unsigned)a.Ti) {
         v0 = xform(*(const uint4*)(xb + p * x_plane));
@@ -172,9 +179,9 @@ __global__ __launch_bounds__(256, 2) void conv_ts_kernel(const ConvTsArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ssum[nt][r] = 0.f; ssq[nt][r] = 0.f; }
 
-    for (int to = 0; to < a.To; ++to) {
+    for (int to = t0; to < t1; ++to) {
       // ---- loads of the next step's s new frames (named scalars, unconditional: see wgrad_ts.hip) ----------
-      const bool more = to + 1 < a.To;
+      const bool more = to + 1 < t1;
       const int pnew = (to + 1) * s - a.pad + k - s;
       const bool in0 = more && (unsigned)pnew < (unsigned)a.Ti;
       const bool in1 = more && s == 2 && (unsigned)(pnew + 1) < (unsigned)a.Ti;
@@ -483,6 +490,18 @@ __global__ __launch_bounds__(256, 2) void conv_ts3_kernel(const ConvTsArgs a) {
 
 int g_vinet_opt_conv_ts = 1;   // 0 = off, 2 = force on every eligible shape (tests)
 
+int g_vinet_opt_conv_ts_segs = 1;   // frame segments for launches without statistics (0 = whole patches only)
+// frame segments per patch: enough items for one round of 512 workgroups, at least 4 output frames each (a segment re-reads
+// k - s input frames of its predecessor); 1 in the split form.  (Not a function of d->stats: the engine asks
+// vinet_conv3d_stats_rows before it has a statistics buffer to point at.)
+int vinet_conv_ts_segments(const VinetConvDesc* d) {
+  if (!g_vinet_opt_conv_ts_segs || d->dtype == VINET_F32S) return 1;
+  const long patches = (long)d->x.B * (((long)d->oH * d->oW) / 64);
+  long segs = (512 + patches - 1) / patches;
+  if (segs > d->oT / 4) segs = d->oT / 4;
+  return segs < 1 ? 1 : (int)segs;
+}
+
 bool vinet_conv_use_ts(const VinetConvDesc* d) {
   const bool split = d->dtype == VINET_F32S && d->out_dtype == VINET_F32;       // conv_ts3_kernel: fp32 tensors, hi / lo weight planes
   if (!g_vinet_opt_conv_ts || d->tline != 1 || !((d->dtype == VINET_BF16 && d->out_dtype == VINET_BF16) || split) || d->mode != VINET_CONV_GENERIC) return false;
@@ -497,6 +516,9 @@ bool vinet_conv_use_ts(const VinetConvDesc* d) {
                      ((uintptr_t)d->x.ptr % 16) == 0 && ((uintptr_t)d->y.ptr % 16) == 0;
   if (!shape) return false;
   if (g_vinet_opt_conv_ts >= 2) return true;
+  // the frames of a patch split into segments, so small batches fill the chip: batch 1 = 336 patches x 2 segments of 8 output
+  // frames (conv_dma on this layer: 66 us per clip whatever the batch)
+  if (!split && g_vinet_opt_conv_ts_segs && d->oT >= 4) return (long)d->x.B * (HW / 64) * vinet_conv_ts_segments(d) >= 384;
   return (long)d->x.B * (HW / 64) >= 2048 && d->oT >= 4;
 }
 // positions per workgroup = per statistics row
@@ -512,6 +534,7 @@ int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s) {
   VN_CHECK_ARG((d->oT - 1) * d->omT + d->ooT < d->y.T && d->ooT >= 0 && d->omT > 0, "conv_ts: output placement outside y");
   if (d->dtype == VINET_F32S) {
     a.patches = a.HW / 32;
+    a.segs = 1; a.seg_frames = a.To; a.dSegs = make_fastdiv(1u);
     a.items = d->x.B * a.patches;
     a.dPatches = make_fastdiv((uint32_t)a.patches);
     const int smem3 = 7 * 2 * 32 * 128 + 32 * 256;
@@ -531,7 +554,11 @@ int vinet_launch_conv_ts(const VinetConvDesc* d, hipStream_t s) {
     return vn_launch_status("conv_ts3");
   }
   a.patches = a.HW / 64;
-  a.items = d->x.B * a.patches;
+  a.segs = vinet_conv_ts_segments(d);
+  a.seg_frames = (a.To + a.segs - 1) / a.segs;
+  a.segs = (a.To + a.seg_frames - 1) / a.seg_frames;
+  a.dSegs = make_fastdiv((uint32_t)a.segs);
+  a.items = d->x.B * a.patches * a.segs;
   a.dPatches = make_fastdiv((uint32_t)a.patches);
   const int smem = 8 * 64 * 64 * 2 + 2 * 64 * 2 * 4;
   void (*const kern[2][2])(const ConvTsArgs) = {{conv_ts_kernel<false, false>, conv_ts_kernel<false, true>},
