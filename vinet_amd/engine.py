@@ -45,6 +45,12 @@ WGRAD_SIDE_STREAM = True
 # without a second stream they are alone on the GPU and get all of it
 WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "208"))
 TAIL_WGRAD_FULL = os.environ.get("VINET_TAIL_WGRAD_FULL", "1") != "0"
+# weight-gradient jobs per join with the main stream (1 = a join per job), eager / under capture.  Eager: 1 .. 16 within noise
+# at 8 and 32 clips (432 / 608 clips/s).  Replayed step: 1: 381 / 546, 4: 396 / 566, 8: 402 / 574, 16: 410 / 583, 32: 399 / 578,
+# 64 (= all weight gradients behind the backward pass): 367 / 549 -- every fork costs the replay ~12 us on the main stream's
+# next kernel (profiles/r4_experiments.txt).
+WGRAD_GROUP = int(os.environ.get("VINET_WGRAD_GROUP", "1"))
+WGRAD_GROUP_CAPTURE = int(os.environ.get("VINET_WGRAD_GROUP_CAPTURE", "16"))
 # cap of the decoder's (BatchNorm-less, deferred) weight gradients, which run beside the backward of the low-resolution encoder stages
 WGRAD_CUS_DEC = int(os.environ.get("VINET_WGRAD_CUS_DEC", str(WGRAD_CUS)))
 # every packed weight gradient of a backward pass unpacked by ONE launch at its end (0 = one vinet_unpack_wgrad per conv).  Not
@@ -1377,8 +1383,15 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         # flush -- a fan-out of redundant graph edges that ROCm 7.2 replays wrongly, see Ctx.flush_deferred -- not from the
         # deferral; with one join per batch the captured step follows the eager trajectory.)
         defer = DEFER_DECODER_WGRAD_F32S if ctx.cdt == F32S else DEFER_DECODER_WGRAD
+        group = WGRAD_GROUP_CAPTURE if ctx.capturing else WGRAD_GROUP
         if defer and bn is None and ctx.side_stream() is not None and (not ctx.capturing or os.environ.get("VINET_DBG_DEFER_IN_CAPTURE", "1") != "0"):
             ctx._deferred.append(wgrad_job)
+        elif group > 1 and ctx.side_stream() is not None:
+            # weight-gradient jobs leave for their stream `group` at a time behind one join (fewer fork points: every join is an
+            # event pair on the host and, in a replayed graph, ~12 us of cross-queue latency on the main stream's next kernel)
+            ctx._deferred.append(wgrad_job)
+            if len(ctx._deferred) >= group:
+                ctx.flush_deferred()
         else:
             ctx.flush_deferred()
             wgrad_job()
