@@ -870,6 +870,45 @@ def test_stem_bn_backward_statistics_leave_with_the_temporal_data_gradient():
     _note("stem_bn_bwd_stats_fused", dict(reduce_launches=counts, worst_rel_of_the_three=worst))
 
 
+def test_training_forward_branch_streams_do_not_change_the_step(monkeypatch):
+    """Small batches: the training forward forks the branches of every Inception stage over two more streams
+    (engine.BRANCH_STREAMS_TRAIN_VOX).  A schedule, not arithmetic: loss, gradients (up to the fp32 atomics' order) and the
+    BatchNorm running statistics equal the one-stream forward's, over several steps (a missing join shows as a stale branch)."""
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    from vinet_amd import optim as VO
+    E.set_default_dtype("bf16")
+    B, T, H, W = 2, 16, 64, 96
+    x = synth.clip(B, T, H, W, 11).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
+    gt = synth.gt_map(B, H, W, 11).to(DEV)
+    res = {}
+    for name, vox in (("one_stream", 0), ("forked", 1 << 30)):
+        monkeypatch.setattr(E, "BRANCH_STREAMS_TRAIN_VOX", vox)
+        m = VM.VideoSaliencyModel(num_clips=T)
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), 11))
+        m = m.to(DEV).train()
+        opt = VO.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+        losses = []
+        E.LAUNCH_LOG = []
+        try:
+            for _ in range(3):
+                opt.zero_grad()
+                l = VL.kldiv(m(x), gt)
+                l.backward()
+                losses.append(float(l))
+            streams = {a[1] for a in E.LAUNCH_LOG if a[0] == "vinet_conv3d"}
+        finally:
+            E.LAUNCH_LOG = None
+        torch.cuda.synchronize()
+        rm = torch.cat([b.detach().float().flatten() for n_, b in m.named_buffers() if n_.endswith("running_mean")])
+        res[name] = (losses, opt.flat_g.clone(), rm, len(streams))
+    assert res["forked"][3] >= 3 and res["one_stream"][3] == 1, (res["forked"][3], res["one_stream"][3])
+    assert res["forked"][0] == res["one_stream"][0], (res["forked"][0], res["one_stream"][0])
+    rel = float((res["forked"][1] - res["one_stream"][1]).norm() / res["one_stream"][1].norm())
+    assert rel < 1e-5, "gradients differ from the one-stream forward by %.3e" % rel
+    assert torch.equal(res["forked"][2], res["one_stream"][2])
+
+
 def test_weight_gradient_stream_does_not_change_the_gradients():
     """The second HIP stream (weight gradients beside the data-gradient chain, decoder jobs deferred to the encoder's backward,
     one multi-job unpack at the end) is a schedule, not arithmetic: the gradients must equal those of the one-stream, per-conv

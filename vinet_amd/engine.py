@@ -68,6 +68,11 @@ _SIDE_STREAMS = {}
 # Only under capture by default: an eager batch-1 forward is bound by the host's launch rate, and the fork / join events
 # are more host work (307 -> 263 fps eager; 586 -> 645 fps replayed).  VINET_BRANCH_STREAMS_EAGER=1 forks in eager too.
 BRANCH_STREAMS_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_VOX", "65536"))
+# The training forward forks the same way below this many voxels, at small batches only (same-box A/B, eager / replayed clips/s:
+# 4 clips 278 / 287 -> 293 / 302, 8: 434 / 411 -> 442 / 425, 16: 535 / 508 -> 539 / 516, 32: 615 / 587 -> 616 / 592; at 192 clips
+# the last two stages would qualify and the step loses 0.15 %, hence the batch bound).
+BRANCH_STREAMS_TRAIN_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_TRAIN_VOX", "200000"))
+BRANCH_STREAMS_TRAIN_BATCH = int(os.environ.get("VINET_BRANCH_STREAMS_TRAIN_BATCH", "32"))
 BRANCH_STREAMS_EAGER = os.environ.get("VINET_BRANCH_STREAMS_EAGER", "0") != "0"
 # Which branch leaves the capturing stream: the replayed graph runs the entry conv and the FORKED stream's first kernel
 # back to back on one hardware queue and pays ~12 us of cross-queue latency to start the branch that stayed on the capturing
@@ -358,12 +363,20 @@ class Ctx:
             st = _SIDE_STREAMS[(self.device.index, k)] = torch.cuda.Stream(self.device)
         return st
 
-    def branch_streams(self, nvox):
+    def branch_streams(self, nvox, batch=0):
         """the two extra streams an Inception stage forks its branches over in small-batch inference (None: run in order)"""
-        if self.training or self.recording or self.device.type != "cuda" or nvox > BRANCH_STREAMS_VOX:
+        if self.device.type != "cuda":
             return None
-        if not BRANCH_STREAMS_EAGER and not torch.cuda.is_current_stream_capturing():
-            return None
+        if self.training or self.recording:
+            # the training forward (its tape order is the Python order either way; backward runs on the main stream, behind the
+            # joins): GPU-bound from 4 clips on, so eager forks too
+            if nvox > BRANCH_STREAMS_TRAIN_VOX or batch > BRANCH_STREAMS_TRAIN_BATCH:
+                return None
+        else:
+            if nvox > BRANCH_STREAMS_VOX:
+                return None
+            if not BRANCH_STREAMS_EAGER and not torch.cuda.is_current_stream_capturing():
+                return None
         out = []
         for k in ("b1", "b2"):
             st = _SIDE_STREAMS.get((self.device.index, k))

@@ -187,8 +187,8 @@ class _Mixed(_Block):
         o1, o2, o3 = b0, b0 + b1, b0 + b1 + b2
         # the pool branch FIRST: backward then reaches the entry conv before the pool, so the entry conv's data gradient is the
         # first writer of x.grad (a plain store: the pointwise streaming kernel, conv_pw.h) and the pool backward accumulates
-        fork = ctx.branch_streams(xv.B * xv.T * xv.H * xv.W)
-        if fork is not None:      # small-batch inference: the branches run side by side (engine.BRANCH_STREAMS_VOX)
+        fork = ctx.branch_streams(xv.B * xv.T * xv.H * xv.W, xv.B)
+        if fork is not None:      # small batches: the branches run side by side (engine.BRANCH_STREAMS_VOX / _TRAIN_VOX)
             main = torch.cuda.current_stream(ctx.device)
             fork[1].wait_stream(main)
             with ctx.on_stream(fork[1]):
@@ -197,6 +197,10 @@ class _Mixed(_Block):
                 del pooled
             mods, jp, jbn = self._entry()
             E.conv_forward(ctx, jp, x, bn=jbn, act=L.ACT_RELU, dst=entry)
+            if ctx.training:
+                for m in mods:
+                    m.bn.note_training_step()
+                self.__dict__["_vinet_joint_fold"].clear()
             fork[0].wait_stream(main)
             if E.BRANCH_STREAMS_SWAP:
                 with ctx.on_stream(fork[0]):
