@@ -882,8 +882,10 @@ def test_training_forward_branch_streams_do_not_change_the_step(monkeypatch):
     x = synth.clip(B, T, H, W, 11).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
     gt = synth.gt_map(B, H, W, 11).to(DEV)
     res = {}
-    for name, vox in (("one_stream", 0), ("forked", 1 << 30)):
+    for name, vox, bwd in (("one_stream", 0, False), ("forked", 1 << 30, False), ("forked_bwd", 1 << 30, True)):
         monkeypatch.setattr(E, "BRANCH_STREAMS_TRAIN_VOX", vox)
+        monkeypatch.setattr(E, "BRANCH_STREAMS_BWD", bwd)
+        monkeypatch.setattr(E, "BRANCH_STREAMS_BWD_MIN_BATCH", 1)
         m = VM.VideoSaliencyModel(num_clips=T)
         m.load_state_dict(synth.synth_state_dict(m.state_dict(), 11))
         m = m.to(DEV).train()
@@ -903,10 +905,11 @@ def test_training_forward_branch_streams_do_not_change_the_step(monkeypatch):
         rm = torch.cat([b.detach().float().flatten() for n_, b in m.named_buffers() if n_.endswith("running_mean")])
         res[name] = (losses, opt.flat_g.clone(), rm, len(streams))
     assert res["forked"][3] >= 3 and res["one_stream"][3] == 1, (res["forked"][3], res["one_stream"][3])
-    assert res["forked"][0] == res["one_stream"][0], (res["forked"][0], res["one_stream"][0])
-    rel = float((res["forked"][1] - res["one_stream"][1]).norm() / res["one_stream"][1].norm())
-    assert rel < 1e-5, "gradients differ from the one-stream forward by %.3e" % rel
-    assert torch.equal(res["forked"][2], res["one_stream"][2])
+    for name in ("forked", "forked_bwd"):       # (forked_bwd: the backward pass's branch chains on three streams too, via tape markers)
+        assert res[name][0] == res["one_stream"][0], (name, res[name][0], res["one_stream"][0])
+        rel = float((res[name][1] - res["one_stream"][1]).norm() / res["one_stream"][1].norm())
+        assert rel < 1e-5, "%s: gradients differ from the one-stream schedule by %.3e" % (name, rel)
+        assert torch.equal(res[name][2], res["one_stream"][2])
 
 
 def test_weight_gradient_stream_does_not_change_the_gradients():

@@ -188,6 +188,9 @@ class _Mixed(_Block):
         # the pool branch FIRST: backward then reaches the entry conv before the pool, so the entry conv's data gradient is the
         # first writer of x.grad (a plain store: the pointwise streaming kernel, conv_pw.h) and the pool backward accumulates
         fork = ctx.branch_streams(xv.B * xv.T * xv.H * xv.W, xv.B)
+        if (fork is not None and ctx.recording and ctx.training and E.BRANCH_STREAMS_BWD and E.PARAM_GRAD_HOOK is None and
+                xv.B >= E.BRANCH_STREAMS_BWD_MIN_BATCH):
+            return self._fwd_joint_forked_train(ctx, x, fork, big, r1, r2, cat, entry)
         if fork is not None:      # small batches: the branches run side by side (engine.BRANCH_STREAMS_VOX / _TRAIN_VOX)
             main = torch.cuda.current_stream(ctx.device)
             fork[1].wait_stream(main)
@@ -223,6 +226,69 @@ class _Mixed(_Block):
             self.__dict__["_vinet_joint_fold"].clear()
         self.branch1[1]._fwd(ctx, r1, cat.sub_chan(o1, o2))
         self.branch2[1]._fwd(ctx, r2, cat.sub_chan(o2, o3))
+        return cat
+
+    def _fwd_joint_forked_train(self, ctx, x, fork, big, r1, r2, cat, entry):
+        """Small-batch training: the branches side by side in the forward AND in the backward pass.  The tape is run in reverse,
+        so the forward records, between the branches' nodes, markers that switch the backward pass's stream: backward runs
+        branch 2 on the main stream, branch 1 on fork[0] and branch 3's conv on fork[1] (each chain = BatchNorm backward + data
+        gradients, their weight gradients leave for the weight-gradient stream from whichever stream made dy), joins, then the
+        entry conv (the first writer of x.grad) and the pool's backward (which accumulates into it) on the main stream as before.
+        The branches write disjoint slices of the concat gradient's reduce regions and disjoint parameter gradients.  Under
+        capture the markers do nothing (the captured step groups its weight-gradient joins: engine.WGRAD_GROUP_CAPTURE)."""
+        b0, b1, b2, b3 = self.widths
+        o1, o2, o3 = b0, b0 + b1, b0 + b1 + b2
+        dev = ctx.device
+
+        def m_begin():
+            if not ctx.capturing:
+                main = torch.cuda.current_stream(dev)
+                fork[0].wait_stream(main)
+                fork[1].wait_stream(main)
+
+        def m_enter(k):
+            def f():
+                if not ctx.capturing:
+                    ctx._bwd_cm = ctx.on_stream(fork[k])
+                    ctx._bwd_cm.__enter__()
+            return f
+
+        def m_exit():
+            if not ctx.capturing:
+                ctx._bwd_cm.__exit__(None, None, None)
+                ctx._bwd_cm = None
+
+        def m_join():
+            if not ctx.capturing:
+                main = torch.cuda.current_stream(dev)
+                main.wait_stream(fork[0])
+                main.wait_stream(fork[1])
+
+        main = torch.cuda.current_stream(dev)
+        fork[1].wait_stream(main)
+        with ctx.on_stream(fork[1]):
+            pooled = E.maxpool_forward(ctx, x, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        mods, jp, jbn = self._entry()
+        E.conv_forward(ctx, jp, x, bn=jbn, act=L.ACT_RELU, dst=entry)
+        for m in mods:
+            m.bn.note_training_step()
+        self.__dict__["_vinet_joint_fold"].clear()
+        # (recorded in the reverse of the order the backward pass meets them)
+        ctx.record(m_join)
+        ctx.record(m_exit)
+        with ctx.on_stream(fork[1]):
+            self.branch3[1]._fwd(ctx, pooled, cat.sub_chan(o3, o3 + b3))
+            del pooled
+        ctx.record(m_enter(1))
+        ctx.record(m_exit)
+        fork[0].wait_stream(main)
+        with ctx.on_stream(fork[0]):
+            self.branch1[1]._fwd(ctx, r1, cat.sub_chan(o1, o2))
+        ctx.record(m_enter(0))
+        self.branch2[1]._fwd(ctx, r2, cat.sub_chan(o2, o3))
+        ctx.record(m_begin)
+        main.wait_stream(fork[0])
+        main.wait_stream(fork[1])
         return cat
 
     def _fwd(self, ctx, x, dst=None):
