@@ -46,7 +46,7 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (weak scaling; the reference default global batch is 8); "
                     "0 = 192 at 32x224x384, 64 at 64x256x448 (what fits 288 GB with margin)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the local-batch sweep {1,2,4,8,16,32} that the N = 1 training line carries (SURVEY.md 8(d))")
-    ap.add_argument("--sweep-steps", type=int, default=2)
+    ap.add_argument("--sweep-steps", type=int, default=5)
     ap.add_argument("--model", choices=["vinet", "avinet"], default="vinet",
                     help="avinet = BASELINE config 4: VideoAudioSaliencyModel with the SoundNet branch + bilinear fusion (32x224x384 only)")
     ap.add_argument("--clip", type=int, default=32)
