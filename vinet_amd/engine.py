@@ -71,7 +71,7 @@ BRANCH_STREAMS_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_VOX", "65536"))
 # The training forward forks the same way below this many voxels, at small batches only (same-box A/B, eager / replayed clips/s:
 # 4 clips 278 / 287 -> 293 / 302, 8: 434 / 411 -> 442 / 425, 16: 535 / 508 -> 539 / 516, 32: 615 / 587 -> 616 / 592; at 192 clips
 # the last two stages would qualify and the step loses 0.15 %, hence the batch bound).
-BRANCH_STREAMS_TRAIN_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_TRAIN_VOX", "200000"))
+BRANCH_STREAMS_TRAIN_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_TRAIN_VOX", "800000"))     # (every stage at <= 32 clips: 16 clips 551 -> 556, 32: 618 -> 627 over 200000)
 BRANCH_STREAMS_TRAIN_BATCH = int(os.environ.get("VINET_BRANCH_STREAMS_TRAIN_BATCH", "32"))
 # ... and in the backward pass (tape markers switch its stream: model_utils._Mixed._fwd_joint_forked_train); eager only, and from
 # 8 clips on (below, the eager step is bound by the host and the events are more host work): 8 clips 439 -> 443, 16: 537 -> 544,
