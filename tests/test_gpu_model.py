@@ -870,7 +870,8 @@ def test_stem_bn_backward_statistics_leave_with_the_temporal_data_gradient():
     _note("stem_bn_bwd_stats_fused", dict(reduce_launches=counts, worst_rel_of_the_three=worst))
 
 
-def test_training_forward_branch_streams_do_not_change_the_step(monkeypatch):
+@pytest.mark.parametrize("net", ["vinet", "avinet"])
+def test_training_forward_branch_streams_do_not_change_the_step(monkeypatch, net):
     """Small batches: the training forward forks the branches of every Inception stage over two more streams
     (engine.BRANCH_STREAMS_TRAIN_VOX).  A schedule, not arithmetic: loss, gradients (up to the fp32 atomics' order) and the
     BatchNorm running statistics equal the one-stream forward's, over several steps (a missing join shows as a stale branch)."""
@@ -878,15 +879,17 @@ def test_training_forward_branch_streams_do_not_change_the_step(monkeypatch):
     from vinet_amd import model as VM
     from vinet_amd import optim as VO
     E.set_default_dtype("bf16")
-    B, T, H, W = 2, 16, 64, 96
+    av = net == "avinet"            # (AViNet: the bilinear fusion fixes the clip shape)
+    B, T, H, W = (2, 32, 224, 384) if av else (2, 16, 64, 96)
     x = synth.clip(B, T, H, W, 11).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
+    ins = (x, synth.audio(B, 70560, 11).to(DEV)) if av else (x,)
     gt = synth.gt_map(B, H, W, 11).to(DEV)
     res = {}
     for name, vox, bwd in (("one_stream", 0, False), ("forked", 1 << 30, False), ("forked_bwd", 1 << 30, True)):
         monkeypatch.setattr(E, "BRANCH_STREAMS_TRAIN_VOX", vox)
         monkeypatch.setattr(E, "BRANCH_STREAMS_BWD", bwd)
         monkeypatch.setattr(E, "BRANCH_STREAMS_BWD_MIN_BATCH", 1)
-        m = VM.VideoSaliencyModel(num_clips=T)
+        m = (VM.VideoAudioSaliencyModel if av else VM.VideoSaliencyModel)(num_clips=T)
         m.load_state_dict(synth.synth_state_dict(m.state_dict(), 11))
         m = m.to(DEV).train()
         opt = VO.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
@@ -895,7 +898,7 @@ def test_training_forward_branch_streams_do_not_change_the_step(monkeypatch):
         try:
             for _ in range(3):
                 opt.zero_grad()
-                l = VL.kldiv(m(x), gt)
+                l = VL.kldiv(m(*ins), gt)
                 l.backward()
                 losses.append(float(l))
             streams = {a[1] for a in E.LAUNCH_LOG if a[0] == "vinet_conv3d"}
