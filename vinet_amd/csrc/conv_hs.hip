@@ -380,7 +380,9 @@ int vinet_conv_hs_segments(const VinetConvDesc* d) {
   const long strips = (long)d->x.B * d->oT * (d->oW / 64);
   long segs = (768 + strips - 1) / strips;
   if (segs > d->oH / 7) segs = d->oH / 7;
-  return segs < 1 ? 1 : (int)segs;
+  if (segs < 1) segs = 1;
+  const long seg_rows = (d->oH + segs - 1) / segs;
+  return (int)((d->oH + seg_rows - 1) / seg_rows);      // (the count the launch really uses: equal segments, the last one ragged)
 }
 
 // VinetConvDesc::tline == 2: the caller promises taps (0, kh, 0, slice kh), kh = 0..6 (the folded stem)

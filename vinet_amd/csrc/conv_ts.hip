@@ -499,7 +499,9 @@ int vinet_conv_ts_segments(const VinetConvDesc* d) {
   const long patches = (long)d->x.B * (((long)d->oH * d->oW) / 64);
   long segs = (512 + patches - 1) / patches;
   if (segs > d->oT / 4) segs = d->oT / 4;
-  return segs < 1 ? 1 : (int)segs;
+  if (segs < 1) segs = 1;
+  const long seg_frames = (d->oT + segs - 1) / segs;
+  return (int)((d->oT + seg_frames - 1) / seg_frames);  // (the count the launch really uses: equal segments, the last one ragged)
 }
 
 bool vinet_conv_use_ts(const VinetConvDesc* d) {

@@ -76,7 +76,9 @@ BRANCH_STREAMS_TRAIN_BATCH = int(os.environ.get("VINET_BRANCH_STREAMS_TRAIN_BATC
 # ... and in the backward pass (tape markers switch its stream: model_utils._Mixed._fwd_joint_forked_train); eager only, and from
 # 8 clips on (below, the eager step is bound by the host and the events are more host work): 8 clips 439 -> 443, 16: 537 -> 544,
 # 32: 603 -> 612 clips/s
-BRANCH_STREAMS_BWD = os.environ.get("VINET_BRANCH_STREAMS_BWD", "1") != "0"
+# OPT-IN (default off): the equivalence test of this schedule failed once in three full-suite runs on AViNet (never alone, never
+# on ViNet) and the cause was not found before the round ended.
+BRANCH_STREAMS_BWD = os.environ.get("VINET_BRANCH_STREAMS_BWD", "0") != "0"
 BRANCH_STREAMS_BWD_MIN_BATCH = int(os.environ.get("VINET_BRANCH_STREAMS_BWD_MIN_BATCH", "8"))
 BRANCH_STREAMS_EAGER = os.environ.get("VINET_BRANCH_STREAMS_EAGER", "0") != "0"
 # Which branch leaves the capturing stream: the replayed graph runs the entry conv and the FORKED stream's first kernel
