@@ -63,6 +63,9 @@ def parse(argv=None):
     ap.add_argument("--main-priority", type=int, default=0, help="tuning: run the step on a stream of this priority (-1 = high) instead of the default stream")
     ap.add_argument("--no-extras", action="store_true", help="skip the `inference` and `other_configs` legs the default N = 1 training line carries")
     ap.add_argument("--spawn", action="store_true", help="go through the self-spawn path (one rank per GPU under torch.distributed.run) even for --gpus 1")
+    ap.add_argument("--cfg", default="", help="engine / library options, 'name=value,...' (vinet_amd.engine.configure; 'lib.<option>=<int>' reaches vinet_set_option); recorded in the result line")
+    ap.add_argument("--force-collectives", action="store_true", help="treat a ONE-rank process group as distributed: every collective of the N > 1 path goes through RCCL (functional test on one GPU)")
+    ap.add_argument("--dist-backend", default="", help="process-group backend (default: nccl = RCCL); tests use gloo on device tensors")
     return ap.parse_args(argv)
 
 
@@ -157,15 +160,17 @@ def main():
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         spawn_ranks(args)
     from vinet_amd import _lib, engine, parallel
-    rank, world, local, dev = parallel.init_from_env()
+    parallel.FORCE_COLLECTIVES = bool(args.force_collectives)
+    rank, world, local, dev = parallel.init_from_env(args.dist_backend or None)
     if world != args.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let bench.py spawn them)" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     if parallel.distributed():
         assert dist.get_world_size() == world, "process group size differs from WORLD_SIZE"
-        assert dist.get_backend() == "nccl" or os.environ.get("VINET_DIST_BACKEND"), "RCCL (backend nccl) process group expected"
+        assert dist.get_backend() == "nccl" or args.dist_backend, "RCCL (backend nccl) process group expected"
     _lib.load()
+    engine.configure_from_string(args.cfg)
     out = measure(args, rank, world, dev)
     if rank == 0 and world == 1 and args.mode == "train" and not args.no_extras:
         import gc
@@ -378,6 +383,27 @@ def measure(args, rank, world, dev):
         k["count"] += v["count"]
         k["sites"].append(key)
     dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])[0]
+    # the kernel with the largest total time among those that CARRY SURVEY 8(d) work (convolutions: forward, data and weight
+    # gradients -- algorithmic FLOPs > 0): BatchNorm / copy / activation passes have a budget of zero bytes by that convention, so
+    # when one of them leads (`dom`), its streaming efficiency is not a roofline fraction of the path.  Bracketed in the timed
+    # region beside `dom`.
+    def _flops(k):
+        return sum(((table[s_]["work"] or {}).get("flops", 0.0)) * table[s_]["count"] for s_ in kernels[k]["sites"])
+    workers = [k for k in kernels if _flops(k) > 0]
+    work_k = max(workers, key=lambda k: kernels[k]["ms"]) if workers else None
+    # per step, from the bracketed warm-up step: passes that SURVEY 8(d) prices at zero bytes (fused by convention) + pools
+    def _ms(*prefixes):
+        return sum(v["ms"] for k, v in kernels.items() if k.startswith(prefixes))
+    zero_budget = dict(bn_bwd_reduce=_ms("vinet_bn_bwd_reduce"), bn_bwd_apply=_ms("vinet_bn_bwd_apply"),
+                       bn_finalize=_ms("vinet_bn_finalize", "vinet_bn_bwd_finalize", "vinet_bn_partials_fold", "vinet_bn_fold"),
+                       copy_affine=_ms("vinet_copy_affine"), upsample=_ms("vinet_upsample2x"), act_bwd=_ms("vinet_act_bwd"),
+                       import_export=_ms("vinet_import_ncdhw", "vinet_export_ncdhw"))
+    zero_budget = {k: round(v, 3) for k, v in zero_budget.items()}
+    zero_budget["total"] = round(sum(zero_budget.values()), 3)
+    zero_budget["pools_ms_budgeted"] = round(_ms("maxpool_fwd_kernel", "maxpool_bwd_kernel"), 3)
+    zero_budget["launches"] = {"bn_bwd_reduce": sum(v["count"] for k, v in kernels.items() if k.startswith("vinet_bn_bwd_reduce")),
+                               "bn_bwd_apply": sum(v["count"] for k, v in kernels.items() if k.startswith("vinet_bn_bwd_apply")),
+                               "copy_affine": sum(v["count"] for k, v in kernels.items() if k.startswith("vinet_copy_affine"))}
     if args.profile_all and rank == 0:
         tot = sum(v["ms"] for v in table.values())
         print("---- kernels (one warm-up step, HIP events) ----", file=sys.stderr)
@@ -392,7 +418,7 @@ def measure(args, rank, world, dev):
         print("sum of bracketed kernel time %.3f ms" % tot, file=sys.stderr)
 
     # ---- timed region: only the dominant kernel's launches are bracketed (2 events per launch)
-    prof = engine.Profiler(only=kernels[dom]["sites"])
+    prof = engine.Profiler(only=kernels[dom]["sites"] + (kernels[work_k]["sites"] if work_k and work_k != dom else []))
     engine.set_profiler(None if graphed else prof)
     sync()
     t0 = time.perf_counter()
@@ -405,7 +431,7 @@ def measure(args, rank, world, dev):
     if parallel.distributed():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)
-    # N > 1 (or VINET_FORCE_COLLECTIVES=1): the gradient exchange of the LAST timed step -- per 25 MB bucket when its all-reduce
+    # N > 1 (or --force-collectives): the gradient exchange of the LAST timed step -- per 25 MB bucket when its all-reduce
     # was issued and when it completed (ms from the start of the step), and how much of the exchange lay inside the backward pass
     comm = buckets.timeline() if (args.mode == "train" and parallel.distributed()) else None
     # ... and the same step at the global batches config 3 will really see (train.py:43 defaults to 8; a DHF1K epoch is 600 clips):
@@ -435,14 +461,23 @@ def measure(args, rank, world, dev):
         prof.records = [r for r in engine.Profiler().records]
         domtab = {k: v for k, v in table.items() if k in kernels[dom]["sites"]}
     else:
-        domtab = prof.summary()
+        alltab = prof.summary()
+        domtab = {k: v for k, v in alltab.items() if k in kernels[dom]["sites"]}
         if not sum(v["count"] for v in domtab.values()):
             # the kernel that led the bracketed warm-up step did not run in the timed steps (a first-step-only
             # kernel can lead under counter collection with --warmup 1): report it from the warm-up step
             domtab = {k: v for k, v in table.items() if k in kernels[dom]["sites"]}
-    domstat = dict(ms=sum(v["ms"] for v in domtab.values()), count=sum(v["count"] for v in domtab.values()),
-                   flops=sum((v["work"] or {}).get("flops", 0.0) * v["count"] for v in domtab.values()),
-                   bytes=sum((v["work"] or {}).get("bytes", 0.0) * v["count"] for v in domtab.values()))
+    def _stat(tab):
+        return dict(ms=sum(v["ms"] for v in tab.values()), count=sum(v["count"] for v in tab.values()),
+                    flops=sum((v["work"] or {}).get("flops", 0.0) * v["count"] for v in tab.values()),
+                    bytes=sum((v["work"] or {}).get("bytes", 0.0) * v["count"] for v in tab.values()))
+    domstat = _stat(domtab)
+    workstat = None
+    if work_k is not None:
+        wt = {k: v for k, v in (table if graphed else alltab).items() if k in kernels[work_k]["sites"]}
+        if not sum(v["count"] for v in wt.values()):
+            wt = {k: v for k, v in table.items() if k in kernels[work_k]["sites"]}
+        workstat = _stat(wt)
 
     # ---- local-batch sweep of the same step ({1,2,4,8,16,32}), N = 1 training only
     # (each point eager -- one Python-issued launch per kernel -- and as a replayed hipGraph of the step, vinet_amd.graph)
@@ -513,6 +548,24 @@ def measure(args, rank, world, dev):
         roof.update(traffic=traffic, kernel=dom, launches=domstat["count"], avg_us=avg_s * 1e6,
                     algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=byts,
                     also={"TFLOP/s": flops / avg_s / 1e12, "GB/s": byts / avg_s / 1e9})
+        if workstat is not None and workstat["count"]:
+            # the top kernel that carries SURVEY 8(d) work, with ITS fraction of the roof that bounds it
+            w_s = workstat["ms"] / workstat["count"] / 1e3
+            wf, wb = workstat["flops"] / workstat["count"], workstat["bytes"] / workstat["count"]
+            w_mfma = wf / max(wb, 1.0) > ridge
+            roof["work_kernel"] = dict(kernel=work_k, launches=workstat["count"], avg_us=w_s * 1e6, bound="mfma" if w_mfma else "hbm",
+                                       achieved=(wf / w_s / 1e12) if w_mfma else (wb / w_s / 1e9), peak=MFMA_BF16_PEAK_TF if w_mfma else HBM_PEAK_GBS,
+                                       unit="TFLOP/s" if w_mfma else "GB/s",
+                                       frac=(wf / w_s / 1e12 / MFMA_BF16_PEAK_TF) if w_mfma else (wb / w_s / 1e9 / HBM_PEAK_GBS),
+                                       algorithmic_flops_per_launch=wf, algorithmic_bytes_per_launch=wb)
+            try:
+                wp = pj["kernels"].get(work_k.replace(" ", ""))
+                if wp is not None and B == pj.get("batch", 32) and args.mode == "train":
+                    roof["work_kernel"].update(traffic=wp["traffic_bytes_per_launch"], mfma_busy_frac_pmc=wp.get("mfma_busy_frac"))
+            except (NameError, KeyError):
+                pass
+        roof["zero_budget_pass_ms"] = dict(zero_budget, note="per step, HIP events of the bracketed warm-up step: passes SURVEY 8(d) prices at zero bytes (BatchNorm backward, "
+                                                              "materialisation copies, upsample, activation backward, layout import / export); pools listed beside them")
         if args.mode == "train" and engine.WGRAD_SIDE_STREAM:
             roof["note"] = "per-launch time measured inside the step, where the weight-gradient stream shares the CUs and HBM; bench.py --no-side-stream --profile-all gives the kernel alone"
         if traffic is not None:
@@ -548,6 +601,7 @@ def measure(args, rank, world, dev):
                                       "1xMI355X" if world == 1 else "%dxMI355X RCCL all-reduce" % world),
                        "global_batch": world * B, "local_batch": B, "clip": [args.clip, args.height, args.width],
                        "parallelism": "dp%d" % world,
+                       "engine": engine.config(changed_only=True),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                        "reserved_hbm_gb": round(torch.cuda.memory_reserved(dev) / 1e9, 1)},
             "roofline": roof,
@@ -562,9 +616,10 @@ def measure(args, rank, world, dev):
         if sweep is not None:
             sweep[str(B)] = value
             sweep_eager[str(B)] = value
-            out["sweep"] = dict(unit="clips/s", steps_each=args.sweep_steps, local_batch=sweep, local_batch_eager=sweep_eager,
-                                note="local_batch: the step replayed as one hipGraph (vinet_amd.graph.GraphedTrainStep) for batches below the "
-                                     "headline's, which is eager; local_batch_eager: one Python-issued launch per kernel")
+            out["sweep"] = dict(unit="clips/s", steps_each=args.sweep_steps, primary="local_batch_eager", local_batch=sweep, local_batch_eager=sweep_eager,
+                                note="local_batch_eager (PRIMARY: the faster schedule from 4 clips on): one Python-issued launch per kernel; "
+                                     "local_batch: the step replayed as one hipGraph (vinet_amd.graph.GraphedTrainStep) for batches below the "
+                                     "headline's, which is eager")
         return out
     return {}
 

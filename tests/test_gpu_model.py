@@ -670,14 +670,72 @@ def test_single_rank_rccl_runs_every_collective_of_the_n_gpu_path(tmp_path):
     #  gradient, Adam's step of lr = 1e-4 puts one weight 2e-4 apart -- relative to max |p| ~ 3 that is < 1e-4)
     assert dg < 1e-6 and dp < 1e-4, (dg, dp)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VINET_FORCE_COLLECTIVES="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port + 1 if port < 65000 else port - 1), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
-                          "--no-sweep", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-sweep", "--no-cpu-baseline", "--force-collectives"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
     _note("single_rank_rccl", dict(bucketed_vs_flat_grad=dg, bucketed_vs_flat_param=dp, bench_clips_per_s=line["value"]))
+
+
+def test_gradient_bucket_timeline_stamps_the_end_of_the_collective(monkeypatch):
+    """GradientBuckets.timeline(): `done_ms` must be the END of a bucket's all-reduce.  RCCL runs a collective on the process
+    group's own stream and only `work.wait()` orders the caller's stream behind it, so an event recorded right behind the call
+    stamps the ISSUE (0.012 ms for a 62 MB bucket).  A stand-in collective with RCCL's stream semantics -- it idles
+    ~2 ms on a private stream, `wait()` makes the current stream wait for its end event -- must show up in done - issue."""
+    from vinet_amd import _lib
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    from vinet_amd import optim as VO
+    from vinet_amd import parallel
+    lib = _lib.load()
+    E.set_default_dtype("bf16")
+    priv = torch.cuda.Stream(DEV)
+    spin = 5000000       # shader clocks: 2 ms and more at any DVFS state
+
+    class Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream(DEV).wait_event(self.ev)
+
+    def fake_all_reduce(t, op=None, async_op=False):
+        priv.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(priv):
+            assert lib.vinet_debug_spin(spin, priv.cuda_stream) == 0
+            ev = torch.cuda.Event()
+            ev.record()
+        return Work(ev)
+
+    monkeypatch.setattr(parallel, "distributed", lambda: True)
+    monkeypatch.setattr(parallel.dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(parallel.dist, "get_world_size", lambda: 1)
+    B, T, H, W = 2, 8, 64, 96
+    x = synth.clip(B, T, H, W, 5).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
+    gt = synth.gt_map(B, H, W, 5).to(DEV)
+    m = VM.VideoSaliencyModel(num_clips=T)
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 5))
+    m = m.to(DEV).train()
+    opt = VO.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    buckets = parallel.GradientBuckets(opt)
+    buckets.timing = True
+    try:
+        for _ in range(2):
+            opt.zero_grad()
+            buckets.begin_step()
+            VL.kldiv(m(x), gt).backward()
+            buckets.finish()
+            opt.step()
+        tl = buckets.timeline()
+    finally:
+        E.PARAM_GRAD_HOOK = None
+    assert tl is not None and len(tl["buckets"]) >= 4
+    short = [b for b in tl["buckets"] if b["done_ms"] - b["issue_ms"] < 1.0]
+    assert not short, "completion stamps that are really issue stamps: %s" % short
+    _note("bucket_timeline_end_stamp", dict(min_ms=min(b["done_ms"] - b["issue_ms"] for b in tl["buckets"]), hidden_frac=tl["hidden_frac"]))
 
 
 def test_two_ranks_on_one_gpu_bucketed_allreduce(tmp_path):
@@ -794,16 +852,16 @@ def test_graphed_train_step_follows_the_eager_trajectory():
 
 def test_bench_self_spawn_path(tmp_path):
     """`python bench.py --gpus N` without a launcher re-runs itself as N ranks under torch.distributed.run (one per GPU,
-    backend nccl = RCCL).  With one GPU here: `--spawn` forces that path for N = 1 and VINET_FORCE_COLLECTIVES makes the
+    backend nccl = RCCL).  With one GPU here: `--spawn` forces that path for N = 1 and `--force-collectives` makes the
     single rank run every collective of the N > 1 step; asking for more GPUs than the node has is refused (exit code 2)
     instead of silently measuring one."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(VINET_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1", "--batch", "72",
-                          "--sweep-steps", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+                          "--sweep-steps", "1", "--no-cpu-baseline", "--no-extras", "--force-collectives"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1"
@@ -919,6 +977,51 @@ def test_training_forward_branch_streams_do_not_change_the_step(monkeypatch, net
         _note("branch_streams_%s_%s" % (net, name), {"grad_rel": rel})
         assert rel < 1e-5, "%s: gradients differ from the one-stream schedule by %.3e" % (name, rel)
         assert torch.equal(res[name][2], res["one_stream"][2])
+
+
+@pytest.mark.parametrize("net", ["vinet", "avinet"])
+@pytest.mark.parametrize("spin", [3000000, -3000000])
+def test_branch_fork_schedules_under_spin_stress(monkeypatch, net, spin):
+    """The forked schedules (training forward AND backward: engine.BRANCH_STREAMS_TRAIN_VOX / BRANCH_STREAMS_BWD) with a spin kernel
+    of ~1.3 ms idling the branch stream (spin > 0) or the forking stream (spin < 0) every time a fork enters a branch stream
+    (engine.DBG_SPIN_FORK): the streams drift apart by milliseconds in either direction, so a missing event edge -- or a block the
+    caching allocator hands to one stream while another still uses it -- shows as a mismatch against the one-stream schedule
+    instead of once in a hundred runs.  Real layer sizes (kernels of milliseconds) on purpose."""
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    from vinet_amd import optim as VO
+    E.set_default_dtype("bf16")
+    av = net == "avinet"
+    B, T, H, W = (2, 32, 224, 384) if av else (4, 16, 128, 192)
+    x = synth.clip(B, T, H, W, 13).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
+    ins = (x, synth.audio(B, 70560, 13).to(DEV)) if av else (x,)
+    gt = synth.gt_map(B, H, W, 13).to(DEV)
+    res = {}
+    for name, vox, bwd, sp in (("one_stream", 0, False, 0), ("forked_spin", 1 << 30, True, spin)):
+        monkeypatch.setattr(E, "BRANCH_STREAMS_TRAIN_VOX", vox)
+        monkeypatch.setattr(E, "BRANCH_STREAMS_BWD", bwd)
+        monkeypatch.setattr(E, "BRANCH_STREAMS_BWD_MIN_BATCH", 1)
+        monkeypatch.setattr(E, "DBG_SPIN_FORK", sp)
+        m = (VM.VideoAudioSaliencyModel if av else VM.VideoSaliencyModel)(num_clips=T)
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), 13))
+        m = m.to(DEV).train()
+        opt = VO.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            l = VL.kldiv(m(*ins), gt)
+            l.backward()
+            losses.append(float(l))
+        torch.cuda.synchronize()
+        rm = torch.cat([b.detach().float().flatten() for n_, b in m.named_buffers() if n_.endswith("running_mean")])
+        res[name] = (losses, opt.flat_g.clone(), rm)
+        del m, opt
+    monkeypatch.setattr(E, "DBG_SPIN_FORK", 0)
+    assert res["forked_spin"][0] == res["one_stream"][0], (res["forked_spin"][0], res["one_stream"][0])
+    rel = float((res["forked_spin"][1] - res["one_stream"][1]).norm() / res["one_stream"][1].norm())
+    _note("branch_streams_spin_%s_%d" % (net, spin), {"grad_rel": rel})
+    assert rel < 1e-5, "gradients differ from the one-stream schedule by %.3e" % rel
+    assert torch.equal(res["forked_spin"][2], res["one_stream"][2])
 
 
 def test_weight_gradient_stream_does_not_change_the_gradients():

@@ -151,13 +151,22 @@ def load(path=LIB_PATH):
         fn.restype = _RESTYPE.get(name, C.c_int)
     if lib.vinet_abi_version() != ABI_VERSION:
         raise VinetLibraryError("libvinet_hip.so ABI %d != expected %d" % (lib.vinet_abi_version(), ABI_VERSION))
-    # tuning switches, e.g. VINET_OPT="tperm=0,pp=0" (names: vinet_set_option in include/vinet_hip.h)
-    for item in filter(None, os.environ.get("VINET_OPT", "").split(",")):
-        k, _, v = item.partition("=")
-        if lib.vinet_set_option(k.strip().encode(), int(v)) != 0:
-            raise VinetLibraryError("VINET_OPT: " + lib.vinet_last_error().decode())
     _LIB = lib
     return lib
+
+
+LIB_OPTIONS = {}     # library tuning switches set through set_option in this process (engine.config() reports them)
+
+
+def set_option(name, value):
+    """vinet_set_option(name, value) on the active backend (names: include/vinet_hip.h); engine.configure_from_string and
+    bench.py --cfg reach it as `lib.<name>=<int>`"""
+    lib = get()
+    rc = lib.vinet_set_option(name.encode() if isinstance(name, str) else name, int(value))
+    if rc != 0:
+        msg = lib.vinet_last_error()
+        raise VinetLibraryError("set_option(%s): %s" % (name, msg.decode() if isinstance(msg, bytes) else msg))
+    LIB_OPTIONS[name if isinstance(name, str) else name.decode()] = int(value)
 
 
 def get():

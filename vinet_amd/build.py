@@ -101,31 +101,38 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         out = r.stdout + r.stderr
         if guarded and r.returncode == 0:
-            import json
             try:
                 res = check_guarded(os.path.basename(s), out)
             except RuntimeError:
                 os.remove(o)
                 raise
-            try:
-                allres = json.load(open(RESOURCES)) if os.path.exists(RESOURCES) else {}
-            except ValueError:
-                allres = {}
-            allres[os.path.basename(s)] = res
-            with open(RESOURCES, "w") as f:
-                json.dump(allres, f, indent=1, sort_keys=True)
             out = "\n".join(l for l in out.splitlines() if "kernel-resource-usage" not in l and not l.startswith("   ") )
-        return s, r.returncode, out
+            return s, r.returncode, out, res
+        return s, r.returncode, out, None
 
     if jobs:
         if verbose:
             print("[vinet_amd.build] compiling %d file(s) for gfx950 ..." % len(jobs), flush=True)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
-            for s, rc, out in ex.map(compile_one, jobs):
+            resources = {}
+            for s, rc, out, res in ex.map(compile_one, jobs):
                 if rc != 0:
                     raise RuntimeError("hipcc failed on %s:\n%s" % (s, out))
+                if res is not None:
+                    resources[os.path.basename(s)] = res
                 if verbose and out.strip():
                     print(out)
+        if resources:
+            # (written ONCE, here, after every compile job has finished: the jobs run on a thread pool; the file is a build
+            #  artefact -- git-ignored -- that tools read for register counts)
+            import json
+            try:
+                allres = json.load(open(RESOURCES)) if os.path.exists(RESOURCES) else {}
+            except ValueError:
+                allres = {}
+            allres.update(resources)
+            with open(RESOURCES, "w") as f:
+                json.dump(allres, f, indent=1, sort_keys=True)
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

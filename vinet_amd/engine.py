@@ -36,56 +36,135 @@ EG = {F32: 4, BF16: 8}          # elements per 16 bytes
 
 _DEFAULT_DTYPE = BF16
 _WEIGHTS_EPOCH = 0
-# Weight gradients are off the backward critical path (only the optimizer consumes them):
-# they run on a second HIP stream, concurrently with the dgrad / BN-backward chain.
-ROW_ALIGN = int(os.environ.get("VINET_ROW_ALIGN", "0"))      # bytes; 0 = dense rows.  128 measured neutral on the whole step
-STEM_FOLD = os.environ.get("VINET_STEM_FOLD", "1") != "0"   # padded/folded stem input (A/B switch)
-WGRAD_SIDE_STREAM = True
-# CUs the persistent weight-gradient kernels may occupy while they run beside the main stream (VinetWgradDesc::max_cus, per launch);
-# without a second stream they are alone on the GPU and get all of it
-WGRAD_CUS = int(os.environ.get("VINET_WGRAD_CUS", "208"))
-TAIL_WGRAD_FULL = os.environ.get("VINET_TAIL_WGRAD_FULL", "1") != "0"
-# weight-gradient jobs per join with the main stream (1 = a join per job), eager / under capture.  Eager: 1 .. 16 within noise
-# at 8 and 32 clips (432 / 608 clips/s).  Replayed step: 1: 381 / 546, 4: 396 / 566, 8: 402 / 574, 16: 410 / 583, 32: 399 / 578,
-# 64 (= all weight gradients behind the backward pass): 367 / 549 -- every fork costs the replay ~12 us on the main stream's
-# next kernel (profiles/r4_experiments.txt).
-WGRAD_GROUP = int(os.environ.get("VINET_WGRAD_GROUP", "1"))
-WGRAD_GROUP_CAPTURE = int(os.environ.get("VINET_WGRAD_GROUP_CAPTURE", "16"))
-# cap of the decoder's (BatchNorm-less, deferred) weight gradients, which run beside the backward of the low-resolution encoder stages
-WGRAD_CUS_DEC = int(os.environ.get("VINET_WGRAD_CUS_DEC", str(WGRAD_CUS)))
-# every packed weight gradient of a backward pass unpacked by ONE launch at its end (0 = one vinet_unpack_wgrad per conv).  Not
-# used while a parameter-gradient hook is installed (the bucketed all-reduce wants each gradient as soon as it is final).
-MULTI_UNPACK = int(os.environ.get("VINET_MULTI_UNPACK", "1"))
 _UNPACK_TABLES = {}
-# weight-gradient streams the jobs are dealt over round robin (1 = one side stream)
-N_SIDE_STREAMS = int(os.environ.get("VINET_SIDE_STREAMS", "1"))
 _SIDE_STREAMS = {}
-# Inference at small batches: the four branches of an Inception stage are independent kernels whose grids cannot fill
-# 256 CUs (batch 1: 3 .. 170 workgroups), so below this many input voxels a stage forks them over two more streams
-# (entry -> branch 1 on the caller's stream, branch 2 on one, pool -> branch 3 on the other) and joins at the concat:
-# 3 kernels on the stage's critical path instead of 7.  Under capture the fork / join events become graph edges (fan-out
-# <= 3: below the 6-8 outgoing edges that the runtime's replay mishandles, profiles/r4_capture_fanout.txt).  0 = never.
-# Only under capture by default: an eager batch-1 forward is bound by the host's launch rate, and the fork / join events
-# are more host work (307 -> 263 fps eager; 586 -> 645 fps replayed).  VINET_BRANCH_STREAMS_EAGER=1 forks in eager too.
-BRANCH_STREAMS_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_VOX", "65536"))
-# The training forward forks the same way below this many voxels, at small batches only (same-box A/B, eager / replayed clips/s:
-# 4 clips 278 / 287 -> 293 / 302, 8: 434 / 411 -> 442 / 425, 16: 535 / 508 -> 539 / 516, 32: 615 / 587 -> 616 / 592; at 192 clips
-# the last two stages would qualify and the step loses 0.15 %, hence the batch bound).
-BRANCH_STREAMS_TRAIN_VOX = int(os.environ.get("VINET_BRANCH_STREAMS_TRAIN_VOX", "800000"))     # (every stage at <= 32 clips: 16 clips 551 -> 556, 32: 618 -> 627 over 200000)
-BRANCH_STREAMS_TRAIN_BATCH = int(os.environ.get("VINET_BRANCH_STREAMS_TRAIN_BATCH", "32"))
-# ... and in the backward pass (tape markers switch its stream: model_utils._Mixed._fwd_joint_forked_train); eager only, and from
-# 8 clips on (below, the eager step is bound by the host and the events are more host work): 8 clips 439 -> 443, 16: 537 -> 544,
-# 32: 603 -> 612 clips/s
-# OPT-IN (default off): the equivalence test of this schedule failed once in three full-suite runs on AViNet (never alone, never
-# on ViNet) and the cause was not found before the round ended.
-BRANCH_STREAMS_BWD = os.environ.get("VINET_BRANCH_STREAMS_BWD", "0") != "0"
-BRANCH_STREAMS_BWD_MIN_BATCH = int(os.environ.get("VINET_BRANCH_STREAMS_BWD_MIN_BATCH", "8"))
-BRANCH_STREAMS_EAGER = os.environ.get("VINET_BRANCH_STREAMS_EAGER", "0") != "0"
-# Which branch leaves the capturing stream: the replayed graph runs the entry conv and the FORKED stream's first kernel
-# back to back on one hardware queue and pays ~12 us of cross-queue latency to start the branch that stayed on the capturing
-# stream (rocprofv3 trace of a replay: profiles/r4_trace_infer_b1.txt), so the longer chain (branch 1: the wide 3x3 pair) is
-# the one to fork: 690 -> 737 fps at batch 1, 1033 -> 1076 at batch 2.  0 = branch 2 forks instead.
-BRANCH_STREAMS_SWAP = os.environ.get("VINET_BRANCH_STREAMS_SWAP", "1") != "0"
+
+# ----------------------------------------------------------------------------
+# configuration: ONE explicit entry point, engine.configure(**kw).  Nothing here reads the environment (the only
+# environment variable of the package is VINET_LIB, the path of another build of the library: _lib.py); tools and
+# bench.py pass `--cfg name=value,...` through configure().  The values live as module attributes (tests monkeypatch
+# them); config() returns the current set, which bench.py records in its JSON line.
+# ----------------------------------------------------------------------------
+_CONFIG = dict(
+    # weight gradients are off the backward critical path (only the optimizer consumes them): they run on a second
+    # HIP stream, concurrently with the data-gradient / BatchNorm-backward chain
+    WGRAD_SIDE_STREAM=True,
+    # CUs the persistent weight-gradient kernels may occupy while they run beside the main stream (VinetWgradDesc::max_cus,
+    # per launch); without a second stream they are alone on the GPU and get all of it
+    WGRAD_CUS=208,
+    WGRAD_CUS_DEC=208,          # ... the decoder's (BatchNorm-less, deferred) weight gradients
+    TAIL_WGRAD_FULL=True,       # the tape's last weight gradient (the RGB stem) takes the whole chip
+    # weight-gradient jobs per join with the main stream (1 = a join per job), eager / under capture.  Replayed step: 1: 381 / 546
+    # clips/s at 8 / 32 clips, 16: 410 / 583, 64: 367 / 549 -- every fork costs the replay ~12 us (profiles/r4_experiments.txt)
+    WGRAD_GROUP=1,
+    WGRAD_GROUP_CAPTURE=16,
+    # every packed weight gradient of a backward pass unpacked by ONE launch at its end (0 = one vinet_unpack_wgrad per conv).
+    # Not used while a parameter-gradient hook is installed (the bucketed all-reduce wants each gradient as soon as it is final).
+    MULTI_UNPACK=1,
+    N_SIDE_STREAMS=1,           # weight-gradient streams the jobs are dealt over round robin
+    # Inference at small batches: the four branches of an Inception stage are independent kernels whose grids cannot fill 256
+    # CUs (batch 1: 3 .. 170 workgroups), so below this many input voxels a stage forks them over two more streams and joins at
+    # the concat.  Only under capture by default (an eager batch-1 forward is bound by the host's launch rate: 307 -> 263 fps
+    # eager; 586 -> 645 fps replayed); BRANCH_STREAMS_EAGER forks in eager too.  0 = never.
+    BRANCH_STREAMS_VOX=65536,
+    BRANCH_STREAMS_EAGER=False,
+    # the training forward forks the same way below this many voxels, at small batches only (4 clips +5 %, 8 clips +1.8 %, neutral
+    # at 32; at 192 clips the last two stages would qualify and the step loses 0.15 %, hence the batch bound)
+    BRANCH_STREAMS_TRAIN_VOX=800000,
+    BRANCH_STREAMS_TRAIN_BATCH=32,
+    # ... and in the backward pass (tape markers switch its stream: model_utils._Mixed._fwd_joint_forked_train); eager only, from
+    # 8 clips on: +1..1.5 %.  EXPERIMENTAL, off: see DESIGN.md (round 5) for the stress results of this schedule.
+    BRANCH_STREAMS_BWD=False,
+    BRANCH_STREAMS_BWD_MIN_BATCH=8,
+    # which branch leaves the capturing stream: the longer chain (branch 1) forks (690 -> 737 fps at batch 1); False = branch 2
+    BRANCH_STREAMS_SWAP=True,
+    STEM_FOLD=True,             # padded / folded RGB stem input (the streaming stem kernels need it)
+    JOINT_ENTRY=1,              # Inception blocks run their three input-side 1x1x1 convs as one (model_utils._Mixed._fwd_joint)
+    BN_BWD_FUSE=1,              # the stem's BN-backward apply pass folded into its weight-gradient kernel
+    SHARE_SKIP_GRAD=True,       # a decoder skip's gradient lives in the T-concat's gradient (no copy in backward)
+    # weight gradients of the BN-free (decoder) convs wait until the tape reaches the encoder (+0.5 % on the step at 192 clips)
+    DEFER_DECODER_WGRAD=1,
+    DEFER_DECODER_WGRAD_F32S=0,  # fp32s: the weight-gradient stream is the longer one there (207.3 -> 212.5 clips/s at 64 clips)
+    PERSISTENT_DW=1,            # packed weight-gradient workspaces owned by the conv plans, re-zeroed by the unpack kernel
+    # consumer-side BN costs the MFMA kernels 20-27 %; writing relu(bn(x)) out once costs two passes over x: materialise the
+    # input of a conv when N * taps is at least this (0 = never; whole step: never 478 clips/s, 400: 483, 800: 539, 2500: 485)
+    MATERIALIZE_NT=800,
+    SPLIT_WGRAD_BF16=1,         # fp32s weight gradient as three launches of the bf16 kernels over hi / lo planes
+    SPLIT_IN_APPLY=1,           # fp32s: the planes of dy leave with the BatchNorm-backward apply pass that produces dy
+    # a data gradient that is the LAST writer of the gradient behind BatchNorm + ReLU layers also writes their backward partial
+    # sums (VinetConvDesc::bnb_*): no reduce pass over (dz, z) for those layers.  0 = off, 1 = the stem's fused temporal data
+    # gradient only (round 4), 2 = every data gradient the library can do it for (round 5)
+    DGRAD_BN_STATS=2,
+    UPSAMPLE_BWD_RELU=1,        # ReLU backward of conv -> ReLU -> upsample inside the upsample's backward pass
+    PARAM_GRAD_MODE="fused",    # see set_param_grad_mode
+    # Schedule stress (tests): shader clocks a spin kernel idles on the weight-gradient stream in front of every weight-gradient
+    # launch (DBG_SPIN_SIDE) / on the main stream in front of every data gradient (DBG_SPIN_MAIN) / on a branch stream each time
+    # a fork enters it (DBG_SPIN_FORK; negative: on the forking stream instead, so the branch streams run ahead).  A result
+    # that depends on the streams' relative timing shows up as a mismatch against the one-stream schedule.
+    DBG_SPIN_SIDE=0,
+    DBG_SPIN_MAIN=0,
+    DBG_SPIN_FORK=0,
+    # "vinet_conv3d_wgrad,vinet_bn_bwd_reduce,tag:dgrad": entry points (or call-site tags) whose launches are SKIPPED -- what a
+    # kernel family costs in the step once the overlap of the two streams is taken into account (tools/ablate.sh).  Results are
+    # garbage; the step time is the point.
+    ABLATE="",
+)
+globals().update(_CONFIG)
+_ABLATE, _ABLATE_TAGS = set(), []
+
+
+def configure(**kw):
+    """Set engine options (names: the keys of engine._CONFIG, upper or lower case).  Returns the previous values of the keys
+    given, so `old = configure(x=1) ... configure(**old)` restores them."""
+    global _ABLATE, _ABLATE_TAGS
+    old = {}
+    for k, v in kw.items():
+        K = k.upper()
+        if K not in _CONFIG:
+            raise KeyError("engine.configure: unknown option %r (known: %s)" % (k, ", ".join(sorted(_CONFIG))))
+        d = _CONFIG[K]
+        if isinstance(d, bool):
+            v = (v not in ("0", "false", "False", "")) if isinstance(v, str) else bool(v)
+        elif isinstance(d, int):
+            v = int(v)
+        elif isinstance(d, str):
+            v = str(v)
+        old[K] = globals()[K]
+        globals()[K] = v
+        if K == "PARAM_GRAD_MODE":
+            set_param_grad_mode(v)
+        if K == "ABLATE":
+            items = [a for a in v.split(",") if a]
+            _ABLATE = set(a for a in items if not a.startswith("tag:"))
+            _ABLATE_TAGS = [a[4:] for a in items if a.startswith("tag:")]
+            if _ABLATE_TAGS:
+                _ABLATE.add("\0tags")
+    return old
+
+
+def configure_from_string(text):
+    """'name=value,name=value' (bench.py --cfg, tools): engine options, and `lib.<option>=<int>` for vinet_set_option"""
+    kw = {}
+    for item in filter(None, (text or "").split(",")):
+        k, _, v = item.partition("=")
+        k = k.strip()
+        if k.startswith("lib."):
+            L.set_option(k[4:], int(v))
+        elif k.upper() == "ABLATE":
+            kw["ABLATE"] = v.replace("+", ",")          # ('+' separates the entries inside one --cfg value)
+        else:
+            kw[k] = v
+    return configure(**kw)
+
+
+def config(changed_only=False):
+    """current engine options (+ the library options set through _lib.set_option)"""
+    cur = {k: globals()[k] for k in _CONFIG}
+    if changed_only:
+        cur = {k: v for k, v in cur.items() if v != _CONFIG[k]}
+    if L.LIB_OPTIONS:
+        cur["lib"] = dict(L.LIB_OPTIONS)
+    return cur
 
 
 def set_default_dtype(name):
@@ -134,30 +213,7 @@ class Profiler:
 
 
 PROFILER = None
-LAUNCH_LOG = None      # tools/dbg_defer.py: list that receives (entry point, stream, tag) of every launch issued through Ctx.call
-# Inception blocks run their three input-side 1x1x1 convs as one (model_utils._Mixed._fwd_joint); 0 = per conv
-JOINT_ENTRY = int(os.environ.get("VINET_JOINT_ENTRY", "1"))
-# the stem's BN-backward apply pass folded into its weight-gradient kernel (0 = separate pass)
-BN_BWD_FUSE = int(os.environ.get("VINET_BN_BWD_FUSE", "1"))
-# weight gradients of the BN-free (decoder) convs wait on the side stream until the tape reaches the encoder (0 = launch in tape order); +0.5 % on the whole step at 192 clips (550.7 / 551.7 vs 548.2 / 548.2 clips/s, alternating runs on one box)
-SHARE_SKIP_GRAD = os.environ.get("VINET_SHARE_SKIP_GRAD", "1") != "0"
-DEFER_DECODER_WGRAD = int(os.environ.get("VINET_DEFER_DECODER_WGRAD", "1"))
-# packed weight-gradient workspaces owned by the conv plans and re-zeroed by vinet_unpack_wgrad (0 = a torch.zeros per conv and step)
-PERSISTENT_DW = int(os.environ.get("VINET_PERSISTENT_DW", "1"))
-# Schedule stress (tests / tools/dbg_defer.py): shader clocks a spin kernel idles on the weight-gradient stream in front of every
-# weight-gradient launch (DBG_SPIN_SIDE) / on the main stream in front of every data gradient (DBG_SPIN_MAIN).  The two streams
-# then drift apart by milliseconds in either direction; a result that depends on their relative timing shows up as a
-# gradient mismatch against the one-stream schedule.
-DBG_SPIN_SIDE = int(os.environ.get("VINET_DBG_SPIN_SIDE", "0"))
-DBG_SPIN_MAIN = int(os.environ.get("VINET_DBG_SPIN_MAIN", "0"))
-
-
-# VINET_ABLATE="vinet_conv3d_wgrad,vinet_bn_bwd_reduce,tag:dgrad": entry points (or call-site tags) whose launches are skipped -- how much
-# of the step does a kernel family really cost once the overlap of the two streams is taken into account (tools/ablate.sh)
-_ABLATE = set(a for a in os.environ.get("VINET_ABLATE", "").split(",") if a and not a.startswith("tag:"))
-_ABLATE_TAGS = [a[4:] for a in os.environ.get("VINET_ABLATE", "").split(",") if a.startswith("tag:")]
-if _ABLATE_TAGS:
-    _ABLATE.add("\0tags")
+LAUNCH_LOG = None      # tests: a list that receives (entry point, stream, tag) of every launch issued through Ctx.call
 
 
 def set_profiler(p):
@@ -185,12 +241,10 @@ class View:
 
     @staticmethod
     def alloc(B, T, H, W, Cc, dt, device, zero=False):
-        # Optional (VINET_ROW_ALIGN=128): voxel rows start on 128-byte lines.  The microbenchmark
-        # (tools/ubench/l2_to_lds) moves 8 rows x 128 B per LDS-DMA at 33 B/clk/CU from 960-byte rows (480 channels)
-        # against 55-65 from line-aligned rows, but no layer of the real step got faster: left off.
+        # (dense rows.  Rows padded to 128-byte lines were tried: the microbenchmark tools/ubench/l2_to_lds moves 8 rows x 128 B
+        #  per LDS-DMA at 33 B/clk/CU from 960-byte rows against 55-65 from line-aligned ones, but no layer of the real step got
+        #  faster, and the switch is gone.)
         ld = Cc
-        if ROW_ALIGN and Cc * ESIZE[dt] > ROW_ALIGN and (Cc * ESIZE[dt]) % ROW_ALIGN:
-            ld = rup(Cc * ESIZE[dt], ROW_ALIGN) // ESIZE[dt]
         n = B * T * H * W * ld
         buf = (torch.zeros if zero else torch.empty)(n, dtype=TORCH_DT[dt], device=device)
         return View(buf, 0, B, T, H, W, Cc, ld, T * H * W * ld, dt)
@@ -415,20 +469,20 @@ class Ctx:
         stream, with no main-stream launch in between) gives the main stream's last node one outgoing edge per job, and a
         captured step with such a fan-out REPLAYS WRONG on ROCm 7.2 -- the main stream's next kernel runs before that node
         has finished, although hipGraphDebugDotPrint shows the edge (the two graphs' edge sets differ only by the redundant
-        fan-out edges; tools/dbg_defer.py, tools/dot_edges.py, tools/repro_graph_fanout.py, profiles/r4_capture_fanout.txt).
+        fan-out edges; tools/dot_edges.py, tools/repro_graph_fanout.py, profiles/r4_capture_fanout.txt).
         Eager execution of the same launches is correct under any relative timing of the two streams (spin-kernel stress)."""
         jobs, self._deferred = self._deferred, []
         if not jobs:
             return
-        mode = os.environ.get("VINET_DBG_FLUSH_MODE", "once")        # "per_job" / "dummy": tools/dbg_defer.py only
         side = self.side_stream()
-        if mode == "once" and side is not None:
-            side.wait_stream(torch.cuda.current_stream(self.device))
+        if side is not None:
+            # (every weight-gradient stream the jobs are dealt over: a job on stream k >= 1 skips its own join when _joined is set)
+            cur = torch.cuda.current_stream(self.device)
+            for st in self.side_streams():
+                st.wait_stream(cur)
             self._joined = True
         try:
             for job in jobs:
-                if mode == "dummy" and side is not None:               # a main-stream node between two joins
-                    self.lib.vinet_debug_spin(0, self.stream)
                 job()
         finally:
             self._joined = False
@@ -478,11 +532,21 @@ class Ctx:
         self._unpack_jobs = []
         self.capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         self._tape_left = len(self.tape)         # nodes still to run, the current one included
-        for fn in reversed(self.tape):
-            fn()
-            self._tape_left -= 1
-        self.flush_deferred()
-        self.flush_unpack()
+        self._dw_plans = []
+        try:
+            for fn in reversed(self.tape):
+                fn()
+                self._tape_left -= 1
+            self.flush_deferred()
+            self.flush_unpack()
+        except BaseException:
+            # every weight-gradient kernel ADDS into its plan's persistent workspace, which only the unpack launch hands back
+            # zeroed: a backward pass that dies between the two would leave a residue that every later step silently adds to
+            # its gradient.  Drop the workspaces this pass touched (the next use allocates zero-filled ones).
+            for plan in self._dw_plans:
+                plan._dw_ws.clear()
+            self._deferred, self._unpack_jobs = [], []
+            raise
         if getattr(self, "side_used", False):
             # the optimizer (and every buffer release that follows) is ordered after the side stream
             for st in self.side_streams():
@@ -1002,12 +1066,6 @@ def _splitk_scratch(ctx, d):
     return ws
 
 
-# Consumer-side BN (the pending affine applied at fragment time) costs the MFMA kernels 20-27 % in forward and weight
-# gradient, and keeps forward convs off the ping-pong kernel; writing relu(bn(x)) out once costs two passes over x.
-# Worth it when the conv does enough work per input element: N * taps above this threshold (0 = never).  Measured
-# on the whole step (128 clips): never 478 clips/s, 400: 483, 600: 491, 1000-1700: 491-493, 2500: 485 -- the 1x3x3
-# convs with >= 112 output channels pay, the 3x1x1 192->192 conv (576) does not.
-MATERIALIZE_NT = int(os.environ.get("VINET_MATERIALIZE_NT", "800"))
 
 
 def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n_pad=None):
@@ -1145,6 +1203,9 @@ class _OnStream:
         self.cm = torch.cuda.stream(self.st)
         self.cm.__enter__()
         self.ctx.stream = self.st.cuda_stream
+        if DBG_SPIN_FORK and self.ctx.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            # schedule stress: the branch stream (> 0) or the forking stream (< 0) idles first, so the streams drift apart
+            self.ctx.lib.vinet_debug_spin(abs(DBG_SPIN_FORK), self.st.cuda_stream if DBG_SPIN_FORK > 0 else self.prev)
         return self
 
     def __exit__(self, *exc):
@@ -1160,20 +1221,6 @@ class _NullCtx:
         return False
 
 
-# the weight gradient of the split-bf16 form (fp32s) as three launches of the bf16 kernels over hi / lo planes (0 = the dedicated
-# register-staged split kernel, conv_wgrad.hip)
-SPLIT_WGRAD_BF16 = int(os.environ.get("VINET_SPLIT_WGRAD_BF16", "1"))
-SPLIT_ON_MAIN = int(os.environ.get("VINET_SPLIT_ON_MAIN", "0"))
-# fp32s: the planes of dy are written by the BatchNorm-backward apply pass that produces dy (vinet_bn_bwd_apply_split); 0 = a split pass
-SPLIT_IN_APPLY = int(os.environ.get("VINET_SPLIT_IN_APPLY", "1"))
-# a data gradient that is the only writer of the gradient behind a BatchNorm + ReLU also writes that BatchNorm's backward
-# partial sums where the library can (vinet_conv3d_bn_bwd_stats_rows: the fused temporal data gradient of the stem); 0 = off
-DGRAD_BN_STATS = int(os.environ.get("VINET_DGRAD_BN_STATS", "1"))
-# the backward of a ReLU that sits between a conv and an upsample (the decoder) inside the upsample's backward pass; 0 = vinet_act_bwd
-UPSAMPLE_BWD_RELU = int(os.environ.get("VINET_UPSAMPLE_BWD_RELU", "1"))
-# fp32s: deferral of the decoder's weight gradients (DEFER_DECODER_WGRAD) -- in this form the weight-gradient stream (three launches
-# per conv + the split passes) is the longer one, so it should start with the backward pass, not 35 ms into it
-DEFER_DECODER_WGRAD_F32S = int(os.environ.get("VINET_DEFER_DECODER_WGRAD_F32S", "0"))      # measured at 64 clips: 207.3 -> 212.5 clips/s
 
 
 def _split_planes_folded(ctx, x):
@@ -1321,8 +1368,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         want_planes = bool(SPLIT_WGRAD_BF16 and ctx.cdt == F32S and fused_bnb is None and dy.C % 8 == 0 and x.v.dt == F32 and dy.dt == F32 and
                            ((not plan.stem and x.fold is None and x.v.C % 8 == 0) or
                             (plan.stem and x.fold is not None and x.scale is None and x.v.off == 0)))
-        # SPLIT_ON_MAIN: the split passes run on the main stream (the weight-gradient stream is the longer one in this form)
-        planes_main = _split_planes(ctx, x, dy, dy_planes) if (want_planes and SPLIT_ON_MAIN and ctx.side_stream() is not None) else None
+        planes_main = None
 
         def wgrad_job():
             ctx._side_rr = (getattr(ctx, "_side_rr", -1) + 1) % N_SIDE_STREAMS
@@ -1343,6 +1389,8 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                     #  never read -- keeps a persistent workspace too: no allocation and no fill on the weight-gradient stream)
                     persistent = bool(PERSISTENT_DW)
                     dw = plan.dw_workspace(ctx, nsl * Ny * kp) if persistent else ctx.f32(nsl * Ny * kp, zero=True)
+                    if persistent:
+                        ctx._dw_plans.append(plan)
                     if persistent and any(j[0] == dw.data_ptr() for j in ctx._unpack_jobs):
                         # this plan already ran in this backward (a module used twice in one forward): its workspace holds the
                         # first use's gradient, and the kernels may STORE their result (no split-K, no atomics: "dw is zero on
@@ -1404,7 +1452,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         # deferral; with one join per batch the captured step follows the eager trajectory.)
         defer = DEFER_DECODER_WGRAD_F32S if ctx.cdt == F32S else DEFER_DECODER_WGRAD
         group = WGRAD_GROUP_CAPTURE if ctx.capturing else WGRAD_GROUP
-        if defer and bn is None and ctx.side_stream() is not None and (not ctx.capturing or os.environ.get("VINET_DBG_DEFER_IN_CAPTURE", "1") != "0"):
+        if defer and bn is None and ctx.side_stream() is not None:
             ctx._deferred.append(wgrad_job)
         elif group > 1 and ctx.side_stream() is not None:
             # weight-gradient jobs leave for their stream `group` at a time behind one join (fewer fork points: every join is an
@@ -1567,13 +1615,13 @@ def unfold1d_forward(ctx, x, k, stride, pad):
 #              so `torch.autograd.grad(loss, params)`, gradient hooks and torch's DistributedDataParallel (whose
 #              reducer hangs its bucket hooks on those nodes, train.py:181-185 wraps the reference module the same
 #              way with nn.DataParallel) see this module like any nn.Module.  Costs one fill + one add per parameter.
-_PARAM_GRAD_MODE = os.environ.get("VINET_PARAM_GRAD_MODE", "fused")
+_PARAM_GRAD_MODE = "fused"
 
 
 def set_param_grad_mode(mode):
-    global _PARAM_GRAD_MODE
+    global _PARAM_GRAD_MODE, PARAM_GRAD_MODE
     assert mode in ("fused", "autograd")
-    _PARAM_GRAD_MODE = mode
+    _PARAM_GRAD_MODE = PARAM_GRAD_MODE = mode
 
 
 def param_grad_mode():

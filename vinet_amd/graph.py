@@ -109,7 +109,7 @@ class GraphedTrainStep:
             import copy
             opt.load_state_dict(copy.deepcopy(snap_sd))
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
-        if debug_dot:                          # hipGraphDebugDotPrint of the captured step (tools/dbg_defer.py)
+        if debug_dot:                          # hipGraphDebugDotPrint of the captured step (tools/dot_edges.py)
             self.graph.enable_debug_mode()
         # (a garbage collection inside the capture could drop plans from the pack registry, whose job table would then be
         # rebuilt -- a host-to-device copy -- in the captured region)
@@ -117,7 +117,7 @@ class GraphedTrainStep:
         gc.disable()
         try:
             with torch.cuda.graph(self.graph):
-                if launch_log:                 # (tools/dbg_defer.py: which launch went to which stream, in issue order)
+                if launch_log:                 # (which launch went to which stream, in issue order)
                     engine.LAUNCH_LOG = self.launch_log = []
                     self.capture_stream = torch.cuda.current_stream().cuda_stream
                 self.static_loss = self._body()

@@ -31,7 +31,7 @@ import torch.distributed as dist
 # Functional testing on ONE GPU: treat a single-rank process group as distributed, so that every collective of the N > 1 path
 # (flat broadcast, bucketed all-reduce on the communication stream with its event joins, scalar means) really goes through
 # RCCL.  RCCL refuses two ranks on one device, so this is the only way to execute it without a multi-GPU node.
-FORCE_COLLECTIVES = os.environ.get("VINET_FORCE_COLLECTIVES", "0") == "1"
+FORCE_COLLECTIVES = False      # (bench.py --force-collectives; tests set the attribute)
 
 
 def distributed():
@@ -51,7 +51,7 @@ def init_from_env(backend=None):
     if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or os.environ.get("VINET_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        backend = backend or ("nccl" if use_cuda else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local, device
 
@@ -216,8 +216,13 @@ class GradientBuckets:
                 if self._t0 is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+                work = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+                self._works.append(work)
                 if self._t0 is not None:
+                    # RCCL runs the collective on the process group's OWN stream: an event recorded on `comm` right behind the
+                    # call would stamp its issue, not its end.  work.wait() makes `comm` wait for the collective's end event
+                    # (no host block with the nccl backend), so e1 is the completion stamp.  Timing mode only.
+                    work.wait()
                     e1.record()
                     self._ev.append((b, (hi - lo) * 4, e0, e1))
         else:
