@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 11
+#define VINET_ABI_VERSION 12
 
 enum { VINET_F32 = 0, VINET_BF16 = 1,
        /* conv / weight-gradient descriptors only: fp32 tensors (as VINET_F32), bf16 matrix arithmetic on a two-term split of both
@@ -143,8 +143,10 @@ typedef struct VinetConvDesc {
    * BatchNorm (scale, shift, relu: the ReLU gate is scale * z + shift > 0), bnb_mean / bnb_invstd its batch statistics.
    * With bnb_partials != NULL the launch ALSO writes the partial sums of vinet_bn_bwd_reduce(g, z) -- [rows][2][C] fp32,
    * rows = vinet_conv3d_bn_bwd_stats_rows(desc) -- so the caller skips that pass (train.py:193 -> model_utils.py:145: the
-   * stem's first BatchNorm, whose gradient comes out of the fused temporal data gradient, tline == 3).  Only where the rows
-   * query returns > 0; accumulate must be 0. */
+   * stem's first BatchNorm, whose gradient comes out of the fused temporal data gradient, tline == 3; ABI 12: every BatchNorm
+   * whose output gradient is last written by a data gradient of the shared conv epilogue -- model_utils.py:132,145,149).  The sums
+   * are formed on the values the launch STORES (rounded to y's dtype; with accumulate != 0 on old + new, so the caller must make
+   * this launch the last writer of y).  Only where the rows query returns > 0.  tline == 3: accumulate must be 0. */
   const void* bnb_z;
   int32_t bnb_ld;
   int64_t bnb_sB;

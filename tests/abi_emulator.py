@@ -220,8 +220,27 @@ class AbiEmulator:
         g = _gather(g, np.arange(oW) * d.sW + dw_, 3, x.shape[3])
         return g
 
+    def _bnb_epi_ok(self, d):
+        """conv_api.hip::bnb_epi_ok -- the shared conv epilogue forms the BatchNorm-backward sums for bf16 data gradients that cover y
+        densely in one launch, with whole 8-channel groups, plain inputs (the library also excludes the kernels with their own
+        epilogues; the model has no kernel selection, so it folds wherever the CONTRACT allows)"""
+        if not (d.bnb_z and d.bnb_mean and d.bnb_invstd) or (d.bnb_fwd.relu and not (d.bnb_fwd.scale and d.bnb_fwd.shift)):
+            return False
+        if d.dtype != BF16 or d.out_dtype != BF16 or d.mode != 0 or d.stats or d.act or d.out_scale or d.out_shift:
+            return False
+        if d.n_valid > 0 and d.n_valid != d.y.C:
+            return False
+        if (d.omT, d.omH, d.omW, d.ooT, d.ooH, d.ooW) != (1, 1, 1, 0, 0, 0) or (d.y.T, d.y.H, d.y.W) != (d.oT, d.oH, d.oW):
+            return False
+        if d.y.C % 8 or d.y.ld % 8 or d.y.sB % 8 or d.bnb_ld % 8 or d.bnb_sB % 8 or d.bnb_ld < d.y.C or d.pre.scale or d.pre.relu:
+            return False
+        return True
+
     def vinet_conv3d_bn_bwd_stats_rows(self, d):
-        return 0          # the model never folds the BatchNorm-backward reduce pass into a data gradient
+        d = _deref(d)
+        if d.tline == 3:
+            return 0      # (the fused temporal data gradient of the stem: not modelled with statistics)
+        return self.vinet_conv3d_stats_rows(d) if self._bnb_epi_ok(d) else 0
 
     @_plain_f32
     def vinet_conv3d_fuses_dgrad_phases(self, d):
@@ -307,6 +326,17 @@ class AbiEmulator:
             old = y[sl]
             acc = acc + (old if d.out_dtype == F32 else _bf2f(np.ascontiguousarray(old)))
         y[sl] = acc.astype(np.float32) if d.out_dtype == F32 else _f2bf(acc).reshape(acc.shape)
+        if d.bnb_partials:
+            # the partial sums of vinet_bn_bwd_reduce(y, bnb_z) on the values just stored (rounded, accumulated)
+            assert self._bnb_epi_ok(d), "bnb_partials set for a problem whose rows query returns 0"
+            zt = L.CTensor(d.bnb_z, d.y.B, d.y.T, d.y.H, d.y.W, d.y.C, d.bnb_ld, d.bnb_sB)
+            g, xhat = self._bn_bwd_terms(d.y, zt, d.out_dtype, d.bnb_fwd, d.bnb_mean, d.bnb_invstd)
+            rows = self.vinet_conv3d_stats_rows(d)
+            P = _f32(d.bnb_partials, rows * 2 * N).reshape(rows, 2, N)
+            P[...] = 0
+            P[0, 0] = g.reshape(-1, N).astype(np.float64).sum(0)
+            P[0, 1] = (g * xhat).reshape(-1, N).astype(np.float64).sum(0)
+            self.calls.append("conv3d+bnb")
         return 0
 
     @_plain_f32

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libvinet_hip.so")
-SOURCES = ["conv_api.hip", "conv_bf16.hip", "conv_f32.hip", "conv_wgrad.hip", "wgrad_dma.hip", "wgrad_pp.hip", "wgrad_ts.hip", "conv_ts.hip", "wgrad_hs.hip", "wgrad_rs.hip", "wgrad_tf.hip", "conv_hs.hip", "layout.hip", "bn.hip", "pool.hip", "resample.hip", "loss_adam.hip", "postproc.hip", "preproc.hip"]
+SOURCES = ["conv_api.hip", "conv_bf16.hip", "conv_bnb.hip", "conv_f32.hip", "conv_wgrad.hip", "wgrad_dma.hip", "wgrad_pp.hip", "wgrad_ts.hip", "conv_ts.hip", "wgrad_hs.hip", "wgrad_rs.hip", "wgrad_tf.hip", "conv_hs.hip", "layout.hip", "bn.hip", "pool.hip", "resample.hip", "loss_adam.hip", "postproc.hip", "preproc.hip"]
 import glob
 # every header of csrc/ and include/ is a dependency of every object (a stale object travelling to the GPU box is worse
 # than a rebuild of 20 files)
@@ -29,7 +29,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.j
 # the asm owns (conv_pw.h: the global-load ring with counted vmcnt; pool.hip: routing on the EXEC mask).  A vector-register spill
 # in one of them would read in-flight data: the build FAILS on it instead of shipping silently wrong kernels.  Checked from
 # hipcc's own -Rpass-analysis=kernel-resource-usage remarks of the same compilation (pinned toolchain: ROCm 7.2 / clang 22).
-GUARDED = {"conv_bf16.hip": ("conv_pw_kernel",), "pool.hip": ("maxpool_bwd",)}
+GUARDED = {"conv_bf16.hip": ("conv_pw_kernel",), "pool.hip": ("maxpool_bwd",), "conv_bnb.hip": ()}     # (conv_bnb.hip: resource table only)
 RESOURCES = os.path.join(CSRC, "obj", "kernel_resources.json")
 
 
@@ -114,10 +114,11 @@ def build(force=False, verbose=True):
         if verbose:
             print("[vinet_amd.build] compiling %d file(s) for gfx950 ..." % len(jobs), flush=True)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
-            resources = {}
+            resources, failed = {}, None
             for s, rc, out, res in ex.map(compile_one, jobs):
                 if rc != 0:
-                    raise RuntimeError("hipcc failed on %s:\n%s" % (s, out))
+                    failed = failed or RuntimeError("hipcc failed on %s:\n%s" % (s, out))
+                    continue
                 if res is not None:
                     resources[os.path.basename(s)] = res
                 if verbose and out.strip():
@@ -133,6 +134,8 @@ def build(force=False, verbose=True):
             allres.update(resources)
             with open(RESOURCES, "w") as f:
                 json.dump(allres, f, indent=1, sort_keys=True)
+        if failed is not None:
+            raise failed
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -28,7 +28,7 @@ extern int g_vinet_opt_splitk;
 // may this launch split its K loop?  (no statistics, no accumulation, and scratch lent -- or, for the size query that
 // precedes the lending, assumed lent)
 static bool vinet_conv_may_split(const VinetConvDesc* d, bool query) {
-  return g_vinet_opt_splitk && d->dtype == VINET_BF16 && !d->stats && !d->accumulate && (query || d->splitk_ws != nullptr);
+  return g_vinet_opt_splitk && d->dtype == VINET_BF16 && !d->stats && !d->accumulate && !d->bnb_partials && (query || d->splitk_ws != nullptr);
 }
 
 // Largest BN whose padded width is within 25% of the best achievable padding;
@@ -147,6 +147,8 @@ static int fill_args(const VinetConvDesc* d, ConvArgs& a, ConvTile& t) {
   a.splits = 1; a.chunks_per_split = 0; a.ws = nullptr;
   a.ht_tilesH = a.ht_tilesW = 0;
   a.ht_dN = a.ht_dW = a.ht_dH = a.ht_dTo = make_fastdiv(1);
+  a.bnb_z = nullptr; a.bnb_partials = nullptr; a.bnb_scale = a.bnb_shift = a.bnb_mean = a.bnb_invstd = nullptr;
+  a.bnb_ldz = 0; a.bnb_sBz = 0; a.bnb_z_linear = 0; a.bnb_relu = 0;
   return 0;
 }
 
@@ -185,6 +187,7 @@ extern int g_vinet_opt_wgrad_rs4;
 extern int g_vinet_opt_wgrad_tf;
 extern int g_vinet_opt_wgrad_skinny;
 extern int g_vinet_opt_bn_lean;
+extern int g_vinet_opt_bnb_epi;
 extern int g_vinet_opt_bn_rows;
 extern int g_vinet_opt_pack_tiled;
 extern int g_vinet_opt_wgrad_pp_cap;
@@ -245,6 +248,7 @@ int g_vinet_opt_wgrad_tg = 0;   // tuning: force taps per group in the DMA wgrad
 extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
   if (name && !strcmp(name, "dma3")) { g_vinet_opt_dma3 = value; return 0; }
+  if (name && !strcmp(name, "bnb_epi")) { g_vinet_opt_bnb_epi = value; return 0; }
   if (name && !strcmp(name, "pw")) { g_vinet_opt_pw = value; return 0; }
 #ifndef VINET_EXPERIMENTS
   // measured-slower variants live in side builds only (python -c "from vinet_amd import build; build.build_variant('exp', ['-DVINET_EXPERIMENTS'])")
@@ -455,7 +459,7 @@ int g_vinet_opt_sk_tile = 7;    // bit 0: 128 x 192 tiles, bit 1: 128 x 128 tile
 struct SplitK { int splits, per; long bytes; };
 static SplitK splitk_plan(const VinetConvDesc* d, bool query) {
   SplitK p{1, 0, 0};
-  if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || use_ht(d) || use_pw(d) || vinet_conv_use_ts(d) || vinet_conv_use_hs(d) || d->stats || d->accumulate) return p;
+  if (!g_vinet_opt_splitk || !use_dma(d) || use_pp(d) || use_ht(d) || use_pw(d) || vinet_conv_use_ts(d) || vinet_conv_use_hs(d) || d->stats || d->accumulate || d->bnb_partials) return p;
   const long M = (long)d->x.B * d->oT * d->oH * d->oW;
   const int nchunks = d->ntaps * (d->Kp / 32);
   const ConvTile t = vinet_pick_conv_tile(d->dtype, d->mode, M, d->y.C, nchunks, vinet_conv_may_split(d, query));
@@ -570,8 +574,29 @@ extern "C" int vinet_conv3d_applies_pre_once(const VinetConvDesc* d) {
 }
 
 int vinet_conv_tsd_bnb_rows(const VinetConvDesc* d);
+int g_vinet_opt_bnb_epi = 1;     // BatchNorm-backward partial sums out of the shared conv epilogue (0 = only the fused temporal data gradient)
+// The shared epilogue (conv_igemm.h: conv_epilogue, bf16 fast path) forms the sums for any bf16 data gradient that covers y densely
+// (one launch = the whole extent: unit output strides, no offsets) with whole 8-channel groups, in the kernels whose waves hold
+// at most four row groups (conv_dma, conv_ht, the register-staged kernel); not the ping-pong kernel (register budget), the
+// pointwise streaming kernel and the stem's streaming kernels (own epilogues), split-K launches or fp32 tensors.
+int vinet_launch_conv_dma_bnb(const ConvTile& t, const ConvArgs& a, hipStream_t s);
+int vinet_launch_conv_ht_bnb(int nt, int tw, int tm, const ConvArgs& a, hipStream_t s);
+static bool bnb_epi_ok(const VinetConvDesc* d) {
+  if (!g_vinet_opt_bnb_epi || !d->bnb_z || !d->bnb_mean || !d->bnb_invstd) return false;
+  if (d->bnb_fwd.relu && !(d->bnb_fwd.scale && d->bnb_fwd.shift)) return false;
+  if (d->dtype != VINET_BF16 || d->out_dtype != VINET_BF16 || d->mode != VINET_CONV_GENERIC) return false;
+  if (d->stats || d->act != VINET_ACT_NONE || d->out_scale || d->out_shift || (d->n_valid > 0 && d->n_valid != d->y.C)) return false;
+  if (d->omT != 1 || d->omH != 1 || d->omW != 1 || d->ooT || d->ooH || d->ooW || d->y.T != d->oT || d->y.H != d->oH || d->y.W != d->oW) return false;
+  if (d->y.C % 8 || d->y.ld % 8 || d->y.sB % 8 || ((uintptr_t)d->y.ptr) % 16) return false;
+  if (d->bnb_ld % 8 || d->bnb_sB % 8 || ((uintptr_t)d->bnb_z) % 16 || d->bnb_ld < d->y.C) return false;
+  if (d->pre.scale || d->pre.relu || !use_dma(d)) return false;       // (data gradients read plain tensors)
+  if (vinet_conv_use_hs(d) || vinet_conv_use_ts(d) || use_pw(d) || (!use_ht(d) && use_pp(d))) return false;
+  return true;
+}
 extern "C" int vinet_conv3d_bn_bwd_stats_rows(const VinetConvDesc* d) {
-  return (d && d->tline == 3) ? vinet_conv_tsd_bnb_rows(d) : 0;      // (only the fused temporal data gradient folds the reduce pass in)
+  if (!d) return 0;
+  if (d->tline == 3) return vinet_conv_tsd_bnb_rows(d);      // the fused temporal data gradient of the stem
+  return bnb_epi_ok(d) ? vinet_conv3d_stats_rows(d) : 0;
 }
 
 extern "C" int vinet_conv3d_fuses_dgrad_phases(const VinetConvDesc* d) {
@@ -587,6 +612,13 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
   ConvTile t;
   int rc = fill_args(d, a, t);
   if (rc) return rc;
+  if (d->bnb_partials) {
+    VN_CHECK_ARG(bnb_epi_ok(d), "conv: the BatchNorm-backward statistics (bnb_*) are not available for this problem; ask vinet_conv3d_bn_bwd_stats_rows first");
+    a.bnb_z = (const char*)d->bnb_z; a.bnb_ldz = d->bnb_ld; a.bnb_sBz = d->bnb_sB;
+    a.bnb_z_linear = (d->bnb_sB == (int64_t)d->y.T * d->y.H * d->y.W * d->bnb_ld) ? 1 : 0;
+    a.bnb_relu = d->bnb_fwd.relu; a.bnb_scale = d->bnb_fwd.scale; a.bnb_shift = d->bnb_fwd.shift;
+    a.bnb_mean = d->bnb_mean; a.bnb_invstd = d->bnb_invstd; a.bnb_partials = d->bnb_partials;
+  }
   if (vinet_conv_use_hs(d)) return vinet_launch_conv_hs(d, (hipStream_t)stream);
   if (vinet_conv_use_ts(d)) return vinet_launch_conv_ts(d, (hipStream_t)stream);
   if (use_pw(d)) {
@@ -612,6 +644,7 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
     }
     a.ht_dN = make_fastdiv((uint32_t)a.tilesN); a.ht_dW = make_fastdiv((uint32_t)a.ht_tilesW);
     a.ht_dH = make_fastdiv((uint32_t)a.ht_tilesH);
+    if (a.bnb_partials) return vinet_launch_conv_ht_bnb(h.nt, h.tw, h.tm, a, (hipStream_t)stream);
     return d->dtype == VINET_F32S ? vinet_launch_conv_ht_f32s(h.nt, h.tw, h.tm, h.pre, a, (hipStream_t)stream)
                                   : vinet_launch_conv_ht_bf16(h.nt, h.tw, h.tm, h.pre, a, (hipStream_t)stream);
   }
@@ -634,6 +667,7 @@ extern "C" int vinet_conv3d(const VinetConvDesc* d, void* stream) {
       else hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)vn_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
       return vn_launch_status("conv_splitk_finish");
     }
+    if (a.bnb_partials) return vinet_launch_conv_dma_bnb(t, a, (hipStream_t)stream);
     return vinet_launch_conv_dma_bf16(t, a, (hipStream_t)stream);
   }
   if (use_dma3(d)) {

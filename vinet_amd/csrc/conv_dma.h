@@ -59,7 +59,7 @@ template <int N> VN_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :
 // SIMD the wave's DMA issue (~6 x 120 cycles), address VALU and MFMAs serialise (1900 cycles
 // per K step for 384 cycles of MFMA, s_memtime) and the epilogue's write burst overlaps with
 // nothing; a second resident workgroup fills both gaps.
-template <int MT, int NT, int WARPS_M, int WARPS_N, int STAGES, bool PRE>
+template <int MT, int NT, int WARPS_M, int WARPS_N, int STAGES, bool PRE, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   using Cfg = ConvDmaCfg<MT, NT, WARPS_M, WARPS_N, STAGES, PRE>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, A_LOADS = Cfg::A_LOADS, B_LOADS = Cfg::B_LOADS;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
       }
     return;
   }
-  conv_epilogue<MT, NT, WARPS_M, WARPS_N>(a, acc, smem, tile_m, tile_n);
+  conv_epilogue<MT, NT, WARPS_M, WARPS_N, BNB>(a, acc, smem, tile_m, tile_n);
 #ifdef VINET_CONV_TIMING
   if (tid == 0 && a.out_shift) {   // tuning build only: out_shift doubles as a [grid][4] float dump
     const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
@@ -269,10 +269,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int MT, int NT, int WM, int WN, int STAGES, bool PRE>
+template <int MT, int NT, int WM, int WN, int STAGES, bool PRE, bool BNB = false>
 static int launch_conv_dma_cfg(const ConvArgs& a, hipStream_t s) {
   using Cfg = ConvDmaCfg<MT, NT, WM, WN, STAGES, PRE>;
-  auto kern = conv_dma_kernel<MT, NT, WM, WN, STAGES, PRE>;
+  auto kern = conv_dma_kernel<MT, NT, WM, WN, STAGES, PRE, BNB>;
   static bool attr_done[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -53,6 +53,16 @@ struct ConvArgs {
   // spatial halo tiles (conv_ht.h): tiles per image in H and W, workgroup index -> (column tile, spatial tile) decode
   int ht_tilesH, ht_tilesW;
   FastDiv ht_dN, ht_dW, ht_dH, ht_dTo;
+  // BatchNorm-backward partial sums out of a data gradient's epilogue (VinetConvDesc::bnb_*, round 5): y is the gradient g behind
+  // relu(bnb_scale * z + bnb_shift) (z = bnb_z: same extent as y, own row / clip strides); the launch also writes the partial
+  // sums of vinet_bn_bwd_reduce(g, z) -- (sum g * gate, sum g * gate * (z - mean) * invstd) per channel -- one row per
+  // statistics row of the kernel ([rows][2][N], like `stats`), formed on the ROUNDED values the launch stores (after the
+  // accumulation when accumulate is set: the launch must then be the LAST writer of y).
+  const char* bnb_z;
+  int bnb_ldz, bnb_z_linear, bnb_relu;
+  long bnb_sBz;
+  const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
+  float* bnb_partials;
 };
 
 // logical M-tile index -> tile position in memory order
@@ -72,14 +82,24 @@ template <int MT, int NT>
 constexpr int conv_epi_wave_bytes() {
   constexpr int WNC = NT * 16;
   // (tiles of more than four row groups per wave -- conv_pp.h -- keep the 16-byte stores: their image would not fit)
+#ifdef VINET_EXPERIMENTS
   constexpr int general = 16 * (WNC + 4) * 4, image = MT <= 4 ? MT * 16 * WNC * 2 + MT * 16 * 8 : 0;
+#else
+  // (the row image belongs to the `epi_rows` option, a side-build experiment: the shipped kernels must not pay its LDS --
+  //  with it the 256 x 128 conv_dma tile needed 84 KB and ran ONE workgroup per CU)
+  constexpr int general = 16 * (WNC + 4) * 4, image = 0;
+#endif
   return general > image ? general : image;
 }
+// partial rows per wave row in the workgroup's statistics table: 4 for the forward statistics (lanes p = 0..3 of a row after two
+// DPP rotations), 8 for the BatchNorm-backward sums, which are formed behind the permlane swap, where the two halves q & 1 of a
+// wave hold the same channels of different row groups
+constexpr int CONV_EPI_RED_ROWS = 8;
 template <int MT, int NT, int WARPS_M, int WARPS_N>
 constexpr int conv_epi_bytes() {
   constexpr int W = WARPS_M * WARPS_N, WNC = NT * 16, BN = WNC * WARPS_N;
-  // per-wave staging + statistics table: 4 partial rows per wave row
-  return W * conv_epi_wave_bytes<MT, NT>() + 4 * WARPS_M * BN * 2 * 4;
+  // per-wave staging + statistics table: up to CONV_EPI_RED_ROWS partial rows per wave row
+  return W * conv_epi_wave_bytes<MT, NT>() + CONV_EPI_RED_ROWS * WARPS_M * BN * 2 * 4;
 }
 
 // SPLIT (T = float only; VINET_F32S): fp32 tensors in memory, bf16 matrix arithmetic on a two-term split of every operand --
@@ -169,7 +189,11 @@ VN_DEV uint32_t pk_relu_bf16(uint32_t u) {
 }
 
 // `rows` (optional): see EpiRows; default = rows tile_m*BM + ... as usual.  `tile_m` stays the statistics row of the workgroup.
-template <int MT, int NT, int WARPS_M, int WARPS_N>
+// BNB: the instantiation that can also form the BatchNorm-backward partial sums (ConvArgs::bnb_*).  A template parameter, not a
+// run-time branch: the sums need ~50 more live registers in the store loop, and as a run-time path they raised the register
+// allocation of EVERY kernel that shares this epilogue (conv_dma<4,4,2,2>: 64 -> 127 VGPRs, 4 -> 2 waves per SIMD).  The BNB
+// kernels are instantiated in their own translation unit (conv_bnb.hip) for plain-input conv_dma / conv_ht shapes only.
+template <int MT, int NT, int WARPS_M, int WARPS_N, bool BNB = false>
 VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem, int tile_m, int tile_n, const EpiRows rows = EpiRows{0, -1, 0, 0, 0}) {
   constexpr int BM = 16 * MT * WARPS_M, BN = 16 * NT * WARPS_N;
   static_assert(MT % 2 == 0, "row groups are handled in pairs");
@@ -178,10 +202,12 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
   constexpr int WNC = NT * 16, EROW = WNC + 4;
   const int p = lane & 15, q = lane >> 4;              // my voxel inside a row group, my channel quad inside a column tile
   float* Ew = (float*)(smem + wave * conv_epi_wave_bytes<MT, NT>());
-  float* red = (float*)(smem + conv_epi_bytes<MT, NT, WARPS_M, WARPS_N>() - 4 * WARPS_M * BN * 2 * 4);
+  float* red = (float*)(smem + conv_epi_bytes<MT, NT, WARPS_M, WARPS_N>() - CONV_EPI_RED_ROWS * WARPS_M * BN * 2 * 4);
   const int m_wave = tile_m * BM + wm * MT * 16;
   const int n_wave = tile_n * BN + wn * WNC;
   const bool do_stats = a.stats != nullptr;
+  // (tiles of more than four row groups per wave -- conv_pp.h -- do not carry the BatchNorm-backward sums: register budget)
+  const bool do_bnb = BNB && MT <= 4 && a.bnb_partials != nullptr;
   const bool relu = a.act == VINET_ACT_RELU;
   const float relu_floor = relu ? 0.f : -INFINITY;   // branch-free ReLU: max(v, floor)
   const EpiRows er = rows.ipr >= 0 ? rows : EpiRows{m_wave, 0, 0, 0, 0};      // (ipr == -1: the default row-tiled map)
@@ -246,8 +272,16 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
     auto img_swz = [](int row) { return (row / IMG_P) & (IMG_G - 1); };
     char* const img = (char*)Ew;
     long* const rowoff = (long*)(img + MT * 16 * WNC * 2);
-    long voff[NP];
+    long voff[NP], zoff[NP];
     bool vok[NP];
+    // element offset of voxel m in z (bnb: y is placed densely over its whole extent, so voxel m of the iteration space is
+    // voxel m of z's extent as well)
+    auto z_off = [&](int m) {
+      if (a.bnb_z_linear) return (long)m * a.bnb_ldz;
+      int b, to, ho, wo;
+      decode_m(m, a.dW, a.dH, a.dT, b, to, ho, wo);
+      return (long)b * a.bnb_sBz + ((long)(to * a.yH + ho) * a.yW + wo) * (long)a.bnb_ldz;
+    };
     if (staged) {
 #pragma unroll
       for (int r0 = 0; r0 < MT * 16; r0 += 64) {
@@ -262,6 +296,7 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
         const int ig = 2 * k + (q & 1);
         vok[k] = p < group_rows(ig);
         voff[k] = vok[k] ? voxel_off(group_m0(ig) + p) : 0;
+        if constexpr (BNB) zoff[k] = (do_bnb && vok[k]) ? z_off(group_m0(ig) + p) : 0;
       }
     }
 #pragma unroll
@@ -277,6 +312,38 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
         for (int k = 0; k < NP; ++k)
           old[k] = (vok[k] && nok8) ? *(const uint4*)((const bf16_t*)a.y + voff[k] + n8) : make_uint4(0, 0, 0, 0);
       }
+      // BatchNorm-backward sums of my 8 channels n8 .. n8 + 7 over my voxels (one per row-group pair)
+      uint4 zl[NP];
+      float bsc[8], bsh[8], bmu[8], bs[8], bp[8];
+      if constexpr (BNB) if (do_bnb) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+          zl[k] = (vok[k] && nok8) ? *(const uint4*)((const bf16_t*)a.bnb_z + zoff[k] + n8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bs[e] = 0.f; bp[e] = 0.f;
+          bsc[e] = (nok8 && a.bnb_scale) ? a.bnb_scale[n8 + e] : 1.f;
+          bsh[e] = (nok8 && a.bnb_shift) ? a.bnb_shift[n8 + e] : 0.f;
+          bmu[e] = nok8 ? a.bnb_mean[n8 + e] : 0.f;
+        }
+      }
+      // g = the 8 bf16 this lane stores for pair k (rounded, accumulated): gate with the forward ReLU, add to the sums.
+      // Lanes outside the iteration space contribute nothing.
+      auto bnb_acc = [&](int k, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+        if (!(vok[k] && nok8)) return;
+        const uint32_t ow[4] = {o0, o1, o2, o3}, zw[4] = {zl[k].x, zl[k].y, zl[k].z, zl[k].w};
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          float g0 = __uint_as_float(ow[h] << 16), g1 = __uint_as_float(ow[h] & 0xffff0000u);
+          const float z0 = __uint_as_float(zw[h] << 16), z1 = __uint_as_float(zw[h] & 0xffff0000u);
+          if (a.bnb_relu) {
+            if (!(fmaf(z0, bsc[2 * h], bsh[2 * h]) > 0.f)) g0 = 0.f;
+            if (!(fmaf(z1, bsc[2 * h + 1], bsh[2 * h + 1]) > 0.f)) g1 = 0.f;
+          }
+          bs[2 * h] += g0; bp[2 * h] = fmaf(g0, z0 - bmu[2 * h], bp[2 * h]);
+          bs[2 * h + 1] += g1; bp[2 * h + 1] = fmaf(g1, z1 - bmu[2 * h + 1], bp[2 * h + 1]);
+        }
+      };
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         float v0[4], v1[4];
@@ -317,6 +384,7 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
           } else if (vok[k] && nok8) {
             *(uint4*)((bf16_t*)a.y + voff[k] + n8) = make_uint4(x0, x1, y0, y1);
           }
+          if constexpr (BNB) if (do_bnb) bnb_acc(k, x0, x1, y0, y1);
         } else {
           // y += result: ONE rounding, of old + new in fp32
 #pragma unroll
@@ -331,9 +399,25 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
           o[2] = cvt_pk_bf16_f32(v1[0] + __uint_as_float(ow[2] << 16), v1[1] + __uint_as_float(ow[2] & 0xffff0000u));
           o[3] = cvt_pk_bf16_f32(v1[2] + __uint_as_float(ow[3] << 16), v1[3] + __uint_as_float(ow[3] & 0xffff0000u));
           if (vok[k] && nok8) *(uint4*)((bf16_t*)a.y + voff[k] + n8) = make_uint4(o[0], o[1], o[2], o[3]);
+          if constexpr (BNB) if (do_bnb) bnb_acc(k, o[0], o[1], o[2], o[3]);
         }
       }
       if (do_stats) put_stats(j, ss, qq);
+      if constexpr (BNB) if (do_bnb) {
+        // the 16 lanes of a row hold 16 voxels of the same 8 channels: two DPP rotations leave lanes p = 0..3 with four partial
+        // sums; rows q and q ^ 1 hold the same channels of the other row group of each pair -> 8 partial rows per wave row
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bs[e] = row16_sum4(bs[e]); bp[e] = row16_sum4(bp[e]); }
+        if (p < 4 && nok8) {
+          const int col = wn * WNC + j * 16 + (q >> 1) * 8;
+          float* dst = red + ((long)(wm * 8 + (q & 1) * 4 + p) * BN + col) * 2;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const float i0 = a.bnb_invstd[n8 + e], i1 = a.bnb_invstd[n8 + e + 1];
+            *(float4*)(dst + 2 * e) = make_float4(bs[e], bp[e] * i0, bs[e + 1], bp[e + 1] * i1);
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: hoisted accumulator reads of later tiles spill
     }
     if (staged) {
@@ -459,6 +543,18 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
         for (int w2 = 0; w2 < 4 * WARPS_M; ++w2) { ss += red[(w2 * BN + tid) * 2]; qq += red[(w2 * BN + tid) * 2 + 1]; }
         a.stats[((long)tile_m * 2 + 0) * a.N + n] = ss;
         a.stats[((long)tile_m * 2 + 1) * a.N + n] = qq;
+      }
+    }
+  } else if (BNB && do_bnb) {
+    __syncthreads();
+    if (tid < BN) {
+      const int n = tile_n * BN + tid;
+      if (n < a.N) {
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 8 * WARPS_M; ++w2) { ss += red[(w2 * BN + tid) * 2]; qq += red[(w2 * BN + tid) * 2 + 1]; }
+        a.bnb_partials[((long)tile_m * 2 + 0) * a.N + n] = ss;
+        a.bnb_partials[((long)tile_m * 2 + 1) * a.N + n] = qq;
       }
     }
   }

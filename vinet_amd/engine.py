@@ -290,18 +290,22 @@ class View:
 class Act:
     """activation = view + pending affine/relu + gradient bookkeeping."""
     __slots__ = ("v", "scale", "shift", "relu", "_grad", "grad_ready", "needs_grad", "parent", "pc0", "pt0", "fold",
-                 "indep", "ready_of", "grad_marks", "bn_keep", "bnb_part", "act_out", "grad_masked")
+                 "indep", "ready_of", "grad_marks", "mean", "invstd", "alias_of", "n_readers", "bnb_regs", "act_out", "grad_masked")
 
-    def __init__(self, v, scale=None, shift=None, relu=False, needs_grad=False):
+    def __init__(self, v, scale=None, shift=None, relu=False, needs_grad=False, mean=None, invstd=None):
         self.v, self.scale, self.shift, self.relu = v, scale, shift, relu
+        # batch statistics of the training-mode BatchNorm(s) behind the pending affine (per channel, fp32; slices follow the
+        # channel slices like scale / shift): what a consumer's data gradient needs to fold the BatchNorm-backward reduce pass in
+        self.mean, self.invstd = mean, invstd
         self._grad, self.grad_ready, self.needs_grad = None, False, needs_grad
         self.parent, self.pc0, self.pt0 = None, 0, 0
         self.fold = None
         self.indep = False       # channel region with its own "gradient written" flag (see region())
         self.ready_of = None     # span over several regions: ready when all of them are
         self.grad_marks = 0      # writers of this gradient so far (mark_grad_ready calls on the root)
-        self.bn_keep = None      # training-mode BatchNorm of the producing conv: dict(mean, invstd) (conv_forward)
-        self.bnb_part = None     # (partials, rows, grad_marks): BN-backward partial sums a data gradient left with the gradient
+        self.alias_of = None     # the pending activation this plain one materialises with shared gradient storage (materialize)
+        self.n_readers = 0       # consumers recorded in this forward that will write this gradient (counted on the root)
+        self.bnb_regs = None     # storage owner only: [(c0, c1, partials, rows, root, marks)] BN-backward partial sums that data gradients left
         self.act_out = 0         # activation the producing conv applied in its epilogue (no BatchNorm): conv_forward
         self.grad_masked = -1    # grad_marks at which the gradient already carries that activation's backward (upsample2x backward)
 
@@ -315,7 +319,8 @@ class Act:
     def sub_chan(self, c0, c1):
         """channel slice sharing gradient storage with self (concat member)."""
         a = Act(self.v.chan(c0, c1), None if self.scale is None else self.scale[c0:c1],
-                None if self.shift is None else self.shift[c0:c1], self.relu, self.needs_grad)
+                None if self.shift is None else self.shift[c0:c1], self.relu, self.needs_grad,
+                None if self.mean is None else self.mean[c0:c1], None if self.invstd is None else self.invstd[c0:c1])
         a.parent, a.pc0, a.pt0 = self, c0, None
         return a
 
@@ -328,7 +333,7 @@ class Act:
         return a
 
     def sub_t(self, t0, t1):
-        a = Act(self.v.tslice(t0, t1), self.scale, self.shift, self.relu, self.needs_grad)
+        a = Act(self.v.tslice(t0, t1), self.scale, self.shift, self.relu, self.needs_grad, self.mean, self.invstd)
         a.parent, a.pt0, a.pc0 = self, t0, None
         return a
 
@@ -368,6 +373,52 @@ class Act:
         r = self.root()
         r.grad_ready = True
         r.grad_marks += 1
+
+
+def _abs_chan(a):
+    """(storage owner, absolute channel offset) of an activation inside the buffer that owns its gradient storage; None when a
+    T slice lies on the way (decoder concat members: no BatchNorm there)"""
+    off = 0
+    while a.parent is not None:
+        if a.pc0 is None:
+            return None
+        off += a.pc0
+        a = a.parent
+    return a, off
+
+
+def _note_reader(ctx, x):
+    """forward: one more consumer of `x` whose backward will write x's gradient"""
+    if ctx.recording and x.needs_grad:
+        x.root().n_readers += 1
+
+
+def _register_bnb(x, ws, rows):
+    """a data gradient just wrote x's gradient (already marked) together with the BatchNorm-backward partial sums `ws`
+    ([rows][2][x.C]) of the layer(s) behind x's pending affine: remember them with the writer count of that moment -- they are
+    valid as long as no later writer touches the gradient (_find_bnb checks)"""
+    loc = _abs_chan(x)
+    if loc is None:
+        return
+    owner, off = loc
+    if owner.bnb_regs is None:
+        owner.bnb_regs = []
+    r = x.root()
+    owner.bnb_regs.append((off, off + x.v.C, ws, rows, r, r.grad_marks))
+
+
+def _find_bnb(res, c0, width):
+    """partial sums covering channels [c0, c0 + width) of `res` left by the LAST writer of that gradient: (ws, rows, column offset,
+    row width) or None"""
+    loc = _abs_chan(res)
+    if loc is None or loc[0].bnb_regs is None:
+        return None
+    owner, off = loc
+    a0, a1 = off + c0, off + c0 + width
+    for r0, r1, ws, rows, root, marks in reversed(owner.bnb_regs):
+        if r0 <= a0 and a1 <= r1 and root.grad_marks == marks:
+            return ws, rows, a0 - r0, r1 - r0
+    return None
 
 
 class Ctx:
@@ -637,7 +688,9 @@ def materialize(ctx, a, dst=None, out_dt=None, share_grad=False):
     dst.needs_grad = a.needs_grad
     if alias:
         dst.parent, dst.pc0, dst.pt0 = a, 0, None        # identity "slice": grad_view / readiness resolve into a's
+        dst.alias_of = a
         return dst
+    _note_reader(ctx, a)
     if (share_grad and SHARE_SKIP_GRAD and ctx.recording and a.needs_grad and a.parent is None and a._grad is None
             and dst.parent is not None and out.dt == v.dt):
         a.parent, a.pc0, a.pt0 = dst, 0, None            # a's gradient lives in dst's slice of the concat gradient
@@ -658,7 +711,11 @@ def new_concat(ctx, B, T, H, W, Ctot, pending):
     vectors that the member convs' BN finalize kernels fill in place."""
     v = View.alloc(B, T, H, W, Ctot, ctx.dt, ctx.device)
     if pending:
-        return Act(v, ctx.f32(Ctot), ctx.f32(Ctot), relu=True, needs_grad=True)
+        # (training: the member BatchNorms also leave their batch mean / invstd in slices of two vectors, so that a consumer of
+        #  the whole concat can hand all of them to one data-gradient launch: _conv_backward, VinetConvDesc::bnb_*)
+        st = ctx.training
+        return Act(v, ctx.f32(Ctot), ctx.f32(Ctot), relu=True, needs_grad=True, mean=ctx.f32(Ctot) if st else None,
+                   invstd=ctx.f32(Ctot) if st else None)
     return Act(v, needs_grad=True)
 
 
@@ -986,11 +1043,13 @@ class BNState:
                  invstd.data_ptr() + o, scale.data_ptr() + o, shift.data_ptr() + o, ctx.stream)
         self.steps += 1
 
-    def bwd_finalize(self, ctx, ws, rows, N, M, scale, train_bn, invstd, c1, c2, off=0, ld=0):
+    def bwd_finalize(self, ctx, ws, rows, N, M, scale, train_bn, invstd, c1, c2, off=0, ld=0, ws_off=None):
+        """`off`: this BatchNorm's first channel in the per-channel vectors; `ws_off` / `ld`: its first column and the row width
+        of the partial-sum table (default: the same layout as the vectors)"""
         o = 4 * off
         dg = _param_grad(self.gamma) if self.gamma is not None and self.gamma.requires_grad else None
         db = _param_grad(self.beta) if self.beta is not None and self.beta.requires_grad else None
-        ctx.call("vinet_bn_bwd_finalize", ws.data_ptr() + o, rows, N, ld, float(M), scale.data_ptr() + o, 1 if train_bn else 0,
+        ctx.call("vinet_bn_bwd_finalize", ws.data_ptr() + (o if ws_off is None else 4 * ws_off), rows, N, ld, float(M), scale.data_ptr() + o, 1 if train_bn else 0,
                  _ptr(dg), _ptr(db), invstd.data_ptr() + o, c1.data_ptr() + o, c2.data_ptr() + o, ctx.stream)
         _note_param_grad(ctx, self.gamma, self.beta)
 
@@ -1079,6 +1138,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
     `n_pad`       : store into a channel-padded output (N not a multiple of the vector width).
     """
     lib_dt = ctx.dt
+    _note_reader(ctx, x)
     want_plain = (MATERIALIZE_NT and x.scale is not None and ctx.dt != L.F32 and x.fold is None and not plan.stem and
                   plan.N * plan.ntaps >= MATERIALIZE_NT and x.v.dt == ctx.dt)
     xv = x.v
@@ -1093,6 +1153,8 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         dst = Act(View.alloc(xv.B, oT, oH, oW, Ny, odt, xv.device))
     out = dst.v
     scale_out, shift_out = dst.scale, dst.shift
+    mean_out, invstd_out = dst.mean, dst.invstd
+    dst.mean = dst.invstd = None        # (set below by the training-mode BatchNorm path only)
     assert (out.B, out.T, out.H, out.W, out.C) == (xv.B, oT, oH, oW, Ny), "conv output view mismatch"
     taps, ntaps = plan.folded_taps(ctx.device) if folded else plan.fwd_taps(ctx.device)
     w = plan.packed(ctx, False)
@@ -1176,7 +1238,8 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         ctx.call("vinet_conv3d", C.byref(d), ctx.stream, tag=conv_tag, work=work)
         scale = ctx.f32(plan.N) if scale_out is None else scale_out
         shift = ctx.f32(plan.N) if shift_out is None else shift_out
-        mean, invstd = ctx.f32(plan.N), ctx.f32(plan.N)
+        mean = ctx.f32(plan.N) if mean_out is None else mean_out
+        invstd = ctx.f32(plan.N) if invstd_out is None else invstd_out
         if rows >= 1024:        # tall table (early, high-resolution layers): coalesced pre-reduction to 256 rows
             per = (rows + 255) // 256
             rows2 = (rows + per - 1) // per
@@ -1186,8 +1249,7 @@ def conv_forward(ctx, plan, x, bn=None, act=L.ACT_NONE, dst=None, out_dt=None, n
         bn.finalize(ctx, stats, rows, plan.N, M, mean, invstd, scale, shift)
         res.scale, res.shift, res.relu = scale, shift, (act == L.ACT_RELU)
         keep.update(mean=mean, invstd=invstd)
-        if not isinstance(bn, JointBN):
-            res.bn_keep = keep      # (a consumer's data gradient may fold this BatchNorm's backward reduce pass in: _conv_backward)
+        res.mean, res.invstd = mean, invstd      # (a consumer's data gradient may fold this BatchNorm's backward reduce pass in: _conv_backward)
 
     if ctx.recording:
         ctx.record(lambda: _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M))
@@ -1296,20 +1358,38 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
     if bn is not None:
         fwd = res.affine()
         nb = float(dz.nvox * dz.C * ESIZE[dz.dt])
-        part = res.bnb_part
-        if part is not None and part[2] == res.root().grad_marks:
-            # the data gradient that wrote dz (its only writer: the count of writers has not moved since) left the partial
-            # sums of this reduce pass with it (VinetConvDesc::bnb_*)
-            ws, rows = part[0], part[1]
-        else:
+        # per BatchNorm behind this conv (one, or the members of a joint entry conv): its two backward sums either came with the
+        # gradient -- the data gradient that wrote dz LAST left their partial rows (VinetConvDesc::bnb_*; _find_bnb checks that
+        # no writer came after it) -- or need a reduce pass over (dz, z)
+        members = list(zip(bn.members, bn.offs, bn.widths)) if isinstance(bn, JointBN) else [(bn, 0, Ny)]
+        c1, c2 = ctx.f32(Ny), ctx.f32(Ny)
+        left = []
+        for m_, o_, w_ in members:
+            part = _find_bnb(res, o_, w_) if DGRAD_BN_STATS else None
+            if part is None:
+                left.append((m_, o_, w_))
+            else:
+                m_.bwd_finalize(ctx, part[0], part[1], w_, M, res.scale, train_bn, keep["invstd"], c1, c2, off=o_, ld=part[3], ws_off=part[2])
+        if len(left) == len(members):       # nothing came with the gradient: ONE pass over the whole tensor
             rows = ctx.lib.vinet_stats_rows(C.byref(dz.ct()))
             ws = ctx.f32(rows * 2 * Ny)
             ctx.call("vinet_bn_bwd_reduce", C.byref(dz.ct()), C.byref(out.ct()), dz.dt, fwd, keep["mean"].data_ptr(),
                      keep["invstd"].data_ptr(), ws.data_ptr(), ctx.stream,
                      tag=("vinet_bn_bwd_reduce | C%d x %d voxels" % (dz.C, dz.nvox)) if PROFILER is not None else None,
                      work=dict(flops=0.0, bytes=2 * nb))
-        c1, c2 = ctx.f32(Ny), ctx.f32(Ny)
-        bn.bwd_finalize(ctx, ws, rows, Ny, M, res.scale, train_bn, keep["invstd"], c1, c2)
+            for m_, o_, w_ in left:
+                m_.bwd_finalize(ctx, ws, rows, w_, M, res.scale, train_bn, keep["invstd"], c1, c2, off=o_, ld=Ny)
+        else:
+            for m_, o_, w_ in left:         # (a joint conv: the members whose gradient has several writers)
+                dzs, outs = dz.chan(o_, o_ + w_), out.chan(o_, o_ + w_)
+                rows = ctx.lib.vinet_stats_rows(C.byref(dzs.ct()))
+                ws = ctx.f32(rows * 2 * w_)
+                fsl = L.CAffine(res.scale.data_ptr() + 4 * o_, res.shift.data_ptr() + 4 * o_, 1 if res.relu else 0)
+                ctx.call("vinet_bn_bwd_reduce", C.byref(dzs.ct()), C.byref(outs.ct()), dz.dt, fsl, keep["mean"].data_ptr() + 4 * o_,
+                         keep["invstd"].data_ptr() + 4 * o_, ws.data_ptr(), ctx.stream,
+                         tag=("vinet_bn_bwd_reduce | C%d x %d voxels" % (w_, dz.nvox)) if PROFILER is not None else None,
+                         work=dict(flops=0.0, bytes=2 * nb * w_ / Ny))
+                m_.bwd_finalize(ctx, ws, rows, w_, M, res.scale, train_bn, keep["invstd"], c1, c2, off=o_, ld=w_, ws_off=0)
         # A conv whose input needs no gradient (the RGB stem) has one consumer of dz, its weight gradient: kernels
         # that can form dz from (gradient behind the BN, raw conv output) on the fly spare the apply pass
         if BN_BWD_FUSE and not x.needs_grad and plan.wants_wgrad() and plan.bias is None and out.dt == dz.dt == ctx.dt:
@@ -1492,12 +1572,12 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             if ctx.lib.vinet_conv3d_fuses_dgrad_phases(C.byref(d)):
                 es = ESIZE[ctx.dt]
                 bnb_ws = None
-                if (DGRAD_BN_STATS and not acc and x.bn_keep is not None and x.scale is not None and x.parent is None and
+                if (DGRAD_BN_STATS and not acc and x.mean is not None and x.scale is not None and x.parent is None and
                         x.fold is None and xv.dt == dx.dt and xv.C == plan.Cin and dx.same_dims(xv)):
                     # x = relu(bn(z)), this launch is the first (for the stem: the only) writer of its gradient: the partial
                     # sums of that BatchNorm's backward reduce pass leave with the gradient
                     d.bnb_z, d.bnb_ld, d.bnb_sB, d.bnb_fwd = xv.ptr(), xv.ld, xv.sB, x.affine()
-                    d.bnb_mean, d.bnb_invstd = x.bn_keep["mean"].data_ptr(), x.bn_keep["invstd"].data_ptr()
+                    d.bnb_mean, d.bnb_invstd = x.mean.data_ptr(), x.invstd.data_ptr()
                     brows = ctx.lib.vinet_conv3d_bn_bwd_stats_rows(C.byref(d))
                     if brows > 0:
                         bnb_ws = ctx.f32(brows * 2 * xv.C)
@@ -1509,8 +1589,16 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                 phases = []
                 if bnb_ws is not None:
                     x.mark_grad_ready()
-                    x.bnb_part = (bnb_ws, brows, x.root().grad_marks)
+                    _register_bnb(x, bnb_ws, brows)
                     return
+        # The BatchNorm(s) behind x's pending affine (x itself, or the pending activation it materialises): when this launch is
+        # the LAST writer of x's gradient -- every consumer recorded in forward but this one has written -- and covers it in one
+        # launch, it also writes the partial sums of their backward reduce pass (VinetConvDesc::bnb_*, the shared conv epilogue)
+        bx = x.alias_of if x.alias_of is not None else x
+        bnb_ws, brows = None, 0
+        want_bnb = (DGRAD_BN_STATS >= 2 and len(phases) == 1 and full and bx.mean is not None and bx.scale is not None and bx.relu
+                    and bx.fold is None and ctx.cdt == BF16 and dx.dt == BF16 and bx.v.dt == BF16 and xv.C == plan.Cin
+                    and dx.same_dims(bx.v) and x.root().grad_marks + 1 == x.root().n_readers)
         for ph in phases:
             d = L.CConvDesc()
             d.dtype, d.out_dtype, d.mode = ctx.cdt, dx.dt, L.CONV_GENERIC
@@ -1525,13 +1613,23 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
             d.act, d.accumulate, d.stats = L.ACT_NONE, acc, None
             d.n_valid = plan.Cin if xv.C != plan.Cin else 0
             d.tline, d.tpad = ph["tline"], ph["tpad"]
+            if want_bnb:
+                zv = bx.v
+                d.bnb_z, d.bnb_ld, d.bnb_sB, d.bnb_fwd = zv.ptr(), zv.ld, zv.sB, bx.affine()
+                d.bnb_mean, d.bnb_invstd = bx.mean.data_ptr(), bx.invstd.data_ptr()
+                brows = ctx.lib.vinet_conv3d_bn_bwd_stats_rows(C.byref(d))
+                if brows > 0:
+                    bnb_ws = ctx.f32(brows * 2 * zv.C)
+                    d.bnb_partials = bnb_ws.data_ptr()
             es = ESIZE[ctx.dt]
             nph = len(phases)
             ctx.call("vinet_conv3d", C.byref(d), ctx.stream,
-                     tag=(_conv_kernel_name(ctx, d) + " | dgrad " + plan.site(xv)) if PROFILER is not None else None,
+                     tag=(_conv_kernel_name(ctx, d) + ("+bnb" if bnb_ws is not None else "") + " | dgrad " + plan.site(xv)) if PROFILER is not None else None,
                      work=dict(flops=2.0 * M * plan.N * plan.Cin * plan.ntaps / nph,
                                bytes=float(xv.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * es) / nph))
         x.mark_grad_ready()
+        if bnb_ws is not None:
+            _register_bnb(bx, bnb_ws, brows)
 
 
 # ----------------------------------------------------------------------------
@@ -1547,6 +1645,7 @@ def maxpool_forward(ctx, x, k, s, p, dst=None):
     assert (out.T, out.H, out.W, out.C) == (od[0], od[1], od[2], xv.C) and dst.plain
     pd = L.CPoolDesc(xv.dt, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
     rec = ctx.recording and x.needs_grad
+    _note_reader(ctx, x)
     am = torch.empty(out.nvox * out.C, dtype=torch.uint8, device=xv.device) if rec else None
     ptag = "maxpool k%dx%dx%d s%dx%dx%d C%d in%dx%dx%dx%d" % (k + s + (xv.C, xv.B, xv.T, xv.H, xv.W))
     es = ESIZE[xv.dt]
@@ -1573,6 +1672,7 @@ def upsample2x_forward(ctx, x, dst=None):
     out = dst.v
     assert dst.plain
     ctx.call("vinet_upsample2x", C.byref(xv.ct()), C.byref(out.ct()), xv.dt, ctx.stream)
+    _note_reader(ctx, x)
     dst.needs_grad = x.needs_grad
     if ctx.recording and x.needs_grad:
         def bwd():
@@ -1693,6 +1793,8 @@ class BlockBody:
         acts = [import_ncdhw(ectx, t, self.cpad, needs_grad=r) for t, r in zip(inputs, req)]
         outs = self.fwd(ectx, *acts)
         outs = list(outs) if isinstance(outs, (list, tuple)) else [outs]
+        for o in outs:
+            _note_reader(ectx, o)        # (the seed of backward writes its gradient: import_grad_ncdhw)
         tens = [export_ncdhw(ectx, o, self.out_channels(o)) for o in outs]
         return tens, (acts, outs, [t.shape[1] for t in inputs])
 

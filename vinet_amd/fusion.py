@@ -11,6 +11,8 @@ def bilinear_forward(ctx, bil, y0, audio, out_thw):
     Act [B,4,7,12,C] with out[b, o, c] = sum_ij x1[b,i,c] W[o,i,j] x2[b,j,c] + bias[o]."""
     x1 = E.materialize(ctx, y0) if not _dense_plain(y0) else y0
     x2 = E.materialize(ctx, audio) if not _dense_plain(audio) else audio
+    E._note_reader(ctx, x1)
+    E._note_reader(ctx, x2)
     v1, v2 = x1.v, x2.v
     B, Cc = v1.B, v1.C
     I, J = v1.T * v1.H * v1.W, v2.T * v2.H * v2.W

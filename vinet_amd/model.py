@@ -176,6 +176,7 @@ class _MapBody:
             else:
                 acts.append(E.import_ncdhw(ectx, t, None, needs_grad=r))
         head = self.fwd(ectx, *acts)
+        E._note_reader(ectx, head)       # (the seed of backward writes its gradient)
         hv = head.v
         assert hv.T == 1 and hv.dt == E.F32
         planes = torch.empty((hv.C, hv.B, hv.H, hv.W), dtype=torch.float32, device=hv.device)
