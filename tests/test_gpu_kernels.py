@@ -333,6 +333,50 @@ PW_CASES = [
 ]
 
 
+# Data gradients that also leave the BatchNorm-backward partial sums of the layer(s) behind their output (VinetConvDesc::bnb_*,
+# conv_bnb.hip): halo tiles in both modes and widths, conv_dma in every tile family (pointwise streaming off), store and accumulate
+# forms, ragged M / N, sliced gradient and z views, with and without the ReLU gate
+BNB_CASES = [
+    ("bnb_ht_64_64", (2, 2, 8, 32), 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(bnb=dict())),
+    ("bnb_ht_128_96_tw16", (1, 3, 20, 16), 128, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(bnb=dict(ld=160, coff=32), out_ld=256, out_coff=64)),
+    ("bnb_ht_64_32", (1, 2, 9, 32), 64, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(bnb=dict(relu=False))),
+    ("bnb_ht_acc_192", (2, 2, 8, 32), 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(bnb=dict(), accumulate=True)),
+    ("bnb_htt_192", (2, 6, 8, 16), 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, bnb=dict())),
+    ("bnb_htt_acc_96", (2, 7, 6, 8), 64, 96, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, accumulate=True, bnb=dict(ld=128, coff=16))),
+    ("bnb_htt_64", (1, 5, 14, 24), 128, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, bnb=dict())),
+    ("bnb_pw_176_192", (2, 3, 10, 13), 176, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(tline=6, bnb=dict(), accumulate=True)),
+    ("bnb_pw_288_256", (1, 4, 11, 17), 288, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(tline=6, bnb=dict(ld=320, coff=64))),
+    ("bnb_pw_64_48", (3, 2, 7, 9), 64, 48, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(tline=6, bnb=dict(relu=False), accumulate=True)),
+    ("bnb_pw_96_16", (2, 2, 5, 8), 96, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(tline=6, bnb=dict())),
+    ("bnb_pw_64_128", (2, 5, 9, 16), 64, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), dict(tline=6, bnb=dict(), accumulate=True)),
+    ("bnb_dma_3t_32_64", (2, 6, 5, 12), 32, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, bnb=dict())),
+]
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["random", "exact"])
+@pytest.mark.parametrize("case", BNB_CASES, ids=[c[0] for c in BNB_CASES])
+def test_conv3d_bn_bwd_stats_from_the_epilogue(case, exact):
+    """vinet_conv3d with bnb_partials: the output equals the ABI model's (and the plain launch's: same arithmetic), and the partial
+    rows sum to the reduce pass's two sums over the gradient the launch stored -- exactly, on exact-arithmetic inputs"""
+    lib = _lib()
+    ht = case[0].startswith("bnb_ht")
+    assert lib.vinet_set_option(b"ht", 2 if ht else 0) == 0 and lib.vinet_set_option(b"pw", 0) == 0 and lib.vinet_set_option(b"pp", 0) == 0
+    ex = dict(case[7])
+    if ht and not case[0].startswith("bnb_htt"):
+        ex.setdefault("tline", 5)
+    case = case[:7] + (ex,)
+    try:
+        if exact:
+            with exact_mode():
+                _run_conv_case(case, E.BF16, forced=True)
+        else:
+            _run_conv_case(case, E.BF16, forced=True)
+    finally:
+        lib.vinet_set_option(b"ht", 1)
+        lib.vinet_set_option(b"pw", 1)
+        lib.vinet_set_option(b"pp", 1)
+
+
 @pytest.mark.parametrize("case", PW_CASES, ids=[c[0] for c in PW_CASES])
 def test_conv3d_pointwise_stream(case):
     lib = _lib()
@@ -617,6 +661,12 @@ def _run_conv_case(case, dt, forced=False, want_y=False, cdt=None, tol=None):
     M = B * oT * oH * oW
     rows = (M + 63) // 64 + B * oT * 8
     stats = Pair(torch.zeros(rows * 2 * N))
+    bnb = ex.get("bnb")
+    if bnb is not None:      # the launch is a data gradient behind BatchNorm + ReLU layers: it also writes their backward partial sums
+        zp, zmk = view_pair(B, oT, oH, oW, Ny, odt, "z" + name, 11, ld=bnb.get("ld"), c_off=bnb.get("coff", 0))
+        b_sc, b_sh = fvec("bsc" + name, N, 12, 0.5, 1.5), fvec("bsh" + name, N, 13)
+        b_mu, b_is = fvec("bmu" + name, N, 14), fvec("bis" + name, N, 15, 0.5, 2.0)
+        bpart = Pair(torch.full((rows * 2 * N,), float("nan")))
 
     def mk(side):
         d = L.CConvDesc()
@@ -637,6 +687,12 @@ def _run_conv_case(case, dt, forced=False, want_y=False, cdt=None, tol=None):
             d.tline, d.tpad = (1 if ex["tline"] is True else ex["tline"]), p[0]
         if ex.get("om"):            # output placement of a stride phase: positions (to*omT + ooT, ...) of a larger y
             d.omT, d.ooT = ex["om"]
+        if bnb is not None:
+            z = zmk(side)
+            d.bnb_z, d.bnb_ld, d.bnb_sB = z.ptr(), z.ld, z.sB
+            d.bnb_fwd = L.CAffine(b_sc.ptr(side), b_sh.ptr(side), 1 if bnb.get("relu", True) else 0)
+            d.bnb_mean, d.bnb_invstd = b_mu.ptr(side), b_is.ptr(side)
+            d.bnb_partials = bpart.ptr(side)
         if ex.get("splitk") and side == "gpu":
             nb = _lib().vinet_conv3d_splitk_bytes(C.byref(d))
             assert nb >= 2 * M * Ny * 4, "split-K plan expected for " + name
@@ -646,8 +702,30 @@ def _run_conv_case(case, dt, forced=False, want_y=False, cdt=None, tol=None):
         return [C.byref(d), _stream() if side == "gpu" else 0]
 
     keep_ws = []
+    if bnb is not None:
+        d0 = mk("gpu")[0]._obj
+        nbuf = C.create_string_buffer(128)
+        _lib().vinet_conv3d_kernel_name(C.byref(d0), nbuf, 128)
+        br = _lib().vinet_conv3d_bn_bwd_stats_rows(C.byref(d0))
+        assert 0 < br <= rows, "no BatchNorm-backward statistics for %s (%s)" % (name, nbuf.value.decode())
+        assert br == _lib().vinet_conv3d_stats_rows(C.byref(d0))
     run_both("vinet_conv3d", mk)
     _cmp(yp.get("gpu"), yp.get("cpu"), TOL[dt] if tol is None else tol, "conv " + name)
+    if bnb is not None:
+        # against the reduce pass's definition, in double, on the gradient the GPU wrote: (sum g gate, sum g gate (z - mean) invstd)
+        yv, zv = ymk("cpu"), zmk("cpu")
+        g = E.View(yp.get("gpu"), yv.off, yv.B, yv.T, yv.H, yv.W, yv.C, yv.ld, yv.sB, odt).torch5().double().reshape(-1, Ny)
+        zz = zv.torch5().double().reshape(-1, Ny)
+        if bnb.get("relu", True):
+            g = g * ((zz * b_sc.cpu.double() + b_sh.cpu.double()) > 0)
+        ref = torch.stack([g.sum(0), (g * (zz - b_mu.cpu.double()) * b_is.cpu.double()).sum(0)])
+        got = bpart.get("gpu")[:br * 2 * N].view(br, 2, N).double().sum(0)
+        assert torch.isfinite(got).all(), "unwritten rows of the partial-sum table"
+        if _EXACT[0]:
+            assert torch.equal(got, ref), "bn-backward sums of %s not exact: max diff %g" % (name, float((got - ref).abs().max()))
+        else:
+            scale = g.abs().sum(0).clamp_min(1.0) * 4
+            assert float(((got - ref).abs() / scale).max()) < 2e-3, "bn-backward sums of %s: %g" % (name, float(((got - ref).abs() / scale).max()))
     if ex.get("stats"):
         d0 = mk("gpu")[0]._obj
         bm = _lib().vinet_conv3d_tile_m(C.byref(d0))
