@@ -322,10 +322,12 @@ def loss_case(RL, seed, out):
     print("loss ok", {k: float(v) for k, v in res.items() if k.startswith("full_") and v.ndim == 0})
 
 
-def train_step_case(RM, RL, seed, out):
-    """one Adam step (train.py:208-217) on ViNet-8 at B=2, 8x64x96."""
+def train_step_case(RM, RL, seed, out, shape=(2, 8, 64, 96), name="train_step"):
+    """one Adam step (train.py:208-217) on ViNet-8: B=2, 8x64x96 (`train_step`: 12 samples per channel in the deepest BatchNorms --
+    ill-conditioned on purpose) and B=12, 8x128x192 (`train_step_wc`, round 5: 288 samples per channel there, so that a gradient
+    gate can tell a 2^-17 operand error from a bug)."""
     meta, res = {}, {}
-    B, T, H, W = 2, 8, 64, 96
+    B, T, H, W = shape
     x = synth.clip(B, T, H, W, seed).permute(0, 2, 1, 3, 4)
     gt = synth.gt_map(B, H, W, seed)
     ref = RM.VideoSaliencyModel(num_clips=8)
@@ -380,8 +382,8 @@ def train_step_case(RM, RL, seed, out):
         res["state:" + k] = _np(sd_r[k])
     res["head_w"], res["head_b"] = _np(sd[wk]), _np(sd[bk])
     res["meta"] = np.array(json.dumps(dict(meta, seed=seed, B=B, T=T, H=H, W=W, lr=1e-4, head_w_key=wk, head_b_key=bk)))
-    np.savez_compressed(os.path.join(out, "train_step.npz"), **res)
-    print("train_step ok: loss %.6f -> %.6f" % (float(l0_r), float(l1_r)))
+    np.savez_compressed(os.path.join(out, name + ".npz"), **res)
+    print("%s ok: loss %.6f -> %.6f" % (name, float(l0_r), float(l1_r)))
 
 
 def avinet_case(RM, seed, out):
@@ -425,6 +427,9 @@ def main():
     out = HERE
     if sys.argv[1:] == ["loss"]:        # regenerate one fixture
         loss_case(RL, 3, out)
+        return
+    if sys.argv[1:] == ["round5"]:      # the well-conditioned training-step fixture
+        train_step_case(RM, RL, 43, out, shape=(12, 8, 128, 192), name="train_step_wc")
         return
     if sys.argv[1:] == ["round4"]:      # a block golden at the M = 336-voxel stage (4 x 7 x 12: base4 of a 32 x 224 x 384 clip)
         block_case("mixed_5b", lambda: RU.Mixed_5b(), lambda: O.Mixed_5b(), (1, 832, 4, 7, 12), 15, out, compact=True)

@@ -239,11 +239,11 @@ def e2e_case(tag, dev, tol=1e-4, argmax=True):
 
 
 def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5, grad_factor=3.0, grad_floor=2e-3, worst_max=0.15,
-                    global_tol=None, sq_rtol=8e-2, global_factor=None):
+                    global_tol=None, sq_rtol=8e-2, global_factor=None, fixture="train_step", min_drop=0.2):
     from vinet_amd import loss as VL
     from vinet_amd import model as VM
     from vinet_amd import optim as VO
-    z, meta = G.load("train_step")
+    z, meta = G.load(fixture)
     B, T, H, W = meta["B"], meta["T"], meta["H"], meta["W"]
     x = synth.clip(B, T, H, W, meta["seed"]).permute(0, 2, 1, 3, 4)
     gt = synth.gt_map(B, H, W, meta["seed"])
@@ -310,7 +310,7 @@ def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5, grad
     # Adam's first step is sign descent (m/sqrt(v) = +-1): fp32-noise-level gradient
     # entries flip sign between implementations, so loss1 agrees to ~1e-3, not 1e-5
     close(loss1, z["loss1"], 3e-3, "train loss1")
-    assert float(loss1) < float(loss0) - 0.2
+    assert float(loss1) < float(loss0) - min_drop
     sd = m.state_dict()
     for k in [n for n in z.files if n.startswith("state:")]:
         # base4 statistics come from 12 samples/channel on weights that already took one

@@ -133,6 +133,24 @@ def test_train_step_split_bf16():
                                        reference_fp32_whole_gradient_rel_l2=getattr(MC.train_step_case, "global_ref", None)))
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp32s"])
+def test_train_step_well_conditioned(dtype):
+    """The training-step gate on a WELL-CONDITIONED fixture: ViNet-8 at B = 12, 8 x 128 x 192 -- 288 samples per
+    channel in the deepest BatchNorms instead of 12, so the reference's own fp32 gradient sits close to fp64 and a 2^-17 operand
+    error (the split-bf16 form) cannot hide behind BatchNorm ill-conditioning: per parameter and for the whole gradient vector the
+    error against the fp64 oracle must stay within 2 x the reference's own fp32 error (+ a floor for ReLU-gate flips)."""
+    E.set_default_dtype(dtype)
+    split = dtype == "fp32s"
+    try:
+        MC.train_step_case(DEV, fixture="train_step_wc", pred_tol=1e-4 if split else 2e-5, loss_tol=1e-4 if split else 1e-5,
+                           grad_factor=2.0, grad_floor=2e-2 if split else 2e-3, worst_max=0.1 if split else 0.05, global_factor=2.0,
+                           sq_rtol=0.1 if split else 2e-2, min_drop=0.05)
+    finally:
+        _note("train_step_wc_" + dtype, dict(top_grad_rel_err_vs_fp64=getattr(MC.train_step_case, "last_table", None),
+                                             whole_gradient_rel_l2=getattr(MC.train_step_case, "global_rel", None),
+                                             reference_fp32_whole_gradient_rel_l2=getattr(MC.train_step_case, "global_ref", None)))
+
+
 def test_avinet_split_bf16():
     from vinet_amd import model as VM
     E.set_default_dtype("fp32s")

@@ -299,6 +299,23 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
         if constexpr (BNB) zoff[k] = (do_bnb && vok[k]) ? z_off(group_m0(ig) + p) : 0;
       }
     }
+    uint4 zl[NP];
+    if constexpr (BNB) if (do_bnb) {
+      // the wave's per-channel constants -> its private LDS area (unused on this path): [scale | shift | mean | invstd][WNC]
+      for (int c = lane; c < WNC; c += 64) {
+        const int n = n_wave + c;
+        const bool ok = n < a.N;
+        Ew[c] = (ok && a.bnb_scale) ? a.bnb_scale[n] : 1.f;
+        Ew[WNC + c] = (ok && a.bnb_shift) ? a.bnb_shift[n] : 0.f;
+        Ew[2 * WNC + c] = ok ? a.bnb_mean[n] : 0.f;
+        Ew[3 * WNC + c] = ok ? a.bnb_invstd[n] : 0.f;
+      }
+      const int n80 = n_wave + (q >> 1) * 8;
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        zl[k] = (vok[k] && n80 < a.N) ? *(const uint4*)((const bf16_t*)a.bnb_z + zoff[k] + n80) : make_uint4(0, 0, 0, 0);
+      wave_lds_fence();
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       float sc[4], sh[4], ss[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -312,20 +329,28 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
         for (int k = 0; k < NP; ++k)
           old[k] = (vok[k] && nok8) ? *(const uint4*)((const bf16_t*)a.y + voff[k] + n8) : make_uint4(0, 0, 0, 0);
       }
-      // BatchNorm-backward sums of my 8 channels n8 .. n8 + 7 over my voxels (one per row-group pair)
-      uint4 zl[NP];
-      float bsc[8], bsh[8], bmu[8], bs[8], bp[8];
+      // BatchNorm-backward sums of my 8 channels n8 .. n8 + 7 over my voxels (one per row-group pair).  z of column tile j + 1
+      // is requested before tile j is processed (the loads of a tile would otherwise be consumed one memory latency after their
+      // issue, NT times per wave tile); the per-channel constants come from the wave's LDS table.
+      uint4 zn[NP];
+      f32x2_v bsc[4], bsh[4], bmu[4], bs[4], bp[4];
       if constexpr (BNB) if (do_bnb) {
+        if (j + 1 < NT) {
+          const int n8n = n8 + 16;
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
-          zl[k] = (vok[k] && nok8) ? *(const uint4*)((const bf16_t*)a.bnb_z + zoff[k] + n8) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          bs[e] = 0.f; bp[e] = 0.f;
-          bsc[e] = (nok8 && a.bnb_scale) ? a.bnb_scale[n8 + e] : 1.f;
-          bsh[e] = (nok8 && a.bnb_shift) ? a.bnb_shift[n8 + e] : 0.f;
-          bmu[e] = nok8 ? a.bnb_mean[n8 + e] : 0.f;
+          for (int k = 0; k < NP; ++k)
+            zn[k] = (vok[k] && n8n < a.N) ? *(const uint4*)((const bf16_t*)a.bnb_z + zoff[k] + n8n) : make_uint4(0, 0, 0, 0);
         }
+        const int c8 = j * 16 + (q >> 1) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 t0 = *(const float4*)&Ew[c8 + 4 * h], t1 = *(const float4*)&Ew[WNC + c8 + 4 * h], t2 = *(const float4*)&Ew[2 * WNC + c8 + 4 * h];
+          bsc[2 * h] = (f32x2_v){t0.x, t0.y}; bsc[2 * h + 1] = (f32x2_v){t0.z, t0.w};
+          bsh[2 * h] = (f32x2_v){t1.x, t1.y}; bsh[2 * h + 1] = (f32x2_v){t1.z, t1.w};
+          bmu[2 * h] = (f32x2_v){t2.x, t2.y}; bmu[2 * h + 1] = (f32x2_v){t2.z, t2.w};
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { bs[h] = (f32x2_v){0.f, 0.f}; bp[h] = (f32x2_v){0.f, 0.f}; }
       }
       // g = the 8 bf16 this lane stores for pair k (rounded, accumulated): gate with the forward ReLU, add to the sums.
       // Lanes outside the iteration space contribute nothing.
@@ -334,14 +359,17 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
         const uint32_t ow[4] = {o0, o1, o2, o3}, zw[4] = {zl[k].x, zl[k].y, zl[k].z, zl[k].w};
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          float g0 = __uint_as_float(ow[h] << 16), g1 = __uint_as_float(ow[h] & 0xffff0000u);
-          const float z0 = __uint_as_float(zw[h] << 16), z1 = __uint_as_float(zw[h] & 0xffff0000u);
+          f32x2_v g = {__uint_as_float(ow[h] << 16), __uint_as_float(ow[h] & 0xffff0000u)};
+          const f32x2_v z = {__uint_as_float(zw[h] << 16), __uint_as_float(zw[h] & 0xffff0000u)};
           if (a.bnb_relu) {
-            if (!(fmaf(z0, bsc[2 * h], bsh[2 * h]) > 0.f)) g0 = 0.f;
-            if (!(fmaf(z1, bsc[2 * h + 1], bsh[2 * h + 1]) > 0.f)) g1 = 0.f;
+            const f32x2_v t = {fmaf(z.x, bsc[h].x, bsh[h].x), fmaf(z.y, bsc[h].y, bsh[h].y)};
+            g.x = t.x > 0.f ? g.x : 0.f;
+            g.y = t.y > 0.f ? g.y : 0.f;
           }
-          bs[2 * h] += g0; bp[2 * h] = fmaf(g0, z0 - bmu[2 * h], bp[2 * h]);
-          bs[2 * h + 1] += g1; bp[2 * h + 1] = fmaf(g1, z1 - bmu[2 * h + 1], bp[2 * h + 1]);
+          const f32x2_v dz_ = z - bmu[h];
+          bs[h] += g;
+          bp[h].x = fmaf(g.x, dz_.x, bp[h].x);
+          bp[h].y = fmaf(g.y, dz_.y, bp[h].y);
         }
       };
 #pragma unroll
@@ -407,15 +435,22 @@ VN_DEV void conv_epilogue(const ConvArgs& a, f32x4_v (&acc)[MT][NT], char* smem,
         // the 16 lanes of a row hold 16 voxels of the same 8 channels: two DPP rotations leave lanes p = 0..3 with four partial
         // sums; rows q and q ^ 1 hold the same channels of the other row group of each pair -> 8 partial rows per wave row
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { bs[e] = row16_sum4(bs[e]); bp[e] = row16_sum4(bp[e]); }
+        for (int h = 0; h < 4; ++h) {
+          bs[h].x = row16_sum4(bs[h].x); bs[h].y = row16_sum4(bs[h].y);
+          bp[h].x = row16_sum4(bp[h].x); bp[h].y = row16_sum4(bp[h].y);
+        }
         if (p < 4 && nok8) {
-          const int col = wn * WNC + j * 16 + (q >> 1) * 8;
-          float* dst = red + ((long)(wm * 8 + (q & 1) * 4 + p) * BN + col) * 2;
+          const int c8 = j * 16 + (q >> 1) * 8;
+          float* dst = red + ((long)(wm * 8 + (q & 1) * 4 + p) * BN + wn * WNC + c8) * 2;
 #pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            const float i0 = a.bnb_invstd[n8 + e], i1 = a.bnb_invstd[n8 + e + 1];
-            *(float4*)(dst + 2 * e) = make_float4(bs[e], bp[e] * i0, bs[e + 1], bp[e + 1] * i1);
+          for (int h = 0; h < 4; ++h) {
+            const float i0 = Ew[3 * WNC + c8 + 2 * h], i1 = Ew[3 * WNC + c8 + 2 * h + 1];
+            *(float4*)(dst + 4 * h) = make_float4(bs[h].x, bp[h].x * i0, bs[h].y, bp[h].y * i1);
           }
+        }
+        if (j + 1 < NT) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) zl[k] = zn[k];
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // one column tile at a time: hoisted accumulator reads of later tiles spill

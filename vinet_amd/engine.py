@@ -93,8 +93,11 @@ _CONFIG = dict(
     SPLIT_IN_APPLY=1,           # fp32s: the planes of dy leave with the BatchNorm-backward apply pass that produces dy
     # a data gradient that is the LAST writer of the gradient behind BatchNorm + ReLU layers also writes their backward partial
     # sums (VinetConvDesc::bnb_*): no reduce pass over (dz, z) for those layers.  0 = off, 1 = the stem's fused temporal data
-    # gradient only (round 4), 2 = every data gradient the library can do it for (round 5)
-    DGRAD_BN_STATS=2,
+    # gradient only (round 4), 2 = every data gradient the library can do it for (round 5: the shared conv epilogue, conv_bnb.hip).
+    # Default 1: mode 2 is correct (bit-exact kernel tests, goldens) and removes 16 of the 58 reduce launches (-8 ms of reduce
+    # time in the step), but the 32 data gradients that carry the sums get 7.7 ms slower alone (+z read, +8 VALU per element in
+    # an issue-bound epilogue): 282.8 -> 286.7 ms per step in alternating same-box runs (profiles/r5_bnb_epilogue_ab.txt)
+    DGRAD_BN_STATS=1,
     UPSAMPLE_BWD_RELU=1,        # ReLU backward of conv -> ReLU -> upsample inside the upsample's backward pass
     PARAM_GRAD_MODE="fused",    # see set_param_grad_mode
     # Schedule stress (tests): shader clocks a spin kernel idles on the weight-gradient stream in front of every weight-gradient
@@ -290,7 +293,7 @@ class View:
 class Act:
     """activation = view + pending affine/relu + gradient bookkeeping."""
     __slots__ = ("v", "scale", "shift", "relu", "_grad", "grad_ready", "needs_grad", "parent", "pc0", "pt0", "fold",
-                 "indep", "ready_of", "grad_marks", "mean", "invstd", "alias_of", "n_readers", "bnb_regs", "act_out", "grad_masked")
+                 "indep", "ready_of", "grad_marks", "mean", "invstd", "alias_of", "n_readers", "act_out", "grad_masked")
 
     def __init__(self, v, scale=None, shift=None, relu=False, needs_grad=False, mean=None, invstd=None):
         self.v, self.scale, self.shift, self.relu = v, scale, shift, relu
@@ -305,7 +308,6 @@ class Act:
         self.grad_marks = 0      # writers of this gradient so far (mark_grad_ready calls on the root)
         self.alias_of = None     # the pending activation this plain one materialises with shared gradient storage (materialize)
         self.n_readers = 0       # consumers recorded in this forward that will write this gradient (counted on the root)
-        self.bnb_regs = None     # storage owner only: [(c0, c1, partials, rows, root, marks)] BN-backward partial sums that data gradients left
         self.act_out = 0         # activation the producing conv applied in its epilogue (no BatchNorm): conv_forward
         self.grad_masked = -1    # grad_marks at which the gradient already carries that activation's backward (upsample2x backward)
 
@@ -393,7 +395,7 @@ def _note_reader(ctx, x):
         x.root().n_readers += 1
 
 
-def _register_bnb(x, ws, rows):
+def _register_bnb(ctx, x, ws, rows):
     """a data gradient just wrote x's gradient (already marked) together with the BatchNorm-backward partial sums `ws`
     ([rows][2][x.C]) of the layer(s) behind x's pending affine: remember them with the writer count of that moment -- they are
     valid as long as no later writer touches the gradient (_find_bnb checks)"""
@@ -401,21 +403,21 @@ def _register_bnb(x, ws, rows):
     if loc is None:
         return
     owner, off = loc
-    if owner.bnb_regs is None:
-        owner.bnb_regs = []
     r = x.root()
-    owner.bnb_regs.append((off, off + x.v.C, ws, rows, r, r.grad_marks))
+    # (kept on the pass, not on the activation: an Act that referenced its own root would be a reference cycle, and a step's
+    #  activations must die by reference count when the tape is dropped -- 190 GB of them at the headline batch)
+    ctx._bnb.setdefault(id(owner), []).append((off, off + x.v.C, ws, rows, r, r.grad_marks))
 
 
-def _find_bnb(res, c0, width):
+def _find_bnb(ctx, res, c0, width):
     """partial sums covering channels [c0, c0 + width) of `res` left by the LAST writer of that gradient: (ws, rows, column offset,
     row width) or None"""
     loc = _abs_chan(res)
-    if loc is None or loc[0].bnb_regs is None:
+    if loc is None or id(loc[0]) not in ctx._bnb:
         return None
     owner, off = loc
     a0, a1 = off + c0, off + c0 + width
-    for r0, r1, ws, rows, root, marks in reversed(owner.bnb_regs):
+    for r0, r1, ws, rows, root, marks in reversed(ctx._bnb[id(owner)]):
         if r0 <= a0 and a1 <= r1 and root.grad_marks == marks:
             return ws, rows, a0 - r0, r1 - r0
     return None
@@ -436,6 +438,8 @@ class Ctx:
         self._side_keep = []
         self._deferred = []
         self._unpack_jobs = []
+        self._dw_plans = []
+        self._bnb = {}           # id(storage owner) -> [(c0, c1, partials, rows, root, marks)]: BN-backward partial sums that data gradients left
         self.capturing = False
 
     @property
@@ -603,6 +607,7 @@ class Ctx:
             for st in self.side_streams():
                 torch.cuda.current_stream(self.device).wait_stream(st)
         self._side_keep = []
+        self._bnb = {}
         self.tape = []
 
 
@@ -1365,7 +1370,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
         c1, c2 = ctx.f32(Ny), ctx.f32(Ny)
         left = []
         for m_, o_, w_ in members:
-            part = _find_bnb(res, o_, w_) if DGRAD_BN_STATS else None
+            part = _find_bnb(ctx, res, o_, w_) if DGRAD_BN_STATS else None
             if part is None:
                 left.append((m_, o_, w_))
             else:
@@ -1589,7 +1594,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                 phases = []
                 if bnb_ws is not None:
                     x.mark_grad_ready()
-                    _register_bnb(x, bnb_ws, brows)
+                    _register_bnb(ctx, x, bnb_ws, brows)
                     return
         # The BatchNorm(s) behind x's pending affine (x itself, or the pending activation it materialises): when this launch is
         # the LAST writer of x's gradient -- every consumer recorded in forward but this one has written -- and covers it in one
@@ -1629,7 +1634,7 @@ def _conv_backward(ctx, plan, x, res, bn, act, train_bn, keep, M):
                                bytes=float(xv.nvox * plan.Cin * es + M * plan.N * es + plan.N * plan.Cin * plan.ntaps * es) / nph))
         x.mark_grad_ready()
         if bnb_ws is not None:
-            _register_bnb(bx, bnb_ws, brows)
+            _register_bnb(ctx, bx, bnb_ws, brows)
 
 
 # ----------------------------------------------------------------------------
