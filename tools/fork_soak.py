@@ -19,6 +19,9 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 net = sys.argv[2] if len(sys.argv) > 2 else "avinet"
 forked = "--one-stream" not in sys.argv      # --one-stream: the comparison runs the ONE-stream schedule too (control: what varies without forks?)
 _lib.load()
+for a_ in sys.argv:
+    if a_.startswith("--cfg="):
+        E.configure_from_string(a_[6:])
 DEV = torch.device("cuda:0")
 E.set_default_dtype("bf16")
 av = net == "avinet"
@@ -79,9 +82,15 @@ for r in range(rounds):
     if not ok:
         bad += 1
         off = 0
+        nd = (got[1] != ref[1]).nonzero().flatten()
+        print("    elements of the flat gradient that differ at all: %d of %d, first %s last %s" % (nd.numel(), ref[1].numel(), nd[:3].tolist(), nd[-3:].tolist()))
         for n, s in zip(got[2], got[3]):
             d = float((got[1][off:off + s] - ref[1][off:off + s]).norm() / (ref[1][off:off + s].norm() + 1e-30))
             if d > 1e-4:
                 print("    %-60s rel %.3e   |ref| %.3e |got| %.3e (whole gradient %.3e)" % (n, d, float(ref[1][off:off + s].norm()), float(got[1][off:off + s].norm()), float(ref[1].norm())))
+                dd = (got[1][off:off + s] - ref[1][off:off + s]).abs()
+                idx = (dd > 0).nonzero().flatten()
+                print("      flat offset %d, %d of %d elements differ, indices %s ... %s; largest |diff| %.3e at %d (ref %.3e got %.3e)" % (
+                    off, idx.numel(), s, idx[:6].tolist(), idx[-3:].tolist(), float(dd.max()), int(dd.argmax()), float(ref[1][off + int(dd.argmax())]), float(got[1][off + int(dd.argmax())])))
             off += s
 print("mismatches: %d of %d" % (bad, rounds))

@@ -351,11 +351,45 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(TView x, TView dz, 
   }
 }
 
+// Tiny tensors (at most 64 voxels: ONE partial row -- the last SoundNet layers at small batches, 6 x 1024 at two clips): a thread
+// per channel walks the voxels in order.  No LDS, no cross-thread step, one exit.  (Round 5: beside the weight-gradient stream the
+// 256-thread kernels above dropped, in ~7 % of their launches on such a tensor, one voxel's term of one channel slot for the last
+// 16 lanes of a wave -- transient, a second launch right behind the first is exact)
+template <typename T, int MODE>
+__global__ __launch_bounds__(64) void channel_reduce_small_kernel(TView x, TView dz, Affine fwd, const float* mean, const float* invstd,
+                                                                  int nvox, float* __restrict__ partials) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= x.C) return;
+  float s = 0.f, p = 0.f;
+  const float mu = MODE == 1 ? mean[c] : 0.f, is = MODE == 1 ? invstd[c] : 1.f;
+  const float sc = (MODE == 1 && fwd.relu && fwd.scale) ? fwd.scale[c] : 1.f, sh = (MODE == 1 && fwd.relu && fwd.shift) ? fwd.shift[c] : 0.f;
+  for (int v = 0; v < nvox; ++v) {
+    const float xv = load1<T>((const T*)x.p + vox_lin(x, v) + c);
+    if (MODE == 0) {
+      s += xv; p += xv * xv;
+    } else {
+      float gg = load1<T>((const T*)dz.p + vox_lin(dz, v) + c);
+      if (fwd.relu && !(fmaf(xv, sc, sh) > 0.f)) gg = 0.f;
+      s += gg;
+      p += gg * (xv - mu) * is;
+    }
+  }
+  partials[c] = s;
+  partials[x.C + c] = p;
+}
+
+int g_vinet_opt_reduce_small = 1;   // tensors of <= 64 voxels take channel_reduce_small_kernel
 template <int MODE>
 static int launch_channel_reduce(const VinetTensor* x, const VinetTensor* dz, int dtype, VinetAffine fwd,
                                  const float* mean, const float* invstd, float* partials, void* stream) {
   const long nvox = view_voxels(*x);
   const int rows = stats_rows_for(nvox);
+  if (g_vinet_opt_reduce_small && nvox <= 64 && rows == 1) {
+    const TView xs = make_view(*x), ds = dz ? make_view(*dz) : xs;
+    DISPATCH_T(dtype, T, hipLaunchKernelGGL((channel_reduce_small_kernel<T, MODE>), dim3((x->C + 63) / 64), dim3(64), 0,
+                                            (hipStream_t)stream, xs, ds, make_affine(fwd), mean, invstd, (int)nvox, partials);)
+    return vn_launch_status("channel_reduce_small");
+  }
   const long vb = (nvox + rows - 1) / rows;
   const TView xv = make_view(*x), dv = dz ? make_view(*dz) : xv;
   if (MODE == 1 && g_vinet_opt_bn_lean && dtype == VINET_BF16 && dz && oct_ok(*x) && oct_ok(*dz)) {
@@ -409,8 +443,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (threadIdx.x == 0) {
     s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     p = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    if (dgamma) dgamma[c] += (float)p;
-    if (dbeta) dbeta[c] += (float)s;
+    // (atomics, not `x[c] += v`: the read of a plain read-modify-write of this uniform address is a SCALAR load, i.e. it goes
+    //  through the scalar data cache; the accumulators are the optimizer's flat gradient buffer, which other kernels rewrite
+    //  between steps -- see DESIGN.md, round 5, "run-to-run mismatch of audionet.conv7.bias")
+    if (dgamma) atomicAdd(dgamma + c, (float)p);
+    if (dbeta) atomicAdd(dbeta + c, (float)s);
     if (c1) c1[c] = train ? (float)(s / count) : 0.f;
     if (c2) c2[c] = train ? (float)(p / count) : 0.f;
   }
@@ -679,7 +716,8 @@ __global__ __launch_bounds__(256) void channel_sum_finalize_kernel(const float* 
   __syncthreads();
   if (threadIdx.x == 0) {
     s = red[0] + red[1] + red[2] + red[3];
-    out[j] = accumulate ? out[j] + (float)s : (float)s;
+    if (accumulate) atomicAdd(out + j, (float)s);      // (not a scalar-cache read-modify-write: see bn_bwd_finalize_kernel)
+    else out[j] = (float)s;
   }
 }
 

@@ -188,6 +188,7 @@ extern int g_vinet_opt_wgrad_tf;
 extern int g_vinet_opt_wgrad_skinny;
 extern int g_vinet_opt_bn_lean;
 extern int g_vinet_opt_bnb_epi;
+extern int g_vinet_opt_reduce_small;
 extern int g_vinet_opt_bn_rows;
 extern int g_vinet_opt_pack_tiled;
 extern int g_vinet_opt_wgrad_pp_cap;
@@ -249,6 +250,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "dma")) { g_vinet_opt_dma = value; return 0; }
   if (name && !strcmp(name, "dma3")) { g_vinet_opt_dma3 = value; return 0; }
   if (name && !strcmp(name, "bnb_epi")) { g_vinet_opt_bnb_epi = value; return 0; }
+  if (name && !strcmp(name, "reduce_small")) { g_vinet_opt_reduce_small = value; return 0; }
   if (name && !strcmp(name, "pw")) { g_vinet_opt_pw = value; return 0; }
 #ifndef VINET_EXPERIMENTS
   // measured-slower variants live in side builds only (python -c "from vinet_amd import build; build.build_variant('exp', ['-DVINET_EXPERIMENTS'])")
