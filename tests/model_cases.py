@@ -283,19 +283,21 @@ def train_step_case(dev, make_optimizer=None, pred_tol=2e-5, loss_tol=1e-5, grad
         #  B = 2 the deep BatchNorms see 12 samples per channel and single small parameters -- a BatchNorm bias of base3, the stem's
         #  weights, residuals of cancelling sums where the reference's OWN fp32 gradient sits 1.6-3.8 % from fp64 -- amplify a 2^-17
         #  operand error to 5-20 %; what a wrong kernel would do, an O(1) error on a large tensor, the global bound catches)
-        assert e_me <= grad_factor * e_ref + grad_floor, "%s: rel err %.3e vs reference-fp32 %.3e" % (k, e_me, e_ref)
         worst = max(worst, e_me)
     table.sort(reverse=True)
-    train_step_case.last_table = table[:8]
+    train_step_case.last_table = table[:16]
+    train_step_case.worst_ratio = max(((e_me - grad_floor) / max(e_ref, 1e-30), k) for e_me, e_ref, k in table)   # (reported; gated below)
+    num = sum(float((params[k].grad.double().cpu() - truth[k]).pow(2).sum()) for k in params)
+    nref = sum(float((ref32[k] - truth[k]).pow(2).sum()) for k in params)
+    den = sum(float(truth[k].pow(2).sum()) for k in params)
+    train_step_case.global_rel = (num / den) ** 0.5
+    train_step_case.global_ref = (nref / den) ** 0.5
+    for e_me, e_ref, k in table:
+        assert e_me <= grad_factor * e_ref + grad_floor, "%s: rel err %.3e vs reference-fp32 %.3e" % (k, e_me, e_ref)
     assert worst < worst_max, table[:5]
     if global_tol is not None or global_factor is not None:
-        num = sum(float((params[k].grad.double().cpu() - truth[k]).pow(2).sum()) for k in params)
-        nref = sum(float((ref32[k] - truth[k]).pow(2).sum()) for k in params)
-        den = sum(float(truth[k].pow(2).sum()) for k in params)
-        train_step_case.global_rel = (num / den) ** 0.5
-        train_step_case.global_ref = (nref / den) ** 0.5
         # the whole gradient vector against fp64, as an absolute bound and / or relative to the reference's OWN fp32 error against
-        # fp64 (this fixture is ill-conditioned on purpose -- B = 2, 12 samples per channel in the deepest BatchNorms: the
+        # fp64 (the `train_step` fixture is ill-conditioned on purpose -- B = 2, 12 samples per channel in the deepest BatchNorms: the
         # reference's fp32 gradient vector sits 3 % from fp64, ours in exact fp32 3.4 %; an operand error of 2^-17 instead of 2^-24
         # grows the same way, to 15 % measured (direction, not scale: tools/dbg_split_grad.py))
         bound = min(b for b in (global_tol, None if global_factor is None else global_factor * train_step_case.global_ref + 1e-3) if b is not None)
