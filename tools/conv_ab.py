@@ -100,8 +100,10 @@ def main():
     ap.add_argument("--default", action="store_true", help="one variant per library: its own dispatch, no option overrides (A/B of two builds)")
     ap.add_argument("--tm", action="store_true", help="(3,1,1) temporal sites: the halo-tile temporal mode against the ping-pong GEMM kernel (taps re-staged, no halo reuse) and conv_dma")
     ap.add_argument("--acc", action="store_true", help="accumulate into y (the epilogue of a data gradient that joins an existing gradient)")
+    ap.add_argument("--f32s", action="store_true", help="the split-bf16 form (VINET_F32S): fp32 tensors, hi / lo weight planes from vinet_pack_weights; TF/s = useful (one third of the MFMA rate)")
     args = ap.parse_args()
     libs = [(os.path.basename(p), bind(p)) for p in (args.lib or [L.LIB_PATH])]
+    libs_all = [lib for _, lib in libs]
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     variants = []
@@ -173,11 +175,19 @@ def main():
             continue
         B = args.batch
         oT, oH, oW = [(d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip((T, H, W), k, s, p)]
-        x = torch.randn(B * T * H * W * Cin, device=dev).bfloat16()
-        y = torch.empty(B * oT * oH * oW * N, device=dev, dtype=torch.bfloat16)
         ntaps = k[0] * k[1] * k[2]
         Kp = (Cin + 31) // 32 * 32
-        w = (torch.randn(ntaps * N * Kp, device=dev) * 0.05).bfloat16()
+        if args.f32s:
+            x = torch.randn(B * T * H * W * Cin, device=dev)
+            y = torch.empty(B * oT * oH * oW * N, device=dev, dtype=torch.float32)
+            w = torch.empty(ntaps * N * Kp, device=dev, dtype=torch.float32)
+            wm = torch.randn(N * Cin * ntaps, device=dev) * 0.05
+            rc = libs_all[0].vinet_pack_weights(wm.data_ptr(), N, Cin, ntaps, 0, 0, L.F32S, w.data_ptr(), stream)
+            assert rc == 0, libs_all[0].vinet_last_error()
+        else:
+            x = torch.randn(B * T * H * W * Cin, device=dev).bfloat16()
+            y = torch.empty(B * oT * oH * oW * N, device=dev, dtype=torch.bfloat16)
+            w = (torch.randn(ntaps * N * Kp, device=dev) * 0.05).bfloat16()
         taps = torch.tensor([(a - p[0], b - p[1], c - p[2], (a * k[1] + b) * k[2] + c) for a in range(k[0]) for b in range(k[1]) for c in range(k[2])],
                             dtype=torch.int32, device=dev)
         sc, sh = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev)
@@ -188,6 +198,8 @@ def main():
         def desc(pre):
             d = L.CConvDesc()
             d.dtype = d.out_dtype = L.BF16
+            if args.f32s:
+                d.dtype, d.out_dtype = L.F32S, L.F32
             d.mode = 0
             d.x = L.CTensor(x.data_ptr(), B, T, H, W, Cin, Cin, T * H * W * Cin)
             d.y = L.CTensor(y.data_ptr(), B, oT, oH, oW, N, N, oT * oH * oW * N)

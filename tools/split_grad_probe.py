@@ -2,7 +2,7 @@
 """Where does the split-bf16 (fp32s) training step leave the exact fp32 step?  (GPU; no oracle: the engine's own fp32 path is
 the baseline -- tests/test_gpu_model.py::test_train_step_well_conditioned[fp32] holds it within 1.06 x the reference's fp32 error)
 
-    python tools/split_grad_probe.py [--cfg=name=value,...] [--fixture=train_step_wc]
+    python tools/split_grad_probe.py [--cfg=name=value,...] [--fixture=train_step_wc] [--dtype=fp32s|bf16]
 
 Runs the `train_step_wc` problem (ViNet-8, B = 12, 8 x 128 x 192, tests/golden/train_step_wc.npz weights) once per dtype and prints
 the relative L2 distance of every parameter gradient, in REVERSE module order (the loss end first): the first layer whose error
@@ -54,9 +54,13 @@ def grads(dtype, cfg_text=""):
     return float(loss), pred.detach().double().cpu(), out
 
 
+other = "fp32s"
+for a in sys.argv[1:]:
+    if a.startswith("--dtype="):
+        other = a[8:]            # bf16: the benchmarked path against the same baseline
 l0, p0, g0 = grads("fp32")
-l1, p1, g1 = grads("fp32s", cfg)
-print("loss fp32 %.9f fp32s %.9f   pred rel %.3e" % (l0, l1, float((p1 - p0).norm() / p0.norm())))
+l1, p1, g1 = grads(other, cfg)
+print("loss fp32 %.9f %s %.9f   pred rel %.3e" % (l0, other, l1, float((p1 - p0).norm() / p0.norm())))
 num = den = 0.0
 rows = []
 for (n, a), (n2, b) in zip(g0, g1):
