@@ -1,0 +1,39 @@
+"""The static instruction budget of the MFMA loops (tools/isa_audit.py on the in-tree libvinet_hip.so; no GPU needed: the code
+objects are disassembled with llvm-objdump).  Round 4 measured these loops ISSUE-bound: every non-MFMA instruction per MFMA beyond
+~2 costs time (profiles/r4_wrs_phases.txt), so the mix is held here as a regression gate -- a source or toolchain change that bloats
+a K loop fails the CPU suite instead of showing up as a slower step a round later.  Baseline: profiles/r5_isa_audit_baseline.txt."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "vinet_amd", "libvinet_hip.so")
+
+spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+isa_audit = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(isa_audit)
+
+# (substring of the demangled name, MFMAs in the K loop, ceiling on non-MFMA : MFMA) -- measured 2.65 / 2.67 / 3.19 / 2.51 / 1.88
+BUDGET = [
+    ("conv_ht_kernel<6, 16, 3, false, false, false, false>", 48, 2.8),
+    ("conv_ht_kernel<6, 32, 3, false, false, false, false>", 48, 2.8),
+    ("conv_wgrad_rs4_kernel<3, 48>", None, 3.35),
+    ("conv_wgrad_rs4_kernel<3, 96>", None, 2.65),
+    ("conv_dma_kernel<4, 8, 4, 1, 3, false, false>", 32, 2.0),
+]
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(isa_audit.OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_mfma_loops_keep_their_instruction_budget():
+    rows = isa_audit.audit(LIB, ["conv_ht_kernel", "conv_wgrad_rs4_kernel", "conv_dma_kernel"], min_mfma=8)
+    assert rows, "no MFMA loops found: the disassembly or the loop detection broke"
+    for name, mfma, ceiling in BUDGET:
+        mine = [r for r in rows if r["name"].startswith(name)]
+        assert mine, "%s: kernel or its K loop not found (%d loops audited)" % (name, len(rows))
+        main = max(mine, key=lambda r: r["mfma"])            # the K loop proper (prologue / tail loops hold fewer MFMAs)
+        if mfma is not None:
+            assert main["mfma"] == mfma, (name, main)
+        assert main["non_mfma_per_mfma"] <= ceiling, "%s: %.2f non-MFMA instructions per MFMA (ceiling %.2f): %s" % (
+            name, main["non_mfma_per_mfma"], ceiling, {k: main[k] for k in ("n", "mfma", "valu", "salu", "lds", "vmem", "sync", "branch")})
+        assert "16x16x32" in main["shape"]
