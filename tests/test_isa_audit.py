@@ -37,3 +37,15 @@ def test_mfma_loops_keep_their_instruction_budget():
         assert main["non_mfma_per_mfma"] <= ceiling, "%s: %.2f non-MFMA instructions per MFMA (ceiling %.2f): %s" % (
             name, main["non_mfma_per_mfma"], ceiling, {k: main[k] for k in ("n", "mfma", "valu", "salu", "lds", "vmem", "sync", "branch")})
         assert "16x16x32" in main["shape"]
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(isa_audit.OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_no_packed_fp32_instruction_reads_the_high_half_of_its_second_source():
+    """MI355X erratum found in round 5 (csrc/common.h): `v_pk_add_f32 / v_pk_mul_f32 ... op_sel:[x,1]` -- the LOW result
+    half takes the HIGH half of src1 -- reads zero in lanes 48..63 now and then while a wave of another kernel issues MFMAs on the same
+    SIMD (tools/reduce_race_repro.py --pkvariants: 576...784 wrong of 2e9 results for the three affected selections, 0 for the five
+    others; inside a training step it dropped one voxel's term of SoundNet's last-layer bias gradient in 7 % of the launches of
+    channel_reduce8_kernel<bf16, 0>, the only kernel of the library that contained the form).  hipcc emits it wherever it allocated a
+    register pair in swapped order, so this is a gate on the BUILT library: a kernel that shows up here takes VN_NO_PK_F32."""
+    hits = isa_audit.packed_fp32_high_half_reads(LIB)
+    assert not hits, "packed fp32 instructions with op_sel:[x,1] (erratum form) in: %s" % hits

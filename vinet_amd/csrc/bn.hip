@@ -122,7 +122,7 @@ extern "C" int vinet_bn_fold(const float* gamma, const float* beta, const float*
 // 8-channel form of channel_reduce_kernel: same partials contract ([rows][2][C], block b owns voxels
 // [b*vb, (b+1)*vb)), twice the bytes per load instruction.
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void channel_reduce8_kernel(TView x, TView dz, Affine fwd, const float* mean,
+__global__ __launch_bounds__(256) VN_NO_PK_F32 void channel_reduce8_kernel(TView x, TView dz, Affine fwd, const float* mean,
                                                               const float* invstd, long nvox, long vb,
                                                               float* __restrict__ partials) {
   const int G = x.C / 8;
@@ -352,9 +352,10 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(TView x, TView dz, 
 }
 
 // Tiny tensors (at most 64 voxels: ONE partial row -- the last SoundNet layers at small batches, 6 x 1024 at two clips): a thread
-// per channel walks the voxels in order.  No LDS, no cross-thread step, one exit.  (Round 5: beside the weight-gradient stream the
-// 256-thread kernels above dropped, in ~7 % of their launches on such a tensor, one voxel's term of one channel slot for the last
-// 16 lanes of a wave -- transient, a second launch right behind the first is exact)
+// per channel walks the voxels in order.  No LDS, no cross-thread step, one exit.  (Round 5: this kernel was the first mitigation of
+// the run-to-run mismatch of SoundNet's last-layer gradients, before its cause was found -- the packed-fp32 erratum described in
+// common.h, which hit channel_reduce8_kernel<bf16, 0> and nothing else in the library.  It stays: a single 64-thread wave per 64
+// channels is also the cheaper launch for such a tensor.)
 template <typename T, int MODE>
 __global__ __launch_bounds__(64) void channel_reduce_small_kernel(TView x, TView dz, Affine fwd, const float* mean, const float* invstd,
                                                                   int nvox, float* __restrict__ partials) {

@@ -5,7 +5,7 @@
 // Upsample (1,2,2) trilinear, align_corners=False  (separable .25/.75 stencil)
 // ============================================================================
 template <typename T>
-__global__ void upsample2x_kernel(TView x, TView y, long total) {
+__global__ VN_NO_PK_F32 void upsample2x_kernel(TView x, TView y, long total) {     // (VN_NO_PK_F32: common.h -- hipcc emitted the affected form here)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const uint32_t vox_u = fdiv((uint32_t)i, y.dQ);
