@@ -1,7 +1,7 @@
 // Probe for the round-5 defect ("the run-to-run mismatch"): does a VALU instruction issued right behind
 // `s_waitcnt vmcnt(0)` always see ALL of a global_load_dwordx4's return data?
 //
-//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/ubench/libvmem_return_probe.so tools/ubench/vmem_return_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -shared -fPIC -o tools/ubench/libvmem_return_probe.so tools/ubench/vmem_return_probe.hip
 //   python tools/reduce_race_repro.py --probe ...        (drives it beside the library's weight-gradient kernels)
 //
 // One workgroup of 256 threads per launch (the shape of the failing `channel_reduce8_kernel` launch).  Each lane prefills four

@@ -445,8 +445,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     p = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     // (atomics, not `x[c] += v`: the read of a plain read-modify-write of this uniform address is a SCALAR load, i.e. it goes
-    //  through the scalar data cache; the accumulators are the optimizer's flat gradient buffer, which other kernels rewrite
-    //  between steps -- see DESIGN.md, round 5, "run-to-run mismatch of audionet.conv7.bias")
+    //  through the scalar data cache, while the accumulators are the optimizer's flat gradient buffer, which other kernels
+    //  rewrite between steps.  Introduced in round 5 while hunting the run-to-run gradient mismatch; that turned out to be the
+    //  packed-fp32 erratum of common.h, not this -- the atomics stay as the form that does not depend on cache behaviour.)
     if (dgamma) atomicAdd(dgamma + c, (float)p);
     if (dbeta) atomicAdd(dbeta + c, (float)s);
     if (c1) c1[c] = train ? (float)(s / count) : 0.f;

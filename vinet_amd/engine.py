@@ -74,7 +74,7 @@ _CONFIG = dict(
     BRANCH_STREAMS_TRAIN_BATCH=32,
     # ... and in the backward pass (tape markers switch its stream: model_utils._Mixed._fwd_joint_forked_train); eager only, from
     # 8 clips on: +1..1.5 %.  On since round 5: the mismatch that kept it opt-in in round 4 was not the forks' (spin stress on both
-    # sides of every fork passes; the soak reproduced the mismatch on ONE stream -- DESIGN.md, round 5).
+    # sides of every fork passes; the soak reproduced the mismatch on ONE stream; root cause: a packed-fp32 erratum, csrc/common.h).
     BRANCH_STREAMS_BWD=True,
     BRANCH_STREAMS_BWD_MIN_BATCH=8,
     # which branch leaves the capturing stream: the longer chain (branch 1) forks (690 -> 737 fps at batch 1); False = branch 2
