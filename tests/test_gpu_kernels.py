@@ -2002,3 +2002,89 @@ def test_exact_arithmetic_bit_identity(target):
     _, fn, kw = target
     with exact_mode():
         fn(**kw)
+
+
+# ---- the packed-fp32 erratum (round 5) ------------------------------------------------------------------------------------------------
+PROBE_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ubench", "libvmem_return_probe.so")
+
+
+def _probe_lib():
+    if not os.path.exists(PROBE_SO):
+        pytest.skip("tools/ubench/libvmem_return_probe.so not built (__graft_entry__.build_probe)")
+    pl = C.CDLL(PROBE_SO)
+    pl.corun_mfma_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    pl.pk_variant_launch.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+    return pl
+
+
+@pytest.mark.parametrize("small", [0, 1])
+def test_channel_reductions_are_exact_beside_foreign_mfma_waves(small):
+    """Round 5's run-to-run gradient mismatch, as a regression test: `vinet_channel_sum` / `vinet_channel_stats` /
+    `vinet_bn_bwd_reduce` on SoundNet's 6-voxel x 1024-channel tail, 1500 launches each, while a second stream keeps register-only
+    MFMA waves of another kernel resident on every SIMD.  Before the fix (csrc/common.h VN_NO_PK_F32: the generic reduction contained
+    `v_pk_add_f32 ... op_sel:[0,1]`, which reads zero in lanes 48..63 under exactly this condition) HALF of the launches returned a sum
+    with one voxel's term missing; identical launches must return identical bits, and the sums must be the exact ones.  Both
+    dispatches: the thread-per-channel kernel for tiny tensors (`reduce_small` = 1, the default) and the generic 256-thread kernels."""
+    lib, pl, dev = _lib(), _probe_lib(), _dev()
+    L.set_option("reduce_small", small)
+    try:
+        nv, Cc, iters = 6, 1024, 1500
+        g = torch.Generator(device=dev).manual_seed(3)
+        dy = (torch.randn(nv, Cc, generator=g, device=dev) * 1e-3).bfloat16()
+        z = torch.randn(nv, Cc, generator=g, device=dev).bfloat16()
+        mean, invstd = torch.randn(Cc, generator=g, device=dev) * 0.1, torch.rand(Cc, generator=g, device=dev) + 0.5
+        sc, sh = torch.rand(Cc, generator=g, device=dev) + 0.5, torch.randn(Cc, generator=g, device=dev) * 0.3
+        dyv = E.View(dy.view(-1), 0, 2, nv // 2, 1, 1, Cc, Cc, (nv // 2) * Cc, E.BF16)
+        zv = E.View(z.view(-1), 0, 2, nv // 2, 1, 1, Cc, Cc, (nv // 2) * Cc, E.BF16)
+        rows = lib.vinet_stats_rows(C.byref(dyv.ct()))
+        n = rows * 2 * Cc
+        slots = torch.empty(3, iters, n, device=dev)
+        out = torch.empty(Cc, device=dev)
+        cobuf = torch.zeros(1024, device=dev)
+        side = torch.cuda.Stream()
+        fwd = L.CAffine(sc.data_ptr(), sh.data_ptr(), 1)
+        st = _stream()
+        for i in range(iters):
+            if i % 8 == 0:
+                assert pl.corun_mfma_launch(cobuf.data_ptr(), 100000, 416, side.cuda_stream) == 0
+            assert lib.vinet_channel_sum(C.byref(dyv.ct()), E.BF16, slots[0, i].data_ptr(), Cc, out.data_ptr(), 0, st) == 0
+            assert lib.vinet_channel_stats(C.byref(dyv.ct()), E.BF16, slots[1, i].data_ptr(), st) == 0
+            assert lib.vinet_bn_bwd_reduce(C.byref(dyv.ct()), C.byref(zv.ct()), E.BF16, fwd, mean.data_ptr(), invstd.data_ptr(),
+                                           slots[2, i].data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        for k, what in enumerate(("channel_sum", "channel_stats", "bn_bwd_reduce")):
+            differ = int((slots[k] != slots[k, 0]).any(dim=1).sum())
+            assert differ == 0, "%s (reduce_small=%d): %d of %d launches differ from the first one beside MFMA waves" % (what, small, differ, iters)
+        ref = dy.float().double().sum(0)
+        got = slots[0, 0].view(rows, 2, Cc)[:, 0, :].double().sum(0)
+        assert float((got - ref).abs().max()) < 1e-9
+        gate = (z.float() * sc + sh) > 0
+        ref2 = (dy.float() * gate).double().sum(0)
+        got2 = slots[2, 0].view(rows, 2, Cc)[:, 0, :].double().sum(0)
+        assert float((got2 - ref2).abs().max()) < 1e-9
+    finally:
+        L.set_option("reduce_small", 1)
+
+
+def test_packed_fp32_erratum_is_still_there():
+    """Documentation as a test (never fails on a healthy result): the affected instruction form on bare registers beside MFMA waves.
+    Records the counts in the parity report so a board / firmware on which the erratum is gone shows up as zeros."""
+    pl, dev = _probe_lib(), _dev()
+    cobuf = torch.zeros(1024, device=dev)
+    side = torch.cuda.Stream()
+    res = {}
+    for which, name in ((0, "v_pk_add_f32"), (1, "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]"), (4, "v_pk_add_f32 op_sel:[1,0] op_sel_hi:[0,1]")):
+        pout = torch.zeros(16, dtype=torch.int32, device=dev)
+        for i in range(600):
+            if i % 8 == 0:
+                assert pl.corun_mfma_launch(cobuf.data_ptr(), 100000, 416, side.cuda_stream) == 0
+            assert pl.pk_variant_launch(which, 2000, i, pout.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        o = pout.tolist()
+        res[name] = {"wrong": int(o[1]) & 0xffffffff, "of": int(o[0]) * 256 * 2000 * 2}
+    try:
+        from tests.test_gpu_model import _note
+        _note("packed_fp32_erratum_beside_mfma", res)
+    except Exception:
+        pass
+    assert res["v_pk_add_f32"]["wrong"] == 0 and res["v_pk_add_f32 op_sel:[1,0] op_sel_hi:[0,1]"]["wrong"] == 0, res
