@@ -238,6 +238,72 @@ PK_VARIANT(pkv_add_swap0, "v_pk_add_f32", "op_sel:[1,0] op_sel_hi:[0,1]", a.y + 
 PK_VARIANT(pkv_mul_swap1, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[1,0]", a.x * b.y, a.y * b.x)
 PK_VARIANT(pkv_mul_bcast_lo0, "v_pk_mul_f32", "op_sel_hi:[0,1]", a.x * b.x, a.x * b.y)
 PK_VARIANT(pkv_mul_hi0, "v_pk_mul_f32", "op_sel:[1,0]", a.y * b.x, a.y * b.y)
+// the same within ONE kernel: a 512-thread workgroup whose waves 0..3 run the swapped packed add and whose waves 4..7 (one per SIMD,
+// beside them) issue MFMAs -- does the co-runner have to be another kernel / queue, or just another wave of the SIMD?
+__global__ __launch_bounds__(512) void pk_self_kernel(int reps, unsigned id, SeqOut* out) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const unsigned t = threadIdx.x;
+  if (t >= 256) {
+    bf16x8_t a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + (t & 63) + i); b[i] = (short)(0x3f00 + i); }
+    f32x4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    for (int it = 0; it < reps * 2; ++it) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c3, 0, 0, 0);
+    }
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.f) out->pad1 = 1;
+    return;
+  }
+  unsigned bad = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    f32x2 a = {1.0f + (float)rep, 2.0f + (float)(t & 15)};
+    f32x2 b = {0.25f * (float)(1 + (t & 7)), 8.0f + (float)(t >> 4)};
+    f32x2 r_;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(r_) : "v"(a), "v"(b));
+    if (r_.x != a.x + b.y || r_.y != a.y + b.x) ++bad;
+  }
+  if (t == 0) atomicAdd(&out->launches, 1u);
+  if (bad) atomicAdd(&out->bad, bad);
+}
+// ... and within one DISPATCH: odd workgroups issue MFMAs, even ones the swapped packed add (256 threads each, 1024 workgroups: they
+// share CUs and SIMDs, but belong to the same kernel launch on the same queue)
+__global__ __launch_bounds__(256) void pk_grid_kernel(int reps, SeqOut* out) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const unsigned t = threadIdx.x;
+  if (blockIdx.x & 1) {
+    bf16x8_t a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + (t & 63) + i); b[i] = (short)(0x3f00 + i); }
+    f32x4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    for (int it = 0; it < reps * 2; ++it) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c3, 0, 0, 0);
+    }
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.f) out->pad1 = 1;
+    return;
+  }
+  unsigned bad = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    f32x2 a = {1.0f + (float)rep, 2.0f + (float)(t & 15)};
+    f32x2 b = {0.25f * (float)(1 + (t & 7)), 8.0f + (float)(t >> 4)};
+    f32x2 r_;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(r_) : "v"(a), "v"(b));
+    if (r_.x != a.x + b.y || r_.y != a.y + b.x) ++bad;
+  }
+  if (t == 0) atomicAdd(&out->launches, 1u);
+  if (bad) atomicAdd(&out->bad, bad);
+}
+extern "C" int pk_grid_launch(int reps, int blocks, void* out, void* stream) {
+  hipLaunchKernelGGL(pk_grid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reps, (SeqOut*)out);
+  return (int)hipGetLastError();
+}
+extern "C" int pk_self_launch(int reps, unsigned id, void* out, void* stream) {
+  hipLaunchKernelGGL(pk_self_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, reps, id, (SeqOut*)out);
+  return (int)hipGetLastError();
+}
 extern "C" int pk_variant_launch(int which, int reps, unsigned id, void* out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   void (*k[8])(int, unsigned, SeqOut*) = {pkv_add_plain, pkv_add_swap1, pkv_add_bcast_lo1, pkv_add_bcast_hi1, pkv_add_swap0, pkv_mul_swap1,

@@ -17,7 +17,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_v;
 // MI355X erratum found in round 5 ("the run-to-run mismatch"; tools/reduce_race_repro.py --pkvariants is the minimal
 // reproduction): a packed fp32 VALU instruction (v_pk_add_f32 / v_pk_mul_f32 / ...) whose LOW result half takes the HIGH half of
 // its second source (`op_sel:[x,1]`) reads that half as ZERO in lanes 48..63 now and then while a wave of ANOTHER kernel issues
-// MFMAs on the same SIMD.  hipcc emits the form wherever it allocated a register pair in swapped order.  Kernels in which it did
+// MFMAs on the same SIMD (another DISPATCH: MFMA waves of the same launch never trigger it).  hipcc emits the form wherever it
+// allocated a register pair in swapped order.  Kernels in which it did
 // are compiled without packed fp32 instructions (this attribute), and tests/test_isa_audit.py fails the CPU suite if the form
 // appears anywhere in the built library.
 #define VN_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
