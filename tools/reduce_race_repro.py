@@ -151,6 +151,15 @@ if "--pkself" in sys.argv:
     torch.cuda.synchronize()
     o = [int(v) & 0xffffffff for v in pout.tolist()]
     print("... beside MFMA workgroups of its OWN dispatch (odd / even workgroups of one launch): %d wrong of %.2e results" % (o[1], o[0] * 256 * 4000 * 2))
+    # two dispatches of the SAME kernel on two queues: every workgroup of one multiplies, every workgroup of the other adds
+    pl.pk_grid_launch2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    pout = torch.zeros(16, dtype=torch.int32, device=dev)
+    for i in range(max(1, iters // 100)):
+        assert pl.pk_grid_launch2(4000, 1024, pout.data_ptr(), side.cuda_stream, 1) == 0
+        assert pl.pk_grid_launch2(4000, 1024, pout.data_ptr(), main, 0) == 0
+    torch.cuda.synchronize()
+    o = [int(v) & 0xffffffff for v in pout.tolist()]
+    print("... beside MFMA workgroups of ANOTHER dispatch of the OWN kernel (same code and registers, second queue): %d wrong of %.2e results" % (o[1], o[0] * 256 * 4000 * 2))
     sys.exit(0)
 if "--pkvariants" in sys.argv:
     # every operand selection of the packed fp32 instructions the library contains, on registers, beside the co-runner

@@ -269,10 +269,12 @@ __global__ __launch_bounds__(512) void pk_self_kernel(int reps, unsigned id, Seq
 }
 // ... and within one DISPATCH: odd workgroups issue MFMAs, even ones the swapped packed add (256 threads each, 1024 workgroups: they
 // share CUs and SIMDs, but belong to the same kernel launch on the same queue)
-__global__ __launch_bounds__(256) void pk_grid_kernel(int reps, SeqOut* out) {
+// role: -1 = odd workgroups multiply, even ones add (one dispatch); 0 = every workgroup adds; 1 = every workgroup multiplies (two
+// dispatches of the SAME kernel -- same code, same register allocation -- on two queues)
+__global__ __launch_bounds__(256) void pk_grid_kernel(int reps, SeqOut* out, int role) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const unsigned t = threadIdx.x;
-  if (blockIdx.x & 1) {
+  if (role < 0 ? (blockIdx.x & 1) : role) {
     bf16x8_t a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + (t & 63) + i); b[i] = (short)(0x3f00 + i); }
     f32x4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
@@ -296,8 +298,12 @@ __global__ __launch_bounds__(256) void pk_grid_kernel(int reps, SeqOut* out) {
   if (t == 0) atomicAdd(&out->launches, 1u);
   if (bad) atomicAdd(&out->bad, bad);
 }
+extern "C" int pk_grid_launch2(int reps, int blocks, void* out, void* stream, int role) {
+  hipLaunchKernelGGL(pk_grid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reps, (SeqOut*)out, role);
+  return (int)hipGetLastError();
+}
 extern "C" int pk_grid_launch(int reps, int blocks, void* out, void* stream) {
-  hipLaunchKernelGGL(pk_grid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reps, (SeqOut*)out);
+  hipLaunchKernelGGL(pk_grid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reps, (SeqOut*)out, -1);
   return (int)hipGetLastError();
 }
 extern "C" int pk_self_launch(int reps, unsigned id, void* out, void* stream) {
