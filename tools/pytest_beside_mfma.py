@@ -5,7 +5,8 @@ corun_mfma_kernel: few registers, no memory traffic) -- the condition under whic
     python tools/pytest_beside_mfma.py tests/test_gpu_kernels.py -q -x -k exact
 
 The exact-arithmetic kernel tests compare bit for bit with the ABI model: any instruction of the library that loses data beside
-foreign MFMA waves fails them here."""
+foreign MFMA waves fails them here.  (Kernel / operator tests only: the co-runner thread launches continuously, which the tests that
+capture hipGraphs or time whole steps do not tolerate.)"""
 import ctypes as C
 import os
 import sys
