@@ -625,178 +625,6 @@ def test_custom_ops_on_device():
     MC.close(xp.grad.permute(0, 4, 1, 2, 3), xq.grad, 1e-5, "pool + upsample op gradient")
 
 
-def _two_rank_worker(rank, world, port, out, backend, force=False):
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
-    import torch.distributed as dist
-    from vinet_amd import loss as VL
-    from vinet_amd import model as VM
-    from vinet_amd import optim as VO
-    from vinet_amd import parallel
-    parallel.FORCE_COLLECTIVES = bool(force)
-    L.load()
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(dev)
-    try:
-        dist.init_process_group(backend, rank=rank, world_size=world)
-        t = torch.ones(4, device=dev)
-        dist.all_reduce(t)
-        torch.cuda.synchronize()
-        assert float(t[0]) == world
-    except Exception as e:     # e.g. RCCL refusing two ranks on one device
-        torch.save(dict(error=repr(e)), os.path.join(out, "rank%d.pt" % rank))
-        return
-    E.set_default_dtype("bf16")
-    x = synth.clip(world, 8, 64, 96, 3).permute(0, 2, 1, 3, 4)[rank:rank + 1].to(dev)
-    gt = synth.gt_map(world, 64, 96, 3)[rank:rank + 1].to(dev)
-    res = {}
-    for mode in ("flat", "bucketed"):
-        m = VM.VideoSaliencyModel(num_clips=8)
-        m.load_state_dict(synth.synth_state_dict(m.state_dict(), 7))
-        m = m.to(dev).train()
-        opt = VO.Adam(parallel.trainable_parameters(m), lr=1e-3)
-        bk = parallel.GradientBuckets(opt, bucket_bytes=4 << 20)
-        for _ in range(2):
-            opt.zero_grad()
-            if mode == "bucketed":
-                bk.begin_step()
-            VL.kldiv(m(x), gt).backward()
-            if mode == "bucketed":
-                bk.finish()
-            else:
-                parallel.allreduce_gradients(opt)
-            if _ == 0:
-                res[mode + "_g"] = (opt.flat_g * opt.grad_scale).cpu()
-            opt.step()
-        torch.cuda.synchronize()
-        res[mode + "_p"] = opt.flat_p.cpu()
-    torch.save(res, os.path.join(out, "rank%d.pt" % rank))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_single_rank_rccl_runs_every_collective_of_the_n_gpu_path(tmp_path):
-    """RCCL itself (backend "nccl"), which refuses two ranks on one device: a ONE-rank process group with
-    parallel.FORCE_COLLECTIVES, so the flat all-reduce, the bucketed all-reduces issued from the tape on the communication
-    stream (event-joined with the main and the weight-gradient streams) and the final waits all go through the RCCL library on
-    the GPU.  A one-rank SUM is the identity: both orders must give the same gradients and parameters; then the bench
-    command line runs the same way (barrier, MAX all-reduce of the elapsed time, bucketed step)."""
-    import socket
-    import subprocess
-    import sys
-    import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_two_rank_worker, args=(1, port, str(tmp_path), "nccl", True), nprocs=1, join=True)
-    r = torch.load(str(tmp_path / "rank0.pt"))
-    assert "error" not in r, r
-    dg = float((r["bucketed_g"] - r["flat_g"]).abs().max() / (r["flat_g"].abs().max() + 1e-30))
-    dp = float((r["bucketed_p"] - r["flat_p"]).abs().max() / (r["flat_p"].abs().max() + 1e-30))
-    # (two runs: the weight-gradient atomics order their fp32 sums differently; where that flips the sign of a vanishing
-    #  gradient, Adam's step of lr = 1e-4 puts one weight 2e-4 apart -- relative to max |p| ~ 3 that is < 1e-4)
-    assert dg < 1e-6 and dp < 1e-4, (dg, dp)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port + 1 if port < 65000 else port - 1), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
-                          "--no-sweep", "--no-cpu-baseline", "--force-collectives"], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0
-    _note("single_rank_rccl", dict(bucketed_vs_flat_grad=dg, bucketed_vs_flat_param=dp, bench_clips_per_s=line["value"]))
-
-
-def test_gradient_bucket_timeline_stamps_the_end_of_the_collective(monkeypatch):
-    """GradientBuckets.timeline(): `done_ms` must be the END of a bucket's all-reduce.  RCCL runs a collective on the process
-    group's own stream and only `work.wait()` orders the caller's stream behind it, so an event recorded right behind the call
-    stamps the ISSUE (0.012 ms for a 62 MB bucket).  A stand-in collective with RCCL's stream semantics -- it idles
-    ~2 ms on a private stream, `wait()` makes the current stream wait for its end event -- must show up in done - issue."""
-    from vinet_amd import _lib
-    from vinet_amd import loss as VL
-    from vinet_amd import model as VM
-    from vinet_amd import optim as VO
-    from vinet_amd import parallel
-    lib = _lib.load()
-    E.set_default_dtype("bf16")
-    priv = torch.cuda.Stream(DEV)
-    spin = 5000000       # shader clocks: 2 ms and more at any DVFS state
-
-    class Work:
-        def __init__(self, ev):
-            self.ev = ev
-
-        def wait(self):
-            torch.cuda.current_stream(DEV).wait_event(self.ev)
-
-    def fake_all_reduce(t, op=None, async_op=False):
-        priv.wait_stream(torch.cuda.current_stream(DEV))
-        with torch.cuda.stream(priv):
-            assert lib.vinet_debug_spin(spin, priv.cuda_stream) == 0
-            ev = torch.cuda.Event()
-            ev.record()
-        return Work(ev)
-
-    monkeypatch.setattr(parallel, "distributed", lambda: True)
-    monkeypatch.setattr(parallel.dist, "all_reduce", fake_all_reduce)
-    monkeypatch.setattr(parallel.dist, "get_world_size", lambda: 1)
-    B, T, H, W = 2, 8, 64, 96
-    x = synth.clip(B, T, H, W, 5).permute(0, 2, 1, 3, 4).to(DEV).contiguous()
-    gt = synth.gt_map(B, H, W, 5).to(DEV)
-    m = VM.VideoSaliencyModel(num_clips=T)
-    m.load_state_dict(synth.synth_state_dict(m.state_dict(), 5))
-    m = m.to(DEV).train()
-    opt = VO.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
-    buckets = parallel.GradientBuckets(opt)
-    buckets.timing = True
-    try:
-        for _ in range(2):
-            opt.zero_grad()
-            buckets.begin_step()
-            VL.kldiv(m(x), gt).backward()
-            buckets.finish()
-            opt.step()
-        tl = buckets.timeline()
-    finally:
-        E.PARAM_GRAD_HOOK = None
-    assert tl is not None and len(tl["buckets"]) >= 4
-    short = [b for b in tl["buckets"] if b["done_ms"] - b["issue_ms"] < 1.0]
-    assert not short, "completion stamps that are really issue stamps: %s" % short
-    _note("bucket_timeline_end_stamp", dict(min_ms=min(b["done_ms"] - b["issue_ms"] for b in tl["buckets"]), hidden_frac=tl["hidden_frac"]))
-
-
-def test_two_ranks_on_one_gpu_bucketed_allreduce(tmp_path):
-    """The N > 1 path ON A GPU: two ranks share cuda:0 (backend nccl = RCCL when it accepts two ranks on one device, else
-    gloo on device tensors).  The bucketed all-reduce -- issued from the tape while the weight-gradient side stream and the
-    main stream are both busy, joined by events -- must give the gradients and parameters of the flat one-shot all-reduce
-    after the whole backward, and both replicas must agree."""
-    import socket
-    import torch.multiprocessing as mp
-    used = None
-    for backend in ("nccl", "gloo"):
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        d = tmp_path / backend
-        d.mkdir()
-        mp.spawn(_two_rank_worker, args=(2, port, str(d), backend), nprocs=2, join=True)
-        rs = [torch.load(str(d / ("rank%d.pt" % r))) for r in range(2)]
-        if not any("error" in r for r in rs):
-            used = backend
-            break
-        _note("two_rank_gpu_backend_refused", dict(backend=backend, error=[r.get("error") for r in rs]))
-    assert used is not None, "neither nccl nor gloo could run two ranks on one GPU"
-    r0, r1 = rs
-    assert torch.equal(r0["flat_p"], r1["flat_p"]) and torch.equal(r0["bucketed_p"], r1["bucketed_p"]), "replicas diverged"
-    dg = float((r0["bucketed_g"] - r0["flat_g"]).abs().max() / (r0["flat_g"].abs().max() + 1e-30))
-    assert dg < 1e-6, "bucketed (overlapped) all-reduce differs from the flat one: %g" % dg
-    _note("two_rank_gpu", dict(backend=used, bucketed_vs_flat_grad=dg))
-
-
 def test_config5_full_size_properties():
     """BASELINE config 5 at its full size, 64 x 256 x 448 (no reference exists for it, SURVEY.md F5, and the oracle needs minutes
     per clip there): size-independent properties of the bf16 path -- output shape, finiteness, range, the loss descends over
@@ -878,35 +706,6 @@ def test_graphed_train_step_follows_the_eager_trajectory():
     noise = float((pe - res["eager2"][1]).abs().mean())
     assert float((pe - pg).abs().max()) < 4.2e-4 and float((pe - pg).abs().mean()) <= 1.5 * noise + 5e-6, (noise, float((pe - pg).abs().mean()))
     assert torch.allclose(re_, rg, rtol=1e-3, atol=1e-6) and ne == ng == 2
-
-
-def test_bench_self_spawn_path(tmp_path):
-    """`python bench.py --gpus N` without a launcher re-runs itself as N ranks under torch.distributed.run (one per GPU,
-    backend nccl = RCCL).  With one GPU here: `--spawn` forces that path for N = 1 and `--force-collectives` makes the
-    single rank run every collective of the N > 1 step; asking for more GPUs than the node has is refused (exit code 2)
-    instead of silently measuring one."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2", "--warmup", "1", "--batch", "72",
-                          "--sweep-steps", "1", "--no-cpu-baseline", "--no-extras", "--force-collectives"], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1"
-    # the data-parallel extras of the line: per-bucket issue / completion stamps of the gradient exchange with the share hidden
-    # under backward, and the global-batch sweep (64 of {64, 256, 1536} fits under the 72 clips of this run)
-    ar = line["allreduce"]
-    assert len(ar["buckets"]) >= 4 and abs(sum(b["mb"] for b in ar["buckets"]) - ar["payload_mb"]) < 1.0
-    assert all(b["done_ms"] >= b["issue_ms"] >= 0 for b in ar["buckets"]) and 0.0 <= ar["hidden_frac"] <= 1.0
-    assert list(line["global_batch_sweep"]["global_batch"]) == ["64"] and line["global_batch_sweep"]["global_batch"]["64"]["clips_per_s"] > 0
-    too_many = torch.cuda.device_count() + 1
-    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(too_many), "--steps", "1", "--warmup", "1"],
-                         env=env, capture_output=True, text=True, timeout=300)
-    assert bad.returncode == 2 and "GPU(s) visible" in bad.stderr, (bad.returncode, bad.stderr[-500:])
-    _note("bench_self_spawn", dict(clips_per_s=line["value"], refused_gpus=too_many, allreduce_hidden_frac=ar["hidden_frac"],
-                                   backward_end_ms=ar["backward_end_ms"], buckets=ar["buckets"]))
 
 
 def test_stem_bn_backward_statistics_leave_with_the_temporal_data_gradient():

@@ -54,7 +54,7 @@ def _one_step(m, ys, gt, world_hook=None):
 
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VINET_RDZV_FILE=os.path.join(out, "rdzv"))   # file rendezvous: no port
     torch.set_num_threads(2)
     from tests.abi_emulator import AbiEmulator
     from vinet_amd import _lib as L
@@ -77,7 +77,7 @@ def _worker_graphed(rank, world, port, out):
     """the captured-step wrapper under data parallelism: step = [zero_grad, forward, loss, backward] (a replayed hipGraph on a GPU,
     the same calls eagerly on the ABI emulator) -> ONE all-reduce of the flat gradient buffer -> fused Adam with 1 / world"""
     sys.path.insert(0, ROOT)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VINET_RDZV_FILE=os.path.join(out, "rdzv"))   # file rendezvous: no port
     torch.set_num_threads(2)
     from tests.abi_emulator import AbiEmulator
     from vinet_amd import _lib as L
@@ -155,7 +155,7 @@ def _vinet_batch(B):
 
 def _worker_vinet(rank, world, port, out):
     sys.path.insert(0, ROOT)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VINET_RDZV_FILE=os.path.join(out, "rdzv"))   # file rendezvous: no port
     torch.set_num_threads(2)
     from tests.abi_emulator import AbiEmulator
     from vinet_amd import _lib as L
@@ -278,3 +278,67 @@ def test_gradient_buckets_count_each_parameter_once(monkeypatch):
     assert sent == []
     gb._on_param(None, ps[1])
     assert sent == [1]
+
+
+def _occupied_port_worker(rank, out, port, set_env):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    for k in ("MASTER_ADDR", "MASTER_PORT", "VINET_RDZV_FILE"):
+        os.environ.pop(k, None)
+    if set_env:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from vinet_amd import parallel
+    parallel.FORCE_COLLECTIVES = True
+    parallel.init_from_env(backend="gloo")
+    t = torch.ones(3)
+    dist.all_reduce(t)
+    torch.save(dict(ok=bool((t == 1).all()), port=int(os.environ["MASTER_PORT"])), os.path.join(out, "occ.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["default_29500", "explicit_env_port"])
+def test_one_rank_group_survives_an_occupied_rendezvous_port(tmp_path, which):
+    """the driver's GPU box had the rendezvous port taken and `init_process_group` died with EADDRINUSE.  A
+    one-rank group (bench.py --force-collectives, train.py under FORCE_COLLECTIVES) has nobody to agree a port with, so
+    init_from_env moves to a port the kernel hands out -- with the default 29500 AND an explicit MASTER_PORT both held by a
+    listening socket of this test."""
+    held = socket.socket()
+    held.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        if which == "default_29500":
+            try:
+                held.bind(("", 29500))
+            except OSError:
+                pass                      # somebody else already holds it: equally occupied
+            else:
+                held.listen(1)
+            port = 29500
+        else:
+            held.bind(("", 0))
+            held.listen(1)
+            port = held.getsockname()[1]
+        mp.spawn(_occupied_port_worker, args=(str(tmp_path), port, which != "default_29500"), nprocs=1, join=True)
+    finally:
+        held.close()
+    r = torch.load(os.path.join(tmp_path, "occ.pt"))
+    assert r["ok"] and r["port"] != port, r
+
+
+def test_multi_rank_group_on_an_occupied_port_names_the_ways_out(monkeypatch):
+    from vinet_amd import parallel
+    calls = []
+
+    def boom(*a, **k):
+        calls.append(1)
+        raise RuntimeError("The server socket has failed to listen on any local network address. port: 29500, useIpv6: false, "
+                           "code: -98, name: EADDRINUSE, message: address already in use")
+
+    monkeypatch.setattr(parallel.dist, "init_process_group", boom)
+    monkeypatch.setattr(parallel.dist, "is_initialized", lambda: False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.delenv("VINET_RDZV_FILE", raising=False)
+    with pytest.raises(RuntimeError, match="VINET_RDZV_FILE"):
+        parallel.init_from_env(backend="gloo")
+    assert len(calls) == 1

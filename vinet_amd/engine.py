@@ -599,9 +599,21 @@ class Ctx:
             # every weight-gradient kernel ADDS into its plan's persistent workspace, which only the unpack launch hands back
             # zeroed: a backward pass that dies between the two would leave a residue that every later step silently adds to
             # its gradient.  Drop the workspaces this pass touched (the next use allocates zero-filled ones).
+            # The weight-gradient kernels launched so far may still be RUNNING on the side streams, and the workspaces were
+            # allocated on the main stream: join them first, or the caching allocator could hand the blocks to the next
+            # main-stream allocation while atomics still land in them.  (Not inside a capture: synchronising would invalidate it,
+            # and a failed capture is discarded as a whole anyway.)
+            if self.device.type == "cuda" and not self.capturing:
+                try:
+                    for st in self.side_streams():
+                        torch.cuda.current_stream(self.device).wait_stream(st)
+                    torch.cuda.current_stream(self.device).synchronize()
+                except Exception:
+                    pass
             for plan in self._dw_plans:
                 plan._dw_ws.clear()
             self._deferred, self._unpack_jobs = [], []
+            self._side_keep, self._bnb, self.tape = [], {}, []
             raise
         if getattr(self, "side_used", False):
             # the optimizer (and every buffer release that follows) is ordered after the side stream

@@ -38,8 +38,28 @@ def distributed():
     return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _address_in_use(err):
+    msg = str(err).lower()
+    return "eaddrinuse" in msg or "address already in use" in msg or "errno: 98" in msg
+
+
 def init_from_env(backend=None):
-    """torchrun / torch.distributed.run environment -> (rank, world, local_rank, device)."""
+    """torchrun / torch.distributed.run environment -> (rank, world, local_rank, device).
+
+    Rendezvous, in this order:
+      * VINET_RDZV_FILE=<path>: a `FileStore` -- no TCP port at all (launchers without torchrun; the functional tests);
+      * MASTER_ADDR / MASTER_PORT from the launcher (torch.distributed.run hands its workers the agent's store, so nothing
+        is bound here);
+      * a ONE-rank group (world == 1 with FORCE_COLLECTIVES) has no peer to agree a port with: if the port -- the default
+        29500 or one from the environment -- is taken (EADDRINUSE), it retries on ports the kernel hands out.  A multi-rank
+        group whose port is taken cannot be repaired from inside one rank: the error names the two ways out."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -49,10 +69,25 @@ def init_from_env(backend=None):
     if use_cuda:
         torch.cuda.set_device(device)
     if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
+        backend = backend or ("nccl" if use_cuda else "gloo")
+        rdzv_file = os.environ.get("VINET_RDZV_FILE")
+        if rdzv_file:
+            dist.init_process_group(backend, store=dist.FileStore(rdzv_file, world), rank=rank, world_size=world)
+            return rank, world, local, device
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if use_cuda else "gloo")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        for attempt in range(8):
+            try:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+                break
+            except Exception as e:      # torch raises DistNetworkError / RuntimeError depending on where the bind fails
+                if not _address_in_use(e):
+                    raise
+                if world > 1 or attempt == 7:
+                    raise RuntimeError("rendezvous port %s:%s is in use: pass another --master-port to the launcher, or set "
+                                       "VINET_RDZV_FILE to a fresh path for a file rendezvous"
+                                       % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"])) from e
+                os.environ["MASTER_PORT"] = str(_free_port())
     return rank, world, local, device
 
 
