@@ -367,3 +367,58 @@ def weight_shared_case(dev, dt, tol):
     for k, e in errs:
         assert e <= tol, "weight-shared conv: %s rel err %g > %g" % (k, e, tol)
     return dict(errs)
+
+
+def trajectory_batches(meta):
+    """the fixture's rotation of synthetic batches, by recipe (tests/golden/make_goldens.py trajectory_batches)"""
+    B, T, H, W, seed = meta["B"], meta["T"], meta["H"], meta["W"], meta["seed"]
+    return [(synth.clip(B, T, H, W, seed + 100 * i).permute(0, 2, 1, 3, 4).contiguous(), synth.gt_map(B, H, W, seed + 100 * i))
+            for i in range(meta["batches"])]
+
+
+def trajectory_run(model, kldiv, make_optimizer, batches, steps, dev):
+    """train.py:208-217: zero_grad -> model -> kldiv -> backward -> step, `steps` times over the rotation; the per-step losses"""
+    model.train()
+    opt = make_optimizer([p for p in model.parameters() if p.requires_grad])
+    bs = [(x.to(dev), g.to(dev)) for x, g in batches]
+    losses = []
+    for i in range(steps):
+        x, gt = bs[i % len(bs)]
+        opt.zero_grad()
+        loss = kldiv(model(x), gt)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+    return np.array([float(l) for l in losses])
+
+
+def trajectory_case(dev, dtype, steps=None):
+    """the vinet_amd path against the REFERENCE's training trajectory (tests/golden/train_trajectory.npz): returns
+    dict(losses, ref, rel = |l - ref| / ref per step, end_rel, eval_after, eval_after_ref, state_rel = worst per-tensor
+    || p_end - p_ref_end ||-proxy from the stored checksums)"""
+    from vinet_amd import loss as VL
+    from vinet_amd import model as VM
+    from vinet_amd import optim as VO
+    z, meta = G.load("train_trajectory")
+    steps = steps or meta["steps"]
+    E.set_default_dtype(dtype)
+    m = VM.VideoSaliencyModel(num_clips=meta["T"])
+    m.load_state_dict(G.state_dict_for(m, meta["seed"], z, meta))
+    m = m.to(dev)
+    batches = trajectory_batches(meta)
+    losses = trajectory_run(m, VL.kldiv, lambda ps: VO.Adam(ps, lr=meta["lr"]), batches, steps, dev)
+    ref = z["losses"][:steps]
+    out = dict(losses=losses, ref=ref, rel=np.abs(losses - ref) / np.abs(ref))
+    if steps == meta["steps"]:
+        m.eval()
+        with torch.no_grad():
+            out["eval_after"] = float(VL.kldiv(m(batches[0][0].to(dev)), batches[0][1].to(dev)))
+        out["eval_after_ref"] = float(z["eval_loss_after"])
+        # parameter space: per tensor |sum(p) - sum(p_ref)| against how far training moved that tensor (||p_end - p_0||, stored)
+        names = json.loads(str(z["state_names"]))
+        sd = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+        sq = np.array([float((sd[k] ** 2).sum()) for k in names])
+        moved = z["state_delta_norm"]
+        big = moved > 1e-3
+        out["state_norm_rel"] = float(np.max(np.abs(np.sqrt(sq[big]) - np.sqrt(z["state_sqsum"][big])) / moved[big]))
+    return out

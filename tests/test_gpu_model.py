@@ -625,6 +625,33 @@ def test_custom_ops_on_device():
     MC.close(xp.grad.permute(0, 4, 1, 2, 3), xq.grad, 1e-5, "pool + upsample op gradient")
 
 
+# the band a dtype's loss curve must stay in around the REFERENCE's (relative, every step), and its end-of-run figures
+TRAJECTORY_BANDS = {"fp32": dict(step_rel=1e-3, end_rel=1e-3, eval_rel=2e-3), "fp32s": dict(step_rel=5e-3, end_rel=5e-3, eval_rel=1e-2),
+                    "bf16": dict(step_rel=0.10, end_rel=0.10, eval_rel=0.10)}
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp32s", "bf16"])
+def test_training_trajectory_follows_the_reference(dtype):
+    """does the path TRAIN like the reference?  The reference's own loop (train.py:208-217: zero_grad ->
+    model -> kldiv -> backward -> Adam(lr 1e-4)) was run for 48 steps over a fixed rotation of 4 synthetic batches of ViNet-8 (B = 8,
+    8 x 128 x 192) and its loss per step, final state checksums and eval loss stored (tests/golden/train_trajectory.npz; generator:
+    make_goldens.py round6).  The HIP path takes the same 48 steps in each arithmetic: fp32 must track the reference's loss within
+    1e-3 relative at EVERY step, fp32s within 5e-3, bf16 -- the bench headline's dtype -- within 10 %, and the loss at the end
+    (mean of the last 4 steps: one pass over the rotation) and the eval-mode loss on batch 0 within the same bands."""
+    band = TRAJECTORY_BANDS[dtype]
+    r = MC.trajectory_case(DEV, dtype)
+    worst = int(np.argmax(r["rel"]))
+    end, end_ref = float(r["losses"][-4:].mean()), float(r["ref"][-4:].mean())
+    _note("train_trajectory_" + dtype, dict(steps=len(r["ref"]), worst_step=worst, worst_rel=float(r["rel"][worst]), end_loss=end, end_loss_ref=end_ref,
+                                            end_rel=abs(end - end_ref) / end_ref, eval_after=r["eval_after"], eval_after_ref=r["eval_after_ref"],
+                                            state_norm_rel=r["state_norm_rel"], losses=[round(float(v), 6) for v in r["losses"]]))
+    assert np.isfinite(r["losses"]).all()
+    assert float(r["rel"].max()) <= band["step_rel"], "%s: step %d loss %.6f vs reference %.6f (rel %.3g > %.3g)" % (
+        dtype, worst, r["losses"][worst], r["ref"][worst], r["rel"][worst], band["step_rel"])
+    assert abs(end - end_ref) <= band["end_rel"] * end_ref, (dtype, end, end_ref)
+    assert abs(r["eval_after"] - r["eval_after_ref"]) <= band["eval_rel"] * r["eval_after_ref"], (dtype, r["eval_after"], r["eval_after_ref"])
+
+
 def test_config5_full_size_properties():
     """BASELINE config 5 at its full size, 64 x 256 x 448 (no reference exists for it, SURVEY.md F5, and the oracle needs minutes
     per clip there): size-independent properties of the bf16 path -- output shape, finiteness, range, the loss descends over

@@ -161,6 +161,24 @@ def test_train_step():
     _close(loss1, z["loss1"], 1e-5)
 
 
+@pytest.mark.slow
+def test_training_trajectory_first_steps():
+    """tests/golden/train_trajectory.npz is the REFERENCE's own training loop (train.py:208-217 semantics, Adam lr 1e-4, 48 steps over
+    a rotation of 4 synthetic batches; the generator refuses to write it unless the oracle reproduces all 48 losses and the final
+    state).  Here, on every CPU run: the oracle's first 6 steps land on the stored losses (the first epoch over the rotation and the
+    start of the second: the Adam moments, BatchNorm statistics and batch order are all in play), the stored curve descends by the
+    factor the generator printed, and every stored quantity is finite."""
+    from tests import model_cases as MC
+    z, meta = G.load("train_trajectory")
+    ref = z["losses"]
+    assert meta["steps"] == len(ref) == 48 and meta["batches"] == 4 and np.isfinite(ref).all()
+    assert ref[-4:].mean() < 0.2 * ref[:4].mean(), "the fixture is meant to be a trajectory that trains"
+    m = O.VideoSaliencyModel(num_clips=meta["T"])
+    m.load_state_dict(G.state_dict_for(m, meta["seed"], z, meta))
+    got = MC.trajectory_run(m, O.kldiv, lambda ps: torch.optim.Adam(ps, lr=meta["lr"]), MC.trajectory_batches(meta), 6, torch.device("cpu"))
+    np.testing.assert_allclose(got, ref[:6], rtol=2e-5, atol=0)
+
+
 # ---- oracle/postproc_cpu.py: cv2 / torchvision are absent here ("parity unpinned"); the restatement is checked against two
 # independent implementations of the same published algorithms and against closed-form properties -------------------------
 def test_postproc_resize_matches_half_pixel_bilinear():

@@ -90,36 +90,51 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   const int h0 = th_i * TR, w0 = tw_i * TW;
   const int p0 = tw_i * 64, HWtot = a.Hi * a.Wi;     // (temporal mode: first position of the tile, positions per frame)
 
-  // ---- this lane's DMA role: row (lane >> 3) of an 8-row piece, LDS slot (lane & 7), source chunk slot ^ row -----------
+  // ---- this lane's DMA role: row (lane >> 3) of an 8-row piece, LDS slot (lane & 7), source chunk slot ^ key(position) ----
+  // Swizzle key of a halo position.  LINA (every form but the spatial PRE one): the position's COLUMN inside its halo row, & 7 --
+  // a fragment read touches 16 consecutive columns of ONE halo row, whose keys take all 8 values twice (conflict-free exactly as
+  // with p & 7), and the key no longer depends on the halo ROW: the four A fragments of a lane (rows r, r + 1, ... of the tile, or
+  // columns c, c + 16) then share one swizzle term per tap and differ by COMPILE-TIME byte offsets, which go into the ds_read's
+  // immediate -- 4 vector instructions of address arithmetic per K step instead of 26 (round 6; tools/isa_audit.py).  Temporal
+  // mode: HW = 64, so column & 7 == p & 7 and nothing moves.  Spatial PRE keeps p & 7 (its in-LDS affine reads ONE scale / shift
+  // group per lane, which needs one source chunk per lane).
+  constexpr bool LINA = TM || !PRE;
   const int prow = lane >> 3;
-  const int src_chunk = (lane & 7) ^ prow;
+  const int src_chunk = (lane & 7) ^ prow;                 // weight ring (rows n & 7 == prow) and the p & 7 halo forms
   int hal_off[HL];            // element offset of this lane's halo position inside a frame (+ its chunk); 0 when out of range
   unsigned hal_ok = 0;
+  unsigned long long hal_scq = 0;                          // (LINA, spatial) this lane's source chunk of piece j, 3 bits each
 #pragma unroll
   for (int j = 0; j < HL; ++j) {
     const int p = (j * 4 + wave) * 8 + prow;
     const int hr = p / HW, hc = p - hr * HW;
+    const int sc = (LINA && !TM) ? ((lane & 7) ^ (hc & 7)) : src_chunk;
+    hal_scq |= (unsigned long long)sc << (3 * j);
     if constexpr (TM) {     // halo row = frame t0 - 1 + hr (added at issue time: uniform per piece), column = position p0 + hc
       const bool ok = (p < Cfg::NPOS) & (p0 + hc < HWtot);
-      hal_off[j] = ok ? (p0 + hc) * a.ldx + src_chunk * PE : 0;
+      hal_off[j] = ok ? (p0 + hc) * a.ldx + sc * PE : 0;
       hal_ok |= (unsigned)ok << j;
     } else {
       const int h = h0 - 1 + hr, w = w0 - 1 + hc;
       const bool ok = (p < Cfg::NPOS) & ((unsigned)h < (unsigned)a.Hi) & ((unsigned)w < (unsigned)a.Wi);
-      hal_off[j] = ok ? (h * a.Wi + w) * a.ldx + src_chunk * PE : 0;
+      hal_off[j] = ok ? (h * a.Wi + w) * a.ldx + sc * PE : 0;
       hal_ok |= (unsigned)ok << j;
     }
   }
   const char* const xb = a.x + (long)b * a.sBx * ES;
   const long frame_elems = (long)a.Hi * a.Wi * a.ldx;
-  long b_off[BL];
-  unsigned b_ok[BL];
+  // weight piece j of this lane: row n of the column tile, chunk src_chunk -- as a POINTER for (slice 0, channel chunk 0); a K step
+  // adds one wave-uniform 64-bit offset (v_lshl_add_u64 with a scalar pair: one instruction per DMA, where the masked zero-page
+  // selection took eight).  No zero page on this side any more: rows past Nw read the LAST real row (their columns are never
+  // stored: conv_epilogue masks n < N), steps past the group's last tap read a real tap into a slot nobody consumes, and the K
+  // overhang of a last half chunk (Kp % 64 == 32, bf16 form) is redirected 64 bytes back inside the same row -- finite weights
+  // against activations that ARE zero there (the halo side keeps its zero page for channels >= Cin).
+  const char* wp[BL];
 #pragma unroll
   for (int j = 0; j < BL; ++j) {
     const int n = (j * 4 + wave) * 8 + prow;
     const int nn = tile_n * Cfg::BN + n;
-    b_ok[j] = (unsigned)(nn < a.Nw);
-    b_off[j] = ((long)(b_ok[j] ? nn : 0) * a.Kp * (SPLIT ? 2 : 1) + src_chunk * 8) * 2;      // (split: a row is Kp hi + Kp lo)
+    wp[j] = a.w + ((long)(nn < a.Nw ? nn : a.Nw - 1) * a.Kp * (SPLIT ? 2 : 1) + src_chunk * 8) * 2;      // (split: a row is Kp hi + Kp lo)
   }
   const long slice_bytes = (long)a.Nw * a.Kp * (SPLIT ? 4 : 2);
 
@@ -131,13 +146,15 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   // which of this lane's halo elements are real activations in the image staged last (PRE: the others must stay zero)
   unsigned hal_live = 0;
   auto issue_halo = [&](int dt, int c0) {
-    const unsigned cok = (unsigned)(c0 + src_chunk * PE < a.Cin);
+    // channels past Cin read the zero page: only a LAST chunk can hold any (lim < 8 pieces of PE channels are real)
+    const int lim = (a.Cin - c0 + PE - 1) / PE;
     hal_live = 0;
 #pragma unroll
     for (int j = 0; j < HL; ++j) {
       // spatial: one frame (temporal offset dt of the tap group); temporal: piece (j, wave) belongs to frame to - 1 + its halo row
       const int t = TM ? to - 1 + ((j * 4 + wave) * 8) / HW : to * a.sT + dt;
-      const unsigned ok = cok & (unsigned)((unsigned)t < (unsigned)a.Ti) & ((hal_ok >> j) & 1u);
+      const int sc = (LINA && !TM) ? (int)((hal_scq >> (3 * j)) & 7u) : src_chunk;
+      const unsigned ok = (unsigned)(sc < lim) & (unsigned)((unsigned)t < (unsigned)a.Ti) & ((hal_ok >> j) & 1u);
       const char* base = xb + ((long)t * frame_elems + c0) * ES;
       const char* src = zero + (((base + (long)hal_off[j] * ES) - zero) & -(long)ok);
       dma(src, halo + (j * 4 + wave) * 1024);
@@ -185,17 +202,11 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
     }
     __syncthreads();   // (plain loads above are complete before any DMA is counted)
   }
-  // weight tile of (slice, c0) into ring slot `slot`; live == false: the same number of DMAs from the zero page
-  auto issue_b = [&](int slot, bool live, int slice, int c0) {
+  // weight tile at wave-uniform byte offset `delta` (slice * slice_bytes + chunk) into ring slot `slot`
+  auto issue_b = [&](int slot, long delta) {
     char* dst = bring + slot * Cfg::BSLOT_BYTES + wave * 1024;
-    const long delta = (long)slice * slice_bytes + (long)c0 * (SPLIT ? 4 : 2);
-    const unsigned cok = (unsigned)live & (unsigned)(SPLIT || c0 + src_chunk * 8 < a.Kp);
 #pragma unroll
-    for (int j = 0; j < BL; ++j) {
-      const unsigned ok = cok & b_ok[j];
-      const char* src = zero + (((a.w + b_off[j] + delta) - zero) & -(long)ok);
-      dma(src, dst + j * 4096);
-    }
+    for (int j = 0; j < BL; ++j) dma(wp[j] + delta, dst + j * 4096);
   };
 
   // ---- fragments ---------------------------------------------------------------------------------------------------------
@@ -237,18 +248,42 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   const int kq = lane >> 4;                                           // this lane's 16-byte k group inside a 32-wide K half
   const int bfo0 = (lane & 15) * 128 + (((kq) ^ (lane & 7)) << 4);    // weight fragment rows: n & 7 == lane & 7
   const int bfo1 = (lane & 15) * 128 + (((4 + kq) ^ (lane & 7)) << 4);
+  // LINA: byte address of fragment 0's row for a tap = a128 + (tap's halo offset + 128) * 128 [scalar] + swizzle term, where the
+  // term is ((column + dx) & 7) ^ kq, in units of 16 bytes: computed on (column + 1) << 4 with the tap's (dx + 1) << 4 added
+  // [scalar], masked to bits 4..6 and XORed with kq << 4 -- one add, one bitop3, one add3; the second K half is the same address
+  // ^ 64 (chunk 4 + kq).  Temporal mode: the key is the lane's own (p & 7), the same for every tap.  Fragment i adds a constant.
+  const int a128 = (pl[0] - 128) << 7;
+  const int cl16 = TM ? ((pl[0] & 7) << 4) : ((lane & 15) << 4);    // spatial: column = 1 + (lane & 15) + dx = (lane & 15) + (dx + 1)
+  const int kq16 = kq << 4;
+  auto frag_off = [](int i) constexpr {        // byte offset of A fragment i against fragment 0
+    return TM ? i * 16 * 128 : (TW == 32 ? ((i >> 1) * HW + (i & 1) * 16) * 128 : i * HW * 128);
+  };
 
-  auto compute = [&](int slot, int tapoff) {
+  // one K step: the tap word's halo offset (biased by +128, times 128 bytes) and dx term ((dx + 1) << 4; 0 in temporal mode)
+  auto compute = [&](int slot, int off128, int dx16) {
     const char* Bs = bring + slot * Cfg::BSLOT_BYTES;
+    int ab0 = 0, ab1 = 0;
+    if constexpr (LINA) {
+      const int t16 = TM ? (cl16 ^ kq16) : ((((cl16 + dx16) & 0x70)) ^ kq16);
+      ab0 = a128 + off128 + t16;
+      ab1 = ab0 ^ 64;
+    }
+    const int tapoff = (off128 >> 7) - 128;      // (the p & 7 form only)
+    auto a_addr = [&](int i, int kk) -> const char* {
+      if constexpr (LINA) return halo + (kk ? ab1 : ab0) + frag_off(i);
+      else {
+        const int p = pl[i] + tapoff;
+        return halo + (p << 7) + ((((kk << 2) + kq) ^ (p & 7)) << 4);
+      }
+    };
     if constexpr (SPLIT) {
       // 8 fp32 of this lane's K group (pieces q and q + 4 of the row: the K order the hi / lo weight planes are packed in)
       uint4 ar[MT][2];
       bf16x8_v bh[NT], bl[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int p = pl[i] + tapoff;
-        ar[i][0] = *(const uint4*)(halo + (p << 7) + ((kq ^ (p & 7)) << 4));
-        ar[i][1] = *(const uint4*)(halo + (p << 7) + (((4 + kq) ^ (p & 7)) << 4));
+        ar[i][0] = *(const uint4*)a_addr(i, 0);
+        ar[i][1] = *(const uint4*)a_addr(i, 1);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -281,10 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int p = pl[i] + tapoff;
-        af[kk][i] = *(const bf16x8_v*)(halo + (p << 7) + ((((kk << 2) + kq) ^ (p & 7)) << 4));
-      }
+      for (int i = 0; i < MT; ++i) af[kk][i] = *(const bf16x8_v*)a_addr(i, kk);
 #pragma unroll
       for (int j = 0; j < NT; ++j) bfr[kk][j] = *(const bf16x8_v*)(Bs + j * 2048 + (kk ? bfo1 : bfo0));
     }
@@ -309,7 +341,10 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
 #endif
   int t0 = 0;
   while (t0 < a.ntaps) {
-    // tap rows of the group, packed into scalar registers: (slice << 8 | halo offset + 128) in 16 bits each
+    // tap words of the group, 16 bits each, word j at bit 16 j of a 144-bit scalar queue (q0, q1, q2):
+    //   [7:0] halo offset + 128   [9:8] dx + 1 (0 in temporal mode)   [15:10] weight slice (< 64: vinet_conv_use_ht)
+    // Every step takes word 0 (its own tap) and the slice of word BSLOTS - 1 (the weight tile it sends for), then the queue shifts
+    // down by one word -- zeros come in at the top: slice 0, a real tap, for the steps that prefetch past the group's end.
     unsigned long long tq0 = 0, tq1 = 0;
     uint32_t tq2 = 0;
     const int dt = load_tap(a.taps, t0).x;
@@ -320,26 +355,29 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
       const int4 tp = load_tap(a.taps, t0 + j < a.ntaps ? t0 + j : t0);
       const bool same = in && (TM || tp.x == dt);           // temporal mode: every tap is (dt, 0, 0): one group
       const int off = TM ? tp.x * HW : tp.y * HW + tp.z;     // halo offset of the tap: rows are frames there
-      const unsigned long long e = (unsigned long long)(((tp.w & 0xff) << 8) | ((off + 128) & 0xff));
+      const unsigned long long e = (unsigned long long)(((tp.w & 0x3f) << 10) | ((TM ? 0 : (tp.z + 1) & 3) << 8) | ((off + 128) & 0xff));
       if (j < 4) tq0 |= e << (j * 16);
       else if (j < 8) tq1 |= e << ((j - 4) * 16);
       else tq2 = (uint32_t)e;
       nt += same ? 1 : 0;
     }
-    auto tap_word = [&](int j) {      // j may be >= nt (prefetch past the group): the caller masks with `live`
-      const unsigned long long q = j < 4 ? tq0 : tq1;
-      const uint32_t w16 = j < 8 ? (uint32_t)(q >> ((j & 3) * 16)) : tq2;
-      return w16 & 0xffffu;
-    };
+    static_assert(BSLOTS - 1 <= 3, "the prefetched word must sit in the queue's first 64 bits");
     for (int c0 = 0; c0 < a.Kp; c0 += KC) {
 #ifdef VINET_CONV_TIMING
       tm_h0 = __builtin_amdgcn_s_memtime();
 #endif
+      // last half chunk of the bf16 form (Kp % 64 == 32): this lane's chunks 4..7 lie past the row: 64 bytes back (see wp)
+      const long kadj = (!SPLIT && c0 + KC > a.Kp && src_chunk >= 4) ? -64 : 0;
+#pragma unroll
+      for (int j = 0; j < BL; ++j) wp[j] += kadj;
+      const long cbytes = (long)c0 * (SPLIT ? 4 : 2);
+      unsigned long long q0 = tq0, q1 = tq1;
+      uint32_t q2 = tq2;
       __builtin_amdgcn_s_barrier();                // everyone has finished reading the old halo image and ring
       asm volatile("" ::: "memory");
       issue_halo(dt, c0);
 #pragma unroll
-      for (int j = 0; j < BSLOTS - 1; ++j) issue_b(j, j < nt, (int)(tap_word(j) >> 8), c0);
+      for (int j = 0; j < BSLOTS - 1; ++j) issue_b(j, (long)((uint32_t)(q0 >> (16 * j + 10)) & 0x3fu) * slice_bytes + cbytes);
       int slot = 0, fill = BSLOTS - 1;
       for (int j = 0; j < nt; ++j) {
         wait_vmcnt<BL*(BSLOTS - 2)>();             // halo image (first step) and my weight DMAs of this step have landed
@@ -351,13 +389,18 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
 #endif
         __builtin_amdgcn_s_barrier();              // everyone's have; everyone finished reading slot `fill`
         asm volatile("" ::: "memory");
-        const int jn = j + BSLOTS - 1;
-        issue_b(fill, jn < nt, (int)(tap_word(jn < GT ? jn : 0) >> 8), c0);
-        compute(slot, (int)(tap_word(j) & 0xffu) - 128);
+        const uint32_t w0 = (uint32_t)q0;
+        issue_b(fill, (long)((uint32_t)(q0 >> (16 * (BSLOTS - 1) + 10)) & 0x3fu) * slice_bytes + cbytes);
+        compute(slot, (int)((w0 & 0xffu) << 7), (int)((w0 >> 4) & 0x30u));
         asm volatile("" ::: "memory");
+        q0 = (q0 >> 16) | (q1 << 48);
+        q1 = (q1 >> 16) | ((unsigned long long)q2 << 48);
+        q2 = 0;
         slot = slot + 1 == BSLOTS ? 0 : slot + 1;
         fill = fill + 1 == BSLOTS ? 0 : fill + 1;
       }
+#pragma unroll
+      for (int j = 0; j < BL; ++j) wp[j] -= kadj;
     }
     t0 += nt;
   }
