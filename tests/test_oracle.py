@@ -173,6 +173,12 @@ def test_training_trajectory_first_steps():
     ref = z["losses"]
     assert meta["steps"] == len(ref) == 48 and meta["batches"] == 4 and np.isfinite(ref).all()
     assert ref[-4:].mean() < 0.2 * ref[:4].mean(), "the fixture is meant to be a trajectory that trains"
+    # the chaos yardstick stored with it: 8 perturbed-weight runs of the reference + one fp64 run; they agree early and spread later
+    ens, f64 = z["ensemble_losses"], z["fp64_losses"]
+    assert ens.shape == (8, 48) and f64.shape == (48,) and np.isfinite(ens).all() and np.isfinite(f64).all()
+    allm = np.vstack([ens, ref[None], f64[None]])
+    assert float((allm[:, :6].std(0) / allm[:, :6].mean(0)).max()) < 2e-3, "members must still agree over steps 0..5 (the tight gate's window)"
+    assert float((allm[:, 16:].std(0) / allm[:, 16:].mean(0)).mean()) > 0.1, "... and be O(0.1..1) apart later: that is why the late gate is statistical"
     m = O.VideoSaliencyModel(num_clips=meta["T"])
     m.load_state_dict(G.state_dict_for(m, meta["seed"], z, meta))
     got = MC.trajectory_run(m, O.kldiv, lambda ps: torch.optim.Adam(ps, lr=meta["lr"]), MC.trajectory_batches(meta), 6, torch.device("cpu"))

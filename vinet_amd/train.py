@@ -74,7 +74,10 @@ def build_parser():
     p.add_argument('--use_transformer', default=False, type=_bool)
     p.add_argument('--use_vox', default=False, type=_bool)
     # additions of this build
-    p.add_argument('--compute_dtype', default="bf16", choices=["bf16", "fp32", "fp32s"])
+    p.add_argument('--compute_dtype', default="fp32s", choices=["bf16", "fp32", "fp32s"],
+                   help="arithmetic of the HIP path.  Default fp32s (split-bf16 products, fp32 tensors): INSIDE the reference contract -- maps within "
+                        "1e-3 of the PyTorch-CPU path, exact argmax.  bf16 is the throughput mode (2.9x faster; maps within 2.5e-2, gradients of the "
+                        "encoder noisy: DESIGN.md) and must be asked for; fp32 is the exact-fp32-MFMA path")
     p.add_argument('--synthetic_steps', default=20, type=int, help="steps per epoch with --dataset synthetic")
     p.add_argument('--sound_path_data', default="/ssd_scratch/cvit/samyak/data/", type=str,
                    help="root of the audio-visual sets (hard-coded in the reference: dataloader.py:127)")
@@ -217,6 +220,11 @@ def run(args, train_dataset=None, val_dataset=None):
     from . import engine, optim, parallel
     rank, world, local, device = parallel.init_from_env()
     engine.set_default_dtype(args.compute_dtype)
+    if args.compute_dtype == "bf16" and rank == 0:
+        print("train.py: --compute_dtype bf16 is the throughput mode: forward maps are 8e-3 .. 1.6e-2 from the reference's (contract: 1e-3) and "
+              "encoder gradients are noisy; on the 48-step trajectory fixture it descends like the reference's own ensemble "
+              "(tests/test_gpu_model.py::test_training_trajectory_follows_the_reference), convergence on real data is not established here",
+              file=sys.stderr)
     np.random.seed(0)
     torch.manual_seed(0)
     model = build_model(args)
