@@ -132,7 +132,10 @@ typedef struct VinetConvDesc {
                            5 = 3 x 3 spatial footprint: every tap is (dt, dh, dw, slice) with |dh| <= 1 and |dw| <= 1, and
                            taps of equal dt are contiguous in the table (ConvPlan.fwd_taps order and every stride phase of
                            its data gradient): lets plain-input layers take the halo-tile kernel (conv_ht.h), which
-                           stages the activation patch once per (dt, 64 channels) instead of once per tap.
+                           stages the activation patch once per (dt, 64 channels) instead of once per tap.  The weight
+                           slice of a tap must be < 64 (six bits of the kernel's packed tap word; the net's largest
+                           kernel, 5 x 3 x 3, has 45).  tline 1 (temporal line) carries the same promise for conv_ht's
+                           temporal mode.
                            6 = pointwise: ntaps == 1 and the tap is (0, 0, 0, slice 0) (a 1x1x1 / stride-1 conv or its data
                            gradient): lets large problems take the wave-streaming kernel (conv_pw.h), which keeps the
                            weight tile in LDS and feeds the activations to the matrix cores straight from registers.

@@ -146,10 +146,8 @@ def main():
     if args.ht:
         for ln, lib in libs:
             variants.append((ln + ":default", lib, dict(ht=0), False))
-            variants.append((ln + ":ht16", lib, dict(ht=2, ht32=0), False))
-            variants.append((ln + ":ht32", lib, dict(ht=2, ht32=1), False))
-            variants.append((ln + ":ht16+pre", lib, dict(ht=2, ht32=0), True))
-            variants.append((ln + ":ht32+pre", lib, dict(ht=2, ht32=1), True))
+            variants.append((ln + ":ht", lib, dict(ht=2), False))
+            variants.append((ln + ":ht+pre", lib, dict(ht=2), True))
         libs = []
     for ln, lib in libs:
         variants.append((ln + ":pp256", lib, dict(dma=1, pp=3, tperm=0, n64_tile=0, n192_tile=0, n128_tile=0), False))
@@ -228,6 +226,10 @@ def main():
             d.sT, d.sH, d.sW = s
             d.ntaps, d.taps, d.dw, d.Kp = ntaps, taps.data_ptr(), dw.data_ptr(), Kp
             d.pre = L.CAffine(sc.data_ptr(), sh.data_ptr(), 1) if pre else L.CAffine(None, None, 0)
+            if k[1:] == (3, 3) and s == (k[0], 1, 1) and p == (0, 1, 1):
+                d.tline = 4          # kT x 3 x 3 / (kT,1,1) tap order promised: the row-streaming kernels (wgrad_rs.hip) are eligible
+            elif k[1:] == (1, 1) and k[0] > 1:
+                d.tline, d.tpad = 1, p[0]
             return d
 
         times = [[] for _ in variants]

@@ -14,7 +14,6 @@ from vinet_amd import _lib as L
 
 lib = bind(os.path.join(ROOT, "vinet_amd", os.environ.get("VINET_TIMING_LIB", "libvinet_hip_timing.so")))
 lib.vinet_set_option(b"ht", 2)
-lib.vinet_set_option(b"ht32", int(os.environ.get("VINET_HT32", "1")))
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream().cuda_stream
 Bn = int(sys.argv[1]) if len(sys.argv) > 1 else 64

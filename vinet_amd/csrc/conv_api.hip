@@ -167,7 +167,7 @@ struct HtShape { int nt, tw, tm, pre; };
 struct PwShape { int nt, tilesN, gm, tpw; };
 static PwShape pw_shape(const VinetConvDesc* d);
 static HtShape ht_shape(const VinetConvDesc* d);
-extern int g_vinet_opt_ht, g_vinet_opt_ht3, g_vinet_opt_ht32, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
+extern int g_vinet_opt_ht, g_vinet_opt_ht3, g_vinet_opt_ht_minhw, g_vinet_opt_ht_t, g_vinet_opt_ht_pre, g_vinet_opt_ht_t_minhw;
 bool vinet_conv_use_ts(const VinetConvDesc* d);
 int vinet_conv_ts_positions(const VinetConvDesc* d);
 int vinet_conv_ts_segments(const VinetConvDesc* d);
@@ -254,7 +254,7 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "pw")) { g_vinet_opt_pw = value; return 0; }
 #ifndef VINET_EXPERIMENTS
   // measured-slower variants live in side builds only (python -c "from vinet_amd import build; build.build_variant('exp', ['-DVINET_EXPERIMENTS'])")
-  if (name && value && (!strcmp(name, "epi_rows") || !strcmp(name, "ht32") || (!strcmp(name, "bn_lean") && value == 2))) {
+  if (name && value && (!strcmp(name, "epi_rows") || (!strcmp(name, "bn_lean") && value == 2))) {
     vinet_set_error("set_option: %s=%d needs a -DVINET_EXPERIMENTS build of the library", name, value);
     return -2;
   }
@@ -276,7 +276,6 @@ extern "C" int vinet_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "tperm")) { g_vinet_opt_tperm = value; return 0; }
   if (name && !strcmp(name, "pp")) { g_vinet_opt_pp = value; return 0; }
   if (name && !strcmp(name, "ht")) { g_vinet_opt_ht = value; return 0; }
-  if (name && !strcmp(name, "ht32")) { g_vinet_opt_ht32 = value; return 0; }
   if (name && !strcmp(name, "ht3")) { g_vinet_opt_ht3 = value; return 0; }
   if (name && !strcmp(name, "bn_lean")) { g_vinet_opt_bn_lean = value; return 0; }
   if (name && !strcmp(name, "wgrad_ts_cap")) { g_vinet_opt_wgrad_ts_cap = value; return 0; }
@@ -395,7 +394,6 @@ static bool use_pp(const VinetConvDesc* d) {
 // multiple of 16.  Shape: tile width 32 when W allows it, else 16; column tile = the narrowest of 64 / 96 / 128 that
 // pads N least (192 = 2 x 96).
 int g_vinet_opt_ht = 1;         // 0 = off, 1 = heuristic, 2 = every eligible conv (tests)
-int g_vinet_opt_ht32 = 0;       // 1 = halo-tile kernels on v_mfma_f32_32x32x16_bf16 (conv_ht32.h): correct, measured SLOWER
 int g_vinet_opt_ht_minhw = 28 * 48;
 int g_vinet_opt_ht_t = 1;        // temporal mode of the halo-tile kernel for (3,1,1) / stride-1 convs: 604 -> 647 TF/s plain, 482 -> 514 with a
                                  // pending affine (reuse is only 2x and the image is re-staged every three K steps); whole step neutral (+0...0.6 %)

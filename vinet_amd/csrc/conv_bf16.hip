@@ -2,9 +2,6 @@
 #include "conv_dma.h"
 #include "conv_pp.h"
 #include "conv_ht.h"
-#ifdef VINET_EXPERIMENTS
-#include "conv_ht32.h"   // 32x32x16 halo-tile kernels: bit-identical, 8-17 % slower (profiles/r3_ht32_*): side builds only
-#endif
 #include "conv_pw.h"
 
 #define CASE(MT_, NT_, WM_, WN_)                                                            \
@@ -39,29 +36,7 @@ int vinet_launch_conv_pp_bf16(int bn, const ConvArgs& a, hipStream_t s) {
 
 // halo-tile kernel (conv_ht.h): nt = 16-column tiles per workgroup, tw = tile width (spatial mode), tm = temporal mode
 // ((3,1,1) taps), pre = pending BatchNorm + ReLU applied once per staged element
-extern int g_vinet_opt_ht32;
 int vinet_launch_conv_ht_bf16(int nt, int tw, int tm, int pre, const ConvArgs& a, hipStream_t s) {
-#ifdef VINET_EXPERIMENTS
-  if (g_vinet_opt_ht32) {     // the same tiles on v_mfma_f32_32x32x16_bf16 (conv_ht32.h)
-    if (tm) {
-      if (nt == 4) return pre ? launch_conv_ht32_cfg<2, 32, 3, true, true>(a, s) : launch_conv_ht32_cfg<2, 32, 3, true, false>(a, s);
-      if (nt == 6) return pre ? launch_conv_ht32_cfg<3, 32, 2, true, true>(a, s) : launch_conv_ht32_cfg<3, 32, 2, true, false>(a, s);
-    } else if (pre) {
-      if (tw == 32 && nt == 4) return launch_conv_ht32_cfg<2, 32, 3, false, true>(a, s);
-      if (tw == 32 && nt == 6) return launch_conv_ht32_cfg<3, 32, 2, false, true>(a, s);
-      if (tw == 16 && nt == 4) return launch_conv_ht32_cfg<2, 16, 3, false, true>(a, s);
-      if (tw == 16 && nt == 6) return launch_conv_ht32_cfg<3, 16, 2, false, true>(a, s);
-    } else if (tw == 32) {
-      if (nt == 2) return launch_conv_ht32_cfg<1, 32, 3>(a, s);
-      if (nt == 4) return launch_conv_ht32_cfg<2, 32, 3>(a, s);
-      if (nt == 6) return launch_conv_ht32_cfg<3, 32, 3>(a, s);
-    } else if (tw == 16) {
-      if (nt == 2) return launch_conv_ht32_cfg<1, 16, 3>(a, s);
-      if (nt == 4) return launch_conv_ht32_cfg<2, 16, 3>(a, s);
-      if (nt == 6) return launch_conv_ht32_cfg<3, 16, 3>(a, s);
-    }
-  }
-#endif
   if (tm) {
     if (nt == 4) return pre ? launch_conv_ht_cfg<4, 32, 3, true, true>(a, s) : launch_conv_ht_cfg<4, 32, 3, true, false>(a, s);
     if (nt == 6) return pre ? launch_conv_ht_cfg<6, 32, 2, true, true>(a, s) : launch_conv_ht_cfg<6, 32, 2, true, false>(a, s);

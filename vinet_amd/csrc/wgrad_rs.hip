@@ -21,6 +21,9 @@
 //     once with fp32 atomics (dw is zero on entry).
 #include "common.h"
 
+// (16 zero bytes every lane of a DMA can point at: rows past the image)
+__device__ __attribute__((aligned(64))) uint4 g_vinet_zero_page_rs[4];
+
 struct WgradRsArgs {
   const char* x;
   const char* dy;
@@ -465,21 +468,35 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_rsm_kernel(const WgradRsArg
 // 256-thread workgroup leaves room for a second one on the CU (two independent (tap, channel chunk) groups, or a main-stream
 // kernel beside the weight-gradient stream).  P = 32 KS positions per step = R image rows of WW (R = 1: W = 32, 64, 96;
 // R = 2, 4: W = 48, 24).
+// Round 6: the step's staging is LDS-DMA and the ring is twice as deep.  tools/isa_audit.py on the round-4 form of this kernel: 344
+// non-MFMA instructions beside 108 MFMAs per step (3.19 per MFMA) -- 82 v_add (one per transpose read: table + runtime ring slot) and
+// ~85 for the register staging of the next rows (loads, masks, multiplies, ds_write) -- on ONE wave per SIMD (310 registers), where
+// nothing hides issue time.  Now:
+//   * the next step's x rows and dy tile go straight to LDS (global_load_lds, 16 bytes per lane, lane-linear on the LDS side, the
+//     chunk swizzle applied on the SOURCE address as in conv_ht.h); the address is a scalar base (item, image row) + a per-lane
+//     32-bit offset fixed at kernel start; rows past the image read the zero page.  Lanes of a partial channel chunk read chunk 0
+//     instead of zeros: what they feed are columns c >= Cin / rows n >= N of the product, which are never written.
+//   * RING = 2R + 2 rows: the R incoming rows have slots of their own, so a step is {issue DMA, multiply, wait, ONE barrier}
+//     instead of {load, multiply, barrier, write, barrier}.
+//   * the ring walk is unrolled over its period (U = RING / gcd(R, RING) steps), so every ring slot is a compile-time constant
+//     and goes into the transpose read's immediate offset: the address register of an x fragment is a table entry, no add.  A K
+//     step whose 32 positions straddle two image rows (W = 48: the middle one) keeps a per-lane row bit in its table entries;
+//     only where its second row wraps around the ring (one tap row in U * 3) an add per read is left.
+constexpr int wrs_gcd(int a, int b) { return b == 0 ? a : wrs_gcd(b, a % b); }
+template <int V> struct WrsIC { static constexpr int value = V; };
+
 template <int KS, int WW>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_rs4_kernel(const WgradRsArgs a) {
-  constexpr int P = KS * 32, R = P / WW, RING = R + 2;
-  static_assert(R * WW == P && R >= 1, "whole rows per step");
+  constexpr int P = KS * 32, R = P / WW, RING = 2 * R + 2, U = RING / wrs_gcd(R, RING);
+  static_assert(R * WW == P && R >= 1 && WW % 8 == 0, "whole rows per step, 8-position DMA pieces inside one row");
   constexpr int XROW = (WW + 2) * 128, DROW = P * 128;
-  constexpr int PPT = KS;                           // 16-byte pieces of a step's x rows (and of its dy tile) per thread: P * 8 / 256
+  constexpr int PPT = KS;                           // 1 KB DMA pieces (8 positions x 128 B) per wave and step: P / 8 / 4
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;                                // RING x rows
   char* dyb = smem + RING * XROW;                   // 2 dy tiles
   const int tid = threadIdx.x, lane = tid & 63, ct = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int groups = a.kT * a.cchunks * a.nchunks;
-  // XCD-aware: workgroup b runs on XCD b % 8 with its own L2; the groups of ONE worker walk the same (clip, frame) items at the same
-  // time -- the n-chunk groups of a (tap, channel chunk) read the same x rows, the (tap, channel chunk) groups of an n chunk the
-  // same dy tiles -- so consecutive LOGICAL ids (groups of a worker, n fastest) are put on one XCD (round 6: the r5 counters showed
-  // 3.7x the algorithmic bytes past the L2 for the W = 48 sites, each group's copy fetched through a different XCD's L2)
+  // (XCD-aware: see conv_wgrad_rs_kernel)
   const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int grp = lid % groups, worker = lid / groups;
   const int n0 = (grp % a.nchunks) * 64;
@@ -487,28 +504,36 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rs4_kernel(const WgradRsArg
   const int kt = gc / a.cchunks, c0 = (gc - kt * a.cchunks) * 64;
   const int l_chunk = tid & 7;
   const int H = a.H;
-  const bool cx_ok = c0 + l_chunk * 8 < a.Cin, dn_ok = n0 + l_chunk * 8 < a.N;
-  const int cx_off = cx_ok ? c0 + l_chunk * 8 : 0, dn_off = dn_ok ? n0 + l_chunk * 8 : 0;
+  const char* zero = (const char*)g_vinet_zero_page_rs;
 
-  // piece roles: piece q = tid + 256 j -> tile position q >> 3 = (row pr, column pw), chunk q & 7 (= tid & 7)
-  int x_in[PPT], d_off[PPT], g_pos[PPT], p_r[PPT];
+  // ---- DMA roles: piece j of wave ct = tile positions j * 32 + ct * 8 .. + 7 (one image row: WW % 8 == 0); lane = (position
+  // lane >> 3, LDS slot lane & 7), source chunk = slot ^ swizzle(position)
+  int xo[PPT], yo[PPT];              // per-lane byte offsets against the scalar row bases
+  int pr_[PPT], pw0_[PPT];           // (wave-uniform) image row inside the step and first column of the piece
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
-    const int pos = (tid + 256 * j) >> 3;
-    const int pr = pos / WW, pw = pos - pr * WW;
-    g_pos[j] = pos; p_r[j] = pr;
-    x_in[j] = (pw + 1) * 128 + ((l_chunk ^ wrs_swz(pw + 1)) * 16);
-    d_off[j] = pos * 128 + ((l_chunk ^ wrs_swz(pos)) * 16);
+    const int pos0 = j * 32 + ct * 8, pos = pos0 + (lane >> 3);
+    const int pr = pos0 / WW, pw = pos - pr * WW;
+    pr_[j] = pr; pw0_[j] = pos0 - pr * WW;
+    const int xc = l_chunk ^ wrs_swz(pw + 1), dc = l_chunk ^ wrs_swz(pos);
+    xo[j] = (pw * a.ldx + c0 + (c0 + xc * 8 < a.Cin ? xc * 8 : 0)) * 2;
+    yo[j] = (pos * a.ldy + n0 + (n0 + dc * 8 < a.N ? dc * 8 : 0)) * 2;
   }
+  auto dma = [&](const char* base, int off, char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)off),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
   for (int i = tid; i < RING * 2 * 8; i += 256) {            // zero pad positions of every ring row, once
     const int row = i / 16, side = (i >> 3) & 1, ch = i & 7;
     *(uint4*)(ring + row * XROW + (side ? (WW + 1) * 128 : 0) + ch * 16) = make_uint4(0, 0, 0, 0);
   }
-  // fragment tables of this lane.  K-major fragments: 8 positions x 1 channel per lane, two transpose reads (h) of 4 positions.
-  //   x : address = ring + slot(row f_r + kh) * XROW + xa[ks][h][kw]     (position f_w + kw of the ring row, swizzled chunk)
-  //   dy: address = tile + da[ks][h] + (((2 i + db) ^ ds[ks][h]) << 4)   (column tile i of the 64 output channels)
+  // ---- fragment tables of this lane.  K-major fragments: 8 positions x 1 channel per lane, two transpose reads (h) of 4 positions.
+  //   x : ring + [slot of (the K step's first row + kh)] * XROW  (compile time)  + xs[ks][h][kw]
+  //       xs = (position f_w + kw of the ring row, swizzled chunk) + frl * XROW, frl = 1 for lanes whose positions lie in the K step's
+  //       SECOND image row (a straddling K step); where that second row wraps around the ring: - xwrap[ks][h] (= frl * RING * XROW)
+  //   dy: tile + da[ks][h] + (((2 i + db) ^ ds[ks][h]) << 4)   (column tile i of the 64 output channels)
   const int p = lane & 15, q = lane >> 4;
-  int f_r[KS][2], xa[KS][2][3], da[KS][2], ds[KS][2];
+  int xs[KS][2][3], xwrap[KS][2], da[KS][2], ds[KS][2];
   const int db = (p & 3) >> 1;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -516,10 +541,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rs4_kernel(const WgradRsArg
     for (int h = 0; h < 2; ++h) {
       const int pos = ks * 32 + q * 8 + h * 4 + (p >> 2);
       const int fr = pos / WW, fw = pos - fr * WW;
-      f_r[ks][h] = fr;
+      const int frl = fr - (ks * 32) / WW;
       const int col = ct * 16 + (p & 3) * 4;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) xa[ks][h][kw] = (fw + kw) * 128 + (((col >> 3) ^ wrs_swz(fw + kw)) * 16) + (col & 7) * 2;
+      for (int kw = 0; kw < 3; ++kw) xs[ks][h][kw] = frl * XROW + (fw + kw) * 128 + (((col >> 3) ^ wrs_swz(fw + kw)) * 16) + (col & 7) * 2;
+      xwrap[ks][h] = frl * RING * XROW;
       da[ks][h] = pos * 128 + ((p & 3) & 1) * 8;
       ds[ks][h] = wrs_swz(pos);
     }
@@ -534,30 +560,46 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rs4_kernel(const WgradRsArg
     const uint32_t m = on ? 0xffffffffu : 0u;
     return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
   };
-  auto tr_read = [](const char* ptr) -> s16x4_v {
-#ifdef VINET_WRS_NO_LDS      // ablation (tools/wrs_phases.py): MFMAs on whatever the registers hold
+  // Transposing LDS reads as INLINE ASM, their waits counted by hand.  Through the builtin, hipcc knows they are LDS loads and --
+  // because an LDS-DMA may alias any LDS load it cannot disambiguate -- puts `s_waitcnt vmcnt(0)` in front of every group of
+  // them: each batch would drain the DMAs of the next step's rows that were issued a moment ago (found in the disassembly of
+  // this kernel's first DMA form, and in conv_wgrad_pp / conv_wgrad_dma / conv_wgrad_tf, whose counted vmcnt(8) pipelines it defeats).
+  // LDS answers in order, so `lgkmcnt(n)` in front of a batch's MFMAs with n = the reads issued for the NEXT batch is exact.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto tr_read = [](unsigned addr, auto offc) -> s16x4_v {
     s16x4_v r;
-    asm volatile("" : "=v"(r) : "v"(ptr));
-    return r;
+#ifdef VINET_WRS_NO_LDS      // ablation (tools/wrs_phases.py): MFMAs on whatever the registers hold
+    asm volatile("" : "=v"(r) : "v"(addr));
 #else
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)ptr);
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(decltype(offc)::value));
 #endif
+    return r;
   };
 #ifdef VINET_CONV_TIMING
   unsigned long long tm_pro = 0, tm_mma = 0, tm_b1 = 0, tm_wr = 0, tm_b2 = 0, tm_steps = 0, tm_items = 0;
   const unsigned long long tm_start = __builtin_amdgcn_s_memtime();
 #endif
   const int nsteps = (H + R - 1) / R;
+  const bool cx_ok = c0 + l_chunk * 8 < a.Cin, dn_ok = n0 + l_chunk * 8 < a.N;
+  const int cx_off = cx_ok ? c0 + l_chunk * 8 : 0, dn_off = dn_ok ? n0 + l_chunk * 8 : 0;
 
   for (int item = worker; item < a.items; item += a.workers) {
     const int b = (int)fdiv((uint32_t)item, a.dTo);
     const int to = item - b * a.To;
     const int t = to * a.kT + kt;
     WRS_T(t_item0);
-    const char* xb = a.x + ((long)b * a.sBx + (long)t * H * WW * a.ldx + cx_off) * 2;      // + (y*W + w) * ldx * 2
-    const char* db_ = a.dy + ((long)b * a.sBy + (long)to * H * WW * a.ldy + dn_off) * 2;
+    const char* xi = a.x + ((long)b * a.sBx + (long)t * H * WW * a.ldx) * 2;           // + ((y*W + w) * ldx + channel) * 2
+    const char* di = a.dy + ((long)b * a.sBy + (long)to * H * WW * a.ldy) * 2;
+    const char* xb = xi + cx_off * 2;
+    const char* db_ = di + dn_off * 2;
+    const long xrowb = (long)WW * a.ldx * 2, drowb = (long)WW * a.ldy * 2;
+    const char* xnext = xi + (long)(R + 1) * xrowb;        // image row h0 + R + 1 of the step being multiplied (advanced by R rows per step)
+    const char* dnext = di + (long)R * drowb;              // dy row h0 + R
+    long prx[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) prx[j] = (long)pr_[j] * xrowb;
 
-    // ---- prologue: image rows -1 (zero) and 0..R into slots 0..R+1 (slot of row y = (y + 1) % RING), dy rows 0..R-1
+    // ---- prologue (plain loads): image rows -1 (zero) and 0..R into slots 0..R+1 (slot of row y = (y + 1) % RING), dy rows 0..R-1
     for (int e = tid; e < (R + 1) * WW * 8; e += 256) {
       const int pos = e >> 3, ch = e & 7;                     // (e & 7 == l_chunk)
       const int y = pos / WW, w = pos - y * WW;
@@ -567,70 +609,65 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rs4_kernel(const WgradRsArg
     }
     for (int e = tid; e < WW * 8; e += 256)
       *(uint4*)(ring + ((e >> 3) + 1) * 128 + (((e & 7) ^ wrs_swz((e >> 3) + 1)) * 16)) = make_uint4(0, 0, 0, 0);     // row -1
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const bool in = p_r[j] < H && dn_ok;
-      const uint4 v = *(const uint4*)(db_ + (long)(in ? g_pos[j] : 0) * a.ldy * 2);
-      *(uint4*)(dyb + d_off[j]) = keep(v, in);
+    for (int e = tid; e < P * 8; e += 256) {
+      const int pos = e >> 3, ch = e & 7;
+      const bool in = pos / WW < H && dn_ok;
+      const uint4 v = *(const uint4*)(db_ + (long)(in ? pos : 0) * a.ldy * 2);
+      *(uint4*)(dyb + pos * 128 + ((ch ^ wrs_swz(pos)) * 16)) = keep(v, in);
     }
     __syncthreads();
 
 #ifdef VINET_CONV_TIMING
     tm_pro += __builtin_amdgcn_s_memtime() - t_item0; ++tm_items;
 #endif
-    int s_base = 0;                                          // slot of image row h0 - 1
-    for (int st = 0; st < nsteps; ++st) {
+    // one step; uc = its phase in the ring walk (compile time): image row h0 - 1 sits in slot (uc * R) % RING
+    auto step = [&](auto uc, int st) {
+      constexpr int SB = (decltype(uc)::value * R) % RING;
       WRS_T(t_s0);
       const int h0 = st * R;
-      // ---- loads for the next step: x rows h0+R+1 .. h0+2R, dy rows h0+R .. h0+2R-1 ---------------------------------
-      const bool more = st + 1 < nsteps;
-      uint4 nx[PPT], nd[PPT];
-      bool xi[PPT], di[PPT];
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        xi[j] = more && cx_ok && h0 + R + 1 + p_r[j] < H;
-        di[j] = more && dn_ok && h0 + R + p_r[j] < H;
-        nx[j] = *(const uint4*)(xb + (long)(xi[j] ? (h0 + R + 1) * WW + g_pos[j] : 0) * a.ldx * 2);
-        nd[j] = *(const uint4*)(db_ + (long)(di[j] ? (h0 + R) * WW + g_pos[j] : 0) * a.ldy * 2);
-      }
+      // ---- DMA for the next step: x rows h0+R+1 .. h0+2R into slots (SB + R + 2 + pr) % RING, dy rows h0+R .. h0+2R-1 into the other
+      // tile.  Issued in PPT parts BEHIND the MFMAs of the first batches (one wave per SIMD: what is issued while the matrix pipe
+      // works is free, what is issued in front of it is not).  Branch-free: rows past the image select the zero page by masks.
+      auto issue_dma = [&](int j) {
+        char* dn = dyb + ((st + 1) & 1) * DROW;
+        const long xin = -(long)(h0 + R + 1 + pr_[j] < H), din = -(long)(h0 + R + pr_[j] < H);      // (wave-uniform masks)
+        int sl = SB + R + 2 + pr_[j]; sl -= sl >= RING ? RING : 0;
+        dma(zero + ((xnext + prx[j] - zero) & xin), xo[j] & (int)xin, ring + sl * XROW + (pw0_[j] + 1) * 128);
+        dma(zero + ((dnext - zero) & din), yo[j] & (int)din, dn + (j * 32 + ct * 8) * 128);
+      };
       // ---- MFMAs: per K step the four dy fragments, then per kernel row kh three x fragments and their twelve MFMAs; the
       // reads of a batch are issued before the MFMAs of the batch in front of it ------------------------------------------
-      const char* dt = dyb + (st & 1) * DROW;
-      int srow[2][3];                                        // ring row offsets of the K step being read: image row h0 + f_r + kh - 1
-      auto rows_of = [&](int ks) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int kh = 0; kh < 3; ++kh) {
-            int slot = s_base + f_r[ks][h] + kh;
-            slot -= slot >= RING ? RING : 0;
-            srow[h][kh] = slot * XROW;
-          }
-      };
+      const unsigned dt = lds0 + RING * XROW + (st & 1) * DROW;
       union Frag { bf16x8_v v; s16x4_v h[2]; };
       Frag fa[4], fb[2][3];
       auto read_dy = [&](int ks) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) fa[i].h[h] = tr_read(dt + da[ks][h] + (((2 * i + db) ^ ds[ks][h]) << 4));
+          for (int h = 0; h < 2; ++h) fa[i].h[h] = tr_read(dt + da[ks][h] + (((2 * i + db) ^ ds[ks][h]) << 4), WrsIC<0>{});
       };
-      auto read_x = [&](int buf, int ks, int kh) {
+      auto read_x = [&](int buf, auto ksc, auto khc) {
+        constexpr int ks = decltype(ksc)::value, kh = decltype(khc)::value;
+        constexpr int f0 = (ks * 32) / WW;                             // first image row of the K step (inside the step)
+        constexpr bool straddle = (ks * 32 + 31) / WW != f0;
+        constexpr int slotA = (SB + f0 + kh) % RING;
+        constexpr bool wraps = straddle && slotA + 1 == RING;          // the second row of a straddling K step sits in slot 0
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) fb[buf][kw].h[h] = tr_read(ring + srow[h][kh] + xa[ks][h][kw]);
+          for (int h = 0; h < 2; ++h)
+            fb[buf][kw].h[h] = tr_read(lds0 + (wraps ? xs[ks][h][kw] - xwrap[ks][h] : xs[ks][h][kw]), WrsIC<slotA * XROW>{});
       };
-      rows_of(0);
       read_dy(0);
-      read_x(0, 0, 0);
+      read_x(0, WrsIC<0>{}, WrsIC<0>{});
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b3 = 0; b3 < KS * 3; ++b3) {                  // batch = (ks, kh)
-        const int ks = b3 / 3, kh = b3 % 3;
-        if (b3 + 1 < KS * 3) {
-          if (kh == 2) rows_of(ks + 1);
-          read_x((b3 + 1) & 1, (b3 + 1) / 3, (b3 + 1) % 3);
+      auto batch = [&](auto bc) {                            // batch = (ks, kh)
+        constexpr int b3 = decltype(bc)::value, ks = b3 / 3, kh = b3 % 3;
+        if constexpr (b3 + 1 < KS * 3) {
+          read_x((b3 + 1) & 1, WrsIC<(b3 + 1) / 3>{}, WrsIC<(b3 + 1) % 3>{});
+          asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");      // everything older than the six reads just issued has answered
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -644,30 +681,34 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rs4_kernel(const WgradRsArg
 #endif
           }
         __builtin_amdgcn_sched_barrier(0);
-        if (kh == 2 && ks + 1 < KS) {                        // (behind the K step's last MFMAs: they have read fa long before LDS answers)
+        if constexpr (b3 < PPT) {                             // (behind this batch's twelve MFMAs)
+          issue_dma(b3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (kh == 2 && ks + 1 < KS) {              // (behind the K step's last MFMAs: they have read fa long before LDS answers)
           read_dy(ks + 1);
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
+      };
+      batch(WrsIC<0>{}); batch(WrsIC<1>{}); batch(WrsIC<2>{});
+      if constexpr (KS > 1) { batch(WrsIC<3>{}); batch(WrsIC<4>{}); batch(WrsIC<5>{}); }
+      if constexpr (KS > 2) { batch(WrsIC<6>{}); batch(WrsIC<7>{}); batch(WrsIC<8>{}); }
       WRS_T(t_s1);
-      __syncthreads();
+      xnext += (long)R * xrowb; dnext += (long)R * drowb;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces of the next step's rows have landed ...
+      __syncthreads();                                       // ... everyone's have, and everyone has finished reading this step's
       WRS_T(t_s2);
-      if (more) {
-        char* dn = dyb + ((st + 1) & 1) * DROW;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-          int sl = s_base + p_r[j]; sl -= sl >= RING ? RING : 0;       // new row h0+R+1+pr replaces row h0-1+pr
-          *(uint4*)(ring + sl * XROW + x_in[j]) = keep(nx[j], xi[j]);
-          *(uint4*)(dn + d_off[j]) = keep(nd[j], di[j]);
-        }
-      }
-      s_base += R; s_base -= s_base >= RING ? RING : 0;
-      WRS_T(t_s3);
-      __syncthreads();
 #ifdef VINET_CONV_TIMING
-      { const unsigned long long t_s4 = __builtin_amdgcn_s_memtime();
-        tm_mma += t_s1 - t_s0; tm_b1 += t_s2 - t_s1; tm_wr += t_s3 - t_s2; tm_b2 += t_s4 - t_s3; ++tm_steps; }
+      tm_mma += t_s1 - t_s0; tm_b1 += t_s2 - t_s1; ++tm_steps;
 #endif
+    };
+    for (int st = 0; st < nsteps; st += U) {
+      step(WrsIC<0>{}, st);
+      if constexpr (U > 1) { if (st + 1 < nsteps) step(WrsIC<1 % U>{}, st + 1); }
+      if constexpr (U > 2) { if (st + 2 < nsteps) step(WrsIC<2 % U>{}, st + 2); }
+      if constexpr (U > 3) { if (st + 3 < nsteps) step(WrsIC<3 % U>{}, st + 3); }
+      if constexpr (U > 4) { if (st + 4 < nsteps) step(WrsIC<4 % U>{}, st + 4); }
+      static_assert(U <= 5, "ring period");
     }
   }
 #ifdef VINET_CONV_TIMING
@@ -728,7 +769,7 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
   if (g_vinet_opt_wgrad_rs4 && (a.W == 24 || a.W == 48 || a.W == 32 || a.W == 64 || a.W == 96)) {
     const int ks4 = (a.W == 24 || a.W == 48) ? 3 : a.W / 32;
     const int rows = ks4 * 32 / a.W;
-    const int smem4 = (rows + 2) * (a.W + 2) * 128 + 2 * ks4 * 32 * 128;
+    const int smem4 = (2 * rows + 2) * (a.W + 2) * 128 + 2 * ks4 * 32 * 128;      // RING = 2R + 2 ring rows + two dy tiles
     int w4 = 2 * vn_wgrad_cus(d) / groups;       // two 256-thread workgroups per CU
     if (w4 < 1) w4 = 1;
     if (w4 > a.items) w4 = a.items;
@@ -738,7 +779,7 @@ int vinet_launch_wgrad_rs(const VinetWgradDesc* d, hipStream_t s) {
       int dev = 0;
       (void)hipGetDevice(&dev);
       if (!attr_done[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) { vinet_set_error("hipFuncSetAttribute(wgrad_rs4): %s", hipGetErrorString(e)); return (int)e; }
         attr_done[dev & 63] = true;
       }

@@ -776,7 +776,8 @@ class ConvPlan:
         self.temporal = self.k[1] == 1 and self.k[2] == 1 and self.p[1] == 0 and self.p[2] == 0 and self.s[1] == 1 and self.s[2] == 1
         # 3 x 3 spatial footprint, unit spatial stride, "same" padding: fwd_taps (kt-major) and every stride phase of the data
         # gradient keep |dh|, |dw| <= 1 with equal-dt taps contiguous -- the promise behind VinetConvDesc::tline == 5
-        self.spatial3 = (not stem) and self.k[1:] == (3, 3) and self.p[1:] == (1, 1) and self.s[1:] == (1, 1)
+        # (... and weight slices < 64: conv_ht.h keeps a tap's slice in six bits of its scalar tap word)
+        self.spatial3 = (not stem) and self.k[1:] == (3, 3) and self.p[1:] == (1, 1) and self.s[1:] == (1, 1) and self.ntaps <= 64
         # 1x1x1, unit stride, no padding: forward and data gradient are one tap (0, 0, 0, slice 0) -- VinetConvDesc::tline == 6
         self.pointwise = (not stem) and self.k == (1, 1, 1) and self.s == (1, 1, 1) and self.p == (0, 0, 0)
         if stem:
@@ -835,7 +836,7 @@ class ConvPlan:
                 continue
             key = ("dg", in_dims, rT, rH, rW)
             offs = sorted(r_[0] for r_ in rows)
-            tline = self.temporal and offs == list(range(offs[0], offs[0] + len(offs)))
+            tline = self.temporal and offs == list(range(offs[0], offs[0] + len(offs))) and self.ntaps <= 64
             tl = 1 if tline else 0
             if self.spatial3:
                 dts = [r_[0] for r_ in rows]
