@@ -1957,8 +1957,7 @@ def _exact_targets():
         t.append(("tstream-" + c[0], test_conv3d_tstream, dict(case=c)))
     for c in HT_CASES:
         if not c[7].get("out_f32"):
-            t.append(("halo32-" + c[0], test_conv3d_halo_tile, dict(case=c, mfma32=1)))
-            t.append(("halo16-" + c[0], test_conv3d_halo_tile, dict(case=c, mfma32=0)))
+            t.append(("halo16-" + c[0], test_conv3d_halo_tile, dict(case=c)))
     for c in PW_CASES:
         t.append(("pw-" + c[0], test_conv3d_pointwise_stream, dict(case=c)))
     for c in EPI_ROWS_CASES + EPI_ROWS_HT:

@@ -156,6 +156,21 @@ VN_DEV int4 load_tap(const int4* taps, int i) {
 #endif
 }
 
+// LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, lane-linear on the LDS side) issued from INLINE ASM, for kernels that
+// read the staged tiles with TRANSPOSING LDS reads (ds_read_b64_tr_b16, the weight gradients).  Issued through the builtin,
+// hipcc knows the instruction as a store to LDS that may alias any LDS load it cannot disambiguate -- and it cannot for the
+// transpose-read builtin -- so it puts `s_waitcnt vmcnt(0)` in front of every group of reads: the counted vmcnt(n) pipelines
+// of conv_wgrad_pp / conv_wgrad_dma / conv_wgrad_tf drained completely in every phase (round 6, found in the disassembly;
+// the conv kernels' plain ds_read_b128 do not trigger it).  From asm the compiler sees neither the LDS store nor M0; the
+// waits are the kernels' own counted ones, as designed.  `lds_dst` must be wave-uniform (an SGPR).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+VN_DEV void lds_dma16_asm(const char* src, char* lds_dst) {
+  const unsigned d = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(d) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 // MFMA with the accumulator PINNED in the AGPR file.  With the builtin, hipcc keeps the
 // accumulators of an address-heavy pipelined loop in VGPRs and spills/reloads all of them
 // through AGPRs every iteration (2 x 96 v_accvgpr moves per 24 MFMAs measured); an asm

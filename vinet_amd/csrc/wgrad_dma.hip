@@ -146,8 +146,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
       const unsigned ok = (unsigned)live & (unsigned)(m < a.M) & (unsigned)(n < a.N);
       const char* p = a.dy + ((long)b * a.sBy + ((long)(to * a.Ho + ho) * a.Wo + wo) * (long)a.ldy + n) * 2;
       const char* src = zero + ((p - zero) & -(long)ok);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(stage + q * 1024), 16, 0, 0);
+      lds_dma16_asm(src, (stage + q * 1024));      // (asm: common.h -- no compiler-made vmcnt(0) drains in front of the transpose reads)
     }
     // ---- X tiles, one per tap of the group ----
     if constexpr (TC == 32) {
@@ -181,8 +180,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
         const char* p = a.x + (base + ((long)(ti * a.Hi + hi) * a.Wi + wi) * (long)a.ldx) * 2;
         const char* src = xpad + ((p - xpad) & -(long)ok);
         char* dst = pok ? stage + Cfg::D_BYTES + g * Cfg::X_BYTES + q * 1024 : stage + Cfg::D_BYTES + TG * Cfg::X_BYTES;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        lds_dma16_asm(src, dst);      // (asm: common.h -- no compiler-made vmcnt(0) drains in front of the transpose reads)
       }
     }
 #pragma unroll
@@ -207,8 +205,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradDmaArgs 
                             (unsigned)((unsigned)hi < (unsigned)a.Hi) & (unsigned)((unsigned)wi < (unsigned)a.Wi);
         const char* p = a.x + (base + ((long)(ti * a.Hi + hi) * a.Wi + wi) * (long)a.ldx) * 2;
         const char* src = xpad + ((p - xpad) & -(long)ok);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(stage + Cfg::D_BYTES + g * Cfg::X_BYTES + q * 1024), 16, 0, 0);
+        lds_dma16_asm(src, (stage + Cfg::D_BYTES + g * Cfg::X_BYTES + q * 1024));      // (asm: common.h -- no compiler-made vmcnt(0) drains in front of the transpose reads)
       }
     }
     ++isu;

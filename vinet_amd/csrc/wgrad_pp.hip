@@ -181,10 +181,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(const WgradPPArgs
       }
     }
   };
-  auto dma = [&](const char* src, char* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
+  auto dma = [&](const char* src, char* dst) { lds_dma16_asm(src, dst); };      // (asm: see common.h -- no compiler-made vmcnt(0) drains)
   auto issue_a = [&](int buf, int h, const WppCursor& c) {
     char* dst = smem + buf * Cfg::BUF_BYTES + Cfg::A_OFF + h * Cfg::HALF_BYTES + wave * 1024;
 #pragma unroll
