@@ -14,12 +14,15 @@ spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "t
 isa_audit = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(isa_audit)
 
-# (substring of the demangled name, MFMAs in the K loop, ceiling on non-MFMA : MFMA) -- measured 2.65 / 2.67 / 3.19 / 2.51 / 1.88
+# (substring of the demangled name, MFMAs in the K loop, ceiling on non-MFMA : MFMA).  Round 5 measured 2.65 / 2.67 / 3.19 / 2.51 / 1.88;
+# round 6 (conv_ht: column-keyed swizzle + immediates + scalar weight offsets; wgrad_rs4: LDS-DMA staging, compile-time ring slots)
+# 1.50 / 1.50 / 2.01 / 1.54..1.69 / 1.88 -- profiles/r6_isa_audit.txt.  VERDICT r5's target was <= 2.0 for the first and the third.
 BUDGET = [
-    ("conv_ht_kernel<6, 16, 3, false, false, false, false>", 48, 2.8),
-    ("conv_ht_kernel<6, 32, 3, false, false, false, false>", 48, 2.8),
-    ("conv_wgrad_rs4_kernel<3, 48>", None, 3.35),
-    ("conv_wgrad_rs4_kernel<3, 96>", None, 2.65),
+    ("conv_ht_kernel<6, 16, 3, false, false, false, false>", 48, 1.6),
+    ("conv_ht_kernel<6, 32, 3, false, false, false, false>", 48, 1.6),
+    ("conv_ht_kernel<6, 32, 2, true, false, false, false>", 48, 1.5),
+    ("conv_wgrad_rs4_kernel<3, 48>", None, 2.1),
+    ("conv_wgrad_rs4_kernel<3, 96>", None, 1.8),
     ("conv_dma_kernel<4, 8, 4, 1, 3, false, false>", 32, 2.0),
 ]
 
@@ -31,12 +34,37 @@ def test_mfma_loops_keep_their_instruction_budget():
     for name, mfma, ceiling in BUDGET:
         mine = [r for r in rows if r["name"].startswith(name)]
         assert mine, "%s: kernel or its K loop not found (%d loops audited)" % (name, len(rows))
-        main = max(mine, key=lambda r: r["mfma"])            # the K loop proper (prologue / tail loops hold fewer MFMAs)
-        if mfma is not None:
-            assert main["mfma"] == mfma, (name, main)
-        assert main["non_mfma_per_mfma"] <= ceiling, "%s: %.2f non-MFMA instructions per MFMA (ceiling %.2f): %s" % (
-            name, main["non_mfma_per_mfma"], ceiling, {k: main[k] for k in ("n", "mfma", "valu", "salu", "lds", "vmem", "sync", "branch")})
-        assert "16x16x32" in main["shape"]
+        # the K loop proper holds the most MFMAs (prologue / tail loops hold fewer).  wgrad_rs4 unrolls its step loop over the ring
+        # period, so the tool sees several step bodies of equal size: every one of them is held to the budget
+        top = max(r["mfma"] for r in mine)
+        for main in (r for r in mine if r["mfma"] == top):
+            if mfma is not None:
+                assert main["mfma"] == mfma, (name, main)
+            assert main["non_mfma_per_mfma"] <= ceiling, "%s: %.2f non-MFMA instructions per MFMA (ceiling %.2f): %s" % (
+                name, main["non_mfma_per_mfma"], ceiling, {k: main[k] for k in ("n", "mfma", "valu", "salu", "lds", "vmem", "sync", "branch")})
+            assert "16x16x32" in main["shape"]
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(isa_audit.OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_no_compiler_made_dma_drain_in_front_of_transpose_reads():
+    """Round 6: an LDS-DMA issued through the builtin is, to hipcc, a store to LDS that may alias the transposing LDS reads it cannot
+    disambiguate, and it puts `s_waitcnt vmcnt(0)` in front of every group of them -- the counted vmcnt pipelines of the weight
+    gradients drained in every phase (conv_wgrad_pp: 24 such waits in its loops; 10-26 % slower alone).  The kernels issue their DMAs
+    from inline asm now (common.h lds_dma16_asm) or read through asm (wgrad_rs4): the ping-pong kernel's loops must hold the designed
+    vmcnt(8) waits and NO vmcnt(0)."""
+    found = 0
+    for text in isa_audit.disassemble(LIB):
+        for name, ins in isa_audit.functions(text):
+            if "conv_wgrad_pp_kernel" not in name:
+                continue
+            for lo, hi in isa_audit.loops(ins):
+                seg = ins[lo:hi + 1]
+                if sum(1 for _, mn, _ in seg if mn.startswith("v_mfma")) < 8:
+                    continue
+                waits = [ops.split()[0] for _, mn, ops in seg if mn == "s_waitcnt" and "vmcnt" in ops]
+                found += 1
+                assert "vmcnt(8)" in waits and "vmcnt(0)" not in waits, (name, waits)
+    assert found >= 4
 
 
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(isa_audit.OBJDUMP)), reason="needs the built library and llvm-objdump")

@@ -148,14 +148,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
         const unsigned ok = cin_ok & (unsigned)((unsigned)ti < (unsigned)a.Ti) & (unsigned)((unsigned)hi < (unsigned)a.Hi) &
                             (unsigned)((unsigned)wi < (unsigned)a.Wi);
         const char* src = apad + (((a_ptr[i] + tap_delta) - apad) & -(long)ok);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        if constexpr (PRE) lds_dma16_asm(src, (char*)(stage + (i * 64 + wave * 16) * 64));
+        else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(stage + (i * 64 + wave * 16) * 64), 16, 0, 0);
       }
       const long wdelta = (long)tp.w * slice_bytes + (long)isu_c * 2;
 #pragma unroll
       for (int j = 0; j < B_LOADS; ++j) {
         const char* src = zero + (((b_ptr[j] + wdelta) - zero) & -(long)b_ok[j]);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        if constexpr (PRE) lds_dma16_asm(src, (char*)(stage + (BM + j * 64 + wave * 16) * 64));
+        else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(stage + (BM + j * 64 + wave * 16) * 64), 16, 0, 0);
       }
       isu_c += 32;
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
       // past the end: keep the DMA count per stage exact
 #pragma unroll
       for (int i = 0; i < A_LOADS + B_LOADS; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)zero,
+        if constexpr (PRE) lds_dma16_asm(zero, (char*)(stage + (i * 64 + wave * 16) * 64));
+        else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)zero,
                                          (__attribute__((address_space(3))) void*)(stage + (i * 64 + wave * 16) * 64), 16, 0, 0);
     }
     ++isu;

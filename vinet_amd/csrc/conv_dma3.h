@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma3_kernel(const ConvArgs a) {
   const long slice_bytes = (long)a.Nw * a.Kp * 4;
 
   int isu = 0, isu_tap = 0, isu_c = 0;
+  // (PRE: the affine tables are plain LDS loads, in front of which hipcc drains vmcnt(0) when the DMA is a builtin: common.h)
   auto dma = [&](const char* src, char* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    if constexpr (PRE) lds_dma16_asm(src, dst);
+    else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
   auto issue = [&](int slot) {
     char* stage = smem + slot * Cfg::STAGE_BYTES;

@@ -138,9 +138,12 @@ __global__ __launch_bounds__(256, 2) void conv_ht_kernel(const ConvArgs a) {
   }
   const long slice_bytes = (long)a.Nw * a.Kp * (SPLIT ? 4 : 2);
 
+  // (PRE: xform_halo's plain LDS loads / stores would make hipcc drain vmcnt(0) -- the weight tiles in flight too -- when the DMA
+  //  is a builtin: common.h, lds_dma16_asm)
   auto dma = [&](const char* src, char* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    if constexpr (PRE) lds_dma16_asm(src, dst);
+    else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
   // halo image of (temporal offset dt, channel chunk c0)
   // which of this lane's halo elements are real activations in the image staged last (PRE: the others must stay zero)

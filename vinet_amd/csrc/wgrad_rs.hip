@@ -630,10 +630,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rs4_kernel(const WgradRsArg
       // works is free, what is issued in front of it is not).  Branch-free: rows past the image select the zero page by masks.
       auto issue_dma = [&](int j) {
         char* dn = dyb + ((st + 1) & 1) * DROW;
-        const long xin = -(long)(h0 + R + 1 + pr_[j] < H), din = -(long)(h0 + R + pr_[j] < H);      // (wave-uniform masks)
+        const bool xin = h0 + R + 1 + pr_[j] < H, din = h0 + R + pr_[j] < H;      // (wave-uniform)
         int sl = SB + R + 2 + pr_[j]; sl -= sl >= RING ? RING : 0;
-        dma(zero + ((xnext + prx[j] - zero) & xin), xo[j] & (int)xin, ring + sl * XROW + (pw0_[j] + 1) * 128);
-        dma(zero + ((dnext - zero) & din), yo[j] & (int)din, dn + (j * 32 + ct * 8) * 128);
+        const char* xsrc = xnext + prx[j];
+        xsrc = xin ? xsrc : zero;                                                   // (one s_cselect_b64 each; the offsets by mask)
+        const char* dsrc = din ? dnext : zero;
+        dma(xsrc, xo[j] & -(int)xin, ring + sl * XROW + (pw0_[j] + 1) * 128);
+        dma(dsrc, yo[j] & -(int)din, dn + (j * 32 + ct * 8) * 128);
       };
       // ---- MFMAs: per K step the four dy fragments, then per kernel row kh three x fragments and their twelve MFMAs; the
       // reads of a batch are issued before the MFMAs of the batch in front of it ------------------------------------------
