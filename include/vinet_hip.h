@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define VINET_ABI_VERSION 12
+#define VINET_ABI_VERSION 13   /* 13 (round 6): tline 5 / 1 also promise weight slices < 64; entry points unchanged */
 
 enum { VINET_F32 = 0, VINET_BF16 = 1,
        /* conv / weight-gradient descriptors only: fp32 tensors (as VINET_F32), bf16 matrix arithmetic on a two-term split of both

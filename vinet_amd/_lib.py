@@ -16,7 +16,7 @@ F32, BF16 = 0, 1
 F32S = 2     # conv / weight-gradient descriptors: fp32 tensors, split-bf16 matrix arithmetic (include/vinet_hip.h)
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 CONV_GENERIC, CONV_STEM = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class CTensor(C.Structure):
