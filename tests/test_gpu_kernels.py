@@ -270,6 +270,12 @@ HT_CASES = [
     ("htt_pre_128", (1, 5, 14, 24), 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, pre=True, stats=True, act=1)),
     ("htt_acc_slices", (2, 7, 6, 8), 64, 96, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, accumulate=True, in_ld=160, in_coff=32, out_ld=256, out_coff=64)),
     ("htt_pre_cin160", (1, 4, 8, 8), 160, 80, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, pre=True, epi=True)),
+    # round 6: a last half chunk (Cin = 96: the weight DMA's 64-bytes-back redirection) over five temporal groups, four column
+    # tiles at TW = 16, temporal mode with a pending affine and partial tiles, accumulate into a wide slice
+    ("ht_cin96_5t", (1, 5, 9, 32), 96, 192, (5, 3, 3), (5, 1, 1), (0, 1, 1), dict(stats=True, act=1)),
+    ("ht_n384_tw16", (2, 1, 7, 16), 160, 384, (1, 3, 3), (1, 1, 1), (0, 1, 1), dict(epi=True)),
+    ("htt_pre_192", (1, 5, 14, 24), 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, pre=True, stats=True, act=1)),
+    ("htt_acc_slices_192", (2, 7, 6, 8), 64, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0), dict(tline=True, accumulate=True, in_ld=160, in_coff=32, out_ld=448, out_coff=64)),
 ]
 
 
