@@ -180,7 +180,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
-        out["parity"] = parity_block()
+        try:
+            out["parity"] = parity_block()
+        except Exception as e:      # a report file that cannot be read must never cost the bench line
+            out["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
     result_line = json.dumps(out) if rank == 0 else None
     # The JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio when its first communicator
     # comes up, and a piped C stream is only flushed at exit -- after Python's own buffer, i.e. behind the result.  Every
