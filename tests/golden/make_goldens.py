@@ -540,6 +540,12 @@ def main():
     if sys.argv[1:] == ["loss"]:        # regenerate one fixture
         loss_case(RL, 3, out)
         return
+    if sys.argv[1:] == ["round6_blocks"]:    # block goldens for the Inception stages that had none (VERDICT r5 coverage rows a3 / a4 / a5)
+        block_case("mixed_3c", lambda: RU.Mixed_3c(), lambda: O.Mixed_3c(), (1, 256, 4, 14, 24), 16, out, compact=True)
+        block_case("mixed_4b", lambda: RU.Mixed_4b(), lambda: O.Mixed_4b(), (1, 480, 4, 7, 12), 17, out, compact=True)
+        block_case("mixed_4f", lambda: RU.Mixed_4f(), lambda: O.Mixed_4f(), (1, 528, 4, 7, 12), 18, out, compact=True)
+        block_case("mixed_5c", lambda: RU.Mixed_5c(), lambda: O.Mixed_5c(), (2, 832, 2, 7, 12), 19, out, compact=True)
+        return
     if sys.argv[1:2] == ["round6"]:      # the reference's training loop as a loss trajectory
         trajectory_case(RM, RL, 61, out, steps=int(sys.argv[2]) if len(sys.argv) > 2 else 48)
         return

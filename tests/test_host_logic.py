@@ -42,6 +42,14 @@ def test_mixed_5b_block_at_4x7x12(mode):
     MC.block_case_compact("mixed_5b", mode, CPU, 2e-4, 2e-4)
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["mixed_3c", "mixed_4b", "mixed_4f", "mixed_5c"])
+def test_more_inception_blocks_train_mode(name):
+    """round 6: compact goldens from the reference for the Inception stages that had none: the engine
+    on the CPU model of the C ABI, training mode (BatchNorm statistics, every gradient)"""
+    MC.block_case_compact(name, "train", CPU, 2e-4, 2e-4)
+
+
 def test_weight_shared_conv_gradients():
     """one ConvPlan run twice in a backward: one unpack job per weight-gradient workspace (engine.Ctx.flush_unpack)"""
     MC.weight_shared_case(torch.device("cpu"), E.F32, 2e-4)

@@ -27,6 +27,35 @@ BLOCKS = {
 }
 
 
+COMPACT_BLOCKS = {"mixed_3c": lambda: O.Mixed_3c(), "mixed_4b": lambda: O.Mixed_4b(), "mixed_4f": lambda: O.Mixed_4f(),
+                  "mixed_5c": lambda: O.Mixed_5c(), "mixed_5b": lambda: O.Mixed_5b()}
+
+
+@pytest.mark.parametrize("name", list(COMPACT_BLOCKS))
+def test_compact_inception_blocks(name):
+    """the oracle against the reference's compact block goldens (strided samples + L2 norms: make_goldens.py _compact): Mixed_3c / 4b /
+    4f / 5c (round 6) and 5b (round 4), eval and train mode, outputs, input gradient and every parameter gradient"""
+    z, meta = G.load("block_" + name)
+    m = COMPACT_BLOCKS[name]()
+    sd = synth.synth_state_dict(m.state_dict(), meta["seed"])
+    x = synth.normal("x_" + name, tuple(meta["in_shape"]), meta["seed"])
+    for mode in ("eval", "train"):
+        m.load_state_dict(sd)
+        m.train(mode == "train")
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        proj = synth.normal("proj_" + name, tuple(y.shape), meta["seed"])
+        m.zero_grad()
+        (y * proj).sum().backward()
+        got = {"y": y.detach(), "gx": xi.grad}
+        got.update({"g:" + k: p.grad for k, p in m.named_parameters()})
+        for k, t in got.items():
+            key = mode + "_" + k
+            stride = int(z[key + "#stride"])
+            np.testing.assert_allclose(t.reshape(-1)[::stride].numpy(), z[key], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(float(t.double().norm()), float(z[key + "#norm"]), rtol=1e-6)
+
+
 @pytest.mark.parametrize("name", list(BLOCKS))
 def test_blocks(name):
     z, meta = G.load("block_" + name)
