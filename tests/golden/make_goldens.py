@@ -109,7 +109,7 @@ def block_case(name, make_ref, make_ora, in_shape, seed, out, compact=False):
             proj = synth.normal("proj_" + name, tuple(y.shape), seed)
             m.zero_grad()
             (y * proj).sum().backward()
-            outs.append((y.detach(), xi.grad.detach(), {k: v.grad.detach().clone() for k, v in m.named_parameters()},
+            outs.append((y.detach(), xi.grad.detach(), {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None},   # (SoundNet's two heads get none)
                          {k: v.detach().clone() for k, v in m.state_dict().items()}))
         (y_r, gx_r, gp_r, st_r), (y_o, gx_o, gp_o, st_o) = outs
         _check("%s/%s/y" % (name, mode), y_r, y_o, meta)
@@ -545,6 +545,9 @@ def main():
         block_case("mixed_4b", lambda: RU.Mixed_4b(), lambda: O.Mixed_4b(), (1, 480, 4, 7, 12), 17, out, compact=True)
         block_case("mixed_4f", lambda: RU.Mixed_4f(), lambda: O.Mixed_4f(), (1, 528, 4, 7, 12), 18, out, compact=True)
         block_case("mixed_5c", lambda: RU.Mixed_5c(), lambda: O.Mixed_5c(), (2, 832, 2, 7, 12), 19, out, compact=True)
+        return
+    if sys.argv[1:] == ["round6_soundnet"]:  # the audio branch on its own (row a9): model.py:746-825, eval + train mode, every gradient
+        block_case("soundnet", lambda: RM.SoundNet(), lambda: O.SoundNet(), (2, 1, 70560, 1), 20, out, compact=True)
         return
     if sys.argv[1:2] == ["round6"]:      # the reference's training loop as a loss trajectory
         trajectory_case(RM, RL, 61, out, steps=int(sys.argv[2]) if len(sys.argv) > 2 else 48)

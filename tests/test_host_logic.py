@@ -43,7 +43,7 @@ def test_mixed_5b_block_at_4x7x12(mode):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name", ["mixed_3c", "mixed_4b", "mixed_4f", "mixed_5c"])
+@pytest.mark.parametrize("name", ["mixed_3c", "mixed_4b", "mixed_4f", "mixed_5c", "soundnet"])
 def test_more_inception_blocks_train_mode(name):
     """round 6: compact goldens from the reference for the Inception stages that had none: the engine
     on the CPU model of the C ABI, training mode (BatchNorm statistics, every gradient)"""
