@@ -546,6 +546,9 @@ def main():
         block_case("mixed_4f", lambda: RU.Mixed_4f(), lambda: O.Mixed_4f(), (1, 528, 4, 7, 12), 18, out, compact=True)
         block_case("mixed_5c", lambda: RU.Mixed_5c(), lambda: O.Mixed_5c(), (2, 832, 2, 7, 12), 19, out, compact=True)
         return
+    if sys.argv[1:] == ["round6_decoder32"]:  # the headline configuration's decoder on its own (row a7: model.py:251-311)
+        decoder_case(RM, 24, out, clips=32)
+        return
     if sys.argv[1:] == ["round6_soundnet"]:  # the audio branch on its own (row a9): model.py:746-825, eval + train mode, every gradient
         block_case("soundnet", lambda: RM.SoundNet(), lambda: O.SoundNet(), (2, 1, 70560, 1), 20, out, compact=True)
         return

@@ -177,7 +177,7 @@ def decoder_case(clips, dev, ftol=2e-5, gtol=3e-4):
     (model.py:375-435, 313-373, 437-498; the 48-frame tail has a biased (3,1,1) conv, model.py:466)."""
     from vinet_amd import model as VM
     z, meta = G.load("decoder%d" % clips)
-    m = {8: VM.DecoderConvUp8, 16: VM.DecoderConvUp16, 48: VM.DecoderConvUp48}[clips]()
+    m = {8: VM.DecoderConvUp8, 16: VM.DecoderConvUp16, 48: VM.DecoderConvUp48, 32: VM.DecoderConvUp}[clips]()
     m.load_state_dict(G.state_dict_for(m, meta["seed"], z, meta))
     m = m.to(dev)
     ys = [synth.normal("dec_y%d" % i, tuple(s), meta["seed"]).abs().to(dev).requires_grad_(True) for i, s in enumerate(meta["shapes"])]

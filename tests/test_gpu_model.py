@@ -114,9 +114,9 @@ def test_losses():
     MC.losses_case(DEV)
 
 
-@pytest.mark.parametrize("clips", [8, 16, 48])
+@pytest.mark.parametrize("clips", [8, 16, 32, 48])
 def test_decoders_fp32(clips):
-    """DecoderConvUp8 / 16 / 48 against the reference's output, input gradients and parameter gradients"""
+    """DecoderConvUp8 / 16 / 48 and the 32-frame DecoderConvUp (the headline configuration's, round 6) against the reference's output, input gradients and parameter gradients"""
     E.set_default_dtype("fp32")
     MC.decoder_case(clips, DEV)
 

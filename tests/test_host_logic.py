@@ -85,7 +85,7 @@ def test_decoder8_forward_backward():
     MC.decoder8_case(CPU)
 
 
-@pytest.mark.parametrize("clips", [16, 48])
+@pytest.mark.parametrize("clips", [16, 32, 48])
 def test_decoder16_48_forward_backward(clips):
     """the clip-length specific decoder tails (model.py:339-346, 463-469; the 48-frame one has a biased (3,1,1) conv)"""
     MC.decoder_case(clips, CPU)

@@ -95,11 +95,12 @@ def test_losses():
         assert abs(float(O.kldiv(s, g.double())) - float(z["%s_kldiv_gt64" % tag])) < 1e-12
 
 
-@pytest.mark.parametrize("clips", [8, 16, 48])
+@pytest.mark.parametrize("clips", [8, 16, 32, 48])
 def test_decoders(clips):
-    """DecoderConvUp8 / 16 / 48 (model.py:375-435, 313-373, 437-498) against the reference's outputs and gradients"""
+    """DecoderConvUp8 / 16 / 48 (model.py:375-435, 313-373, 437-498) and the 32-frame DecoderConvUp (model.py:251-311, round 6) against
+    the reference's outputs and gradients"""
     z, meta = G.load("decoder%d" % clips)
-    m = {8: O.DecoderConvUp8, 16: O.DecoderConvUp16, 48: O.DecoderConvUp48}[clips]()
+    m = {8: O.DecoderConvUp8, 16: O.DecoderConvUp16, 48: O.DecoderConvUp48, 32: O.DecoderConvUp}[clips]()
     sd = G.state_dict_for(m, meta["seed"], z, meta)
     m.load_state_dict(sd)
     ys = [synth.normal("dec_y%d" % i, tuple(s), meta["seed"]).abs().requires_grad_(True) for i, s in enumerate(meta["shapes"])]
