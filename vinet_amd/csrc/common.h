@@ -171,6 +171,17 @@ VN_DEV void lds_dma16_asm(const char* src, char* lds_dst) {
 }
 #pragma clang diagnostic pop
 
+// 16-byte non-temporal load / store (the compiler merges the four dwords into one dwordx4 with the nt bit): for streaming passes over
+// GB-sized tensors that nothing re-reads before they have left every cache
+VN_DEV uint4 ld16_nt(const void* p) {
+  const uint32_t* q = (const uint32_t*)p;
+  return make_uint4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
+}
+VN_DEV void st16_nt(void* p, uint4 v) {
+  uint32_t* q = (uint32_t*)p;
+  __builtin_nontemporal_store(v.x, q); __builtin_nontemporal_store(v.y, q + 1); __builtin_nontemporal_store(v.z, q + 2); __builtin_nontemporal_store(v.w, q + 3);
+}
+
 // MFMA with the accumulator PINNED in the AGPR file.  With the builtin, hipcc keeps the
 // accumulators of an address-heavy pipelined loop in VGPRs and spills/reloads all of them
 // through AGPRs every iteration (2 x 96 v_accvgpr moves per 24 MFMAs measured); an asm
