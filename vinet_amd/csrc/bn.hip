@@ -158,8 +158,12 @@ __global__ __launch_bounds__(256) VN_NO_PK_F32 void channel_reduce8_kernel(TView
           const long v = vq + (long)u * R;
           ok[u] = v < v1;
           if (ok[u]) {
-            ld8<T>((const T*)x.p + vox_lin(x, v) + g * 8, xv[u]);
-            if (MODE == 1) ld8<T>((const T*)dz.p + vox_lin(dz, v) + g * 8, gv[u]);
+            if (MODE == 1) {      // (the backward reduce pass: both tensors are GBs and come back a pass later -- non-temporal)
+              ld8_nt<T>((const T*)x.p + vox_lin(x, v) + g * 8, xv[u]);
+              ld8_nt<T>((const T*)dz.p + vox_lin(dz, v) + g * 8, gv[u]);
+            } else {
+              ld8<T>((const T*)x.p + vox_lin(x, v) + g * 8, xv[u]);
+            }
           }
         }
 #pragma unroll
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(TView dz, TView x, A
         const long v = vq + (long)u * R;
         ok[u] = v < v1;
         if (ok[u]) {
-          ld8<T>((const T*)x.p + vox_lin(x, v) + g * 8, xv[u]);
+          ld8_nt<T>((const T*)x.p + vox_lin(x, v) + g * 8, xv[u]);      // (z is dead after this pass; dx and its planes are read a pass later)
           ld8<T>((const T*)dz.p + vox_lin(dz, v) + g * 8, gv[u]);
         }
       }
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(TView dz, TView x, A
           if (fwd.relu && !(fmaf(xv[u][e], A[e], sh[e]) > 0.f)) gg = 0.f;
           o[e] = fmaf(A[e], gg, fmaf(Bc[e], xv[u][e], D[e]));
         }
-        st8<T>((T*)dx.p + vox_lin(dx, vq + (long)u * R) + g * 8, o);
+        st8_nt<T>((T*)dx.p + vox_lin(dx, vq + (long)u * R) + g * 8, o);
         if constexpr (SPLIT) {
           uint32_t h[4], l[4];
 #pragma unroll
@@ -550,8 +554,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(TView dz, TView x, A
             h[e] = pack2bf(o[2 * e], o[2 * e + 1]);
             l[e] = pack2bf(o[2 * e] - __uint_as_float(h[e] << 16), o[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u));
           }
-          *(uint4*)((bf16_t*)hi.p + vox_lin(hi, vq + (long)u * R) + g * 8) = make_uint4(h[0], h[1], h[2], h[3]);
-          *(uint4*)((bf16_t*)lo.p + vox_lin(lo, vq + (long)u * R) + g * 8) = make_uint4(l[0], l[1], l[2], l[3]);
+          st16_nt((bf16_t*)hi.p + vox_lin(hi, vq + (long)u * R) + g * 8, make_uint4(h[0], h[1], h[2], h[3]));
+          st16_nt((bf16_t*)lo.p + vox_lin(lo, vq + (long)u * R) + g * 8, make_uint4(l[0], l[1], l[2], l[3]));
         }
       }
     }

@@ -39,6 +39,20 @@ template <> VN_DEV void st8<float>(float* p, const float* f) {
   *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
 }
 template <> VN_DEV void st8<bf16_t>(bf16_t* p, const float* f) { *(uint4*)p = pack16<bf16_t>(f); }
+// non-temporal forms (common.h: ld16_nt / st16_nt) for passes over tensors that have left every cache before they are read again
+template <typename T> VN_DEV void ld8_nt(const T* p, float* f);
+template <> VN_DEV void ld8_nt<float>(const float* p, float* f) {
+  const uint4 a = ld16_nt(p), b = ld16_nt(p + 4);
+  f[0] = __uint_as_float(a.x); f[1] = __uint_as_float(a.y); f[2] = __uint_as_float(a.z); f[3] = __uint_as_float(a.w);
+  f[4] = __uint_as_float(b.x); f[5] = __uint_as_float(b.y); f[6] = __uint_as_float(b.z); f[7] = __uint_as_float(b.w);
+}
+template <> VN_DEV void ld8_nt<bf16_t>(const bf16_t* p, float* f) { unpack16<bf16_t>(ld16_nt(p), f); }
+template <typename T> VN_DEV void st8_nt(T* p, const float* f);
+template <> VN_DEV void st8_nt<float>(float* p, const float* f) {
+  st16_nt(p, make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])));
+  st16_nt(p + 4, make_uint4(__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7])));
+}
+template <> VN_DEV void st8_nt<bf16_t>(bf16_t* p, const float* f) { st16_nt(p, pack16<bf16_t>(f)); }
 static inline bool oct_ok(const VinetTensor& t) {
   return t.ptr && t.C > 0 && (t.C % 8) == 0 && (t.ld % 8) == 0 && t.ld >= t.C && (t.sB % 8) == 0 && (((uintptr_t)t.ptr) % 16) == 0;
 }
