@@ -162,7 +162,10 @@ VN_DEV int4 load_tap(const int4* taps, int i) {
 // transpose-read builtin -- so it puts `s_waitcnt vmcnt(0)` in front of every group of reads: the counted vmcnt(n) pipelines
 // of conv_wgrad_pp / conv_wgrad_dma / conv_wgrad_tf drained completely in every phase (round 6, found in the disassembly;
 // the conv kernels' plain ds_read_b128 do not trigger it).  From asm the compiler sees neither the LDS store nor M0; the
-// waits are the kernels' own counted ones, as designed.  `lds_dst` must be wave-uniform (an SGPR).
+// waits are the kernels' own counted ones, as designed.  `lds_dst` must be wave-uniform (an SGPR).  M0 is written behind the
+// compiler's back (clobber declared; clang warns that M0 is reserved, silenced here): a kernel that uses this helper issues ALL
+// its LDS-DMAs through it and uses nothing else that lives in M0 (no builtin LDS-DMA, no s_movrel, no GWS / sendmsg) -- true of
+// conv_wgrad_pp, conv_wgrad_dma and the PRE instantiations of conv_dma / conv_dma3 / conv_ht, which select it per template.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 VN_DEV void lds_dma16_asm(const char* src, char* lds_dst) {
